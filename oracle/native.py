@@ -1,0 +1,95 @@
+"""ctypes bindings for oracle/csrc/*.c.  TEST INFRASTRUCTURE (see oracle/__init__.py)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def _cpu_has_fma():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("flags"):
+                    fl = line.split()
+                    return "fma" in fl and "avx2" in fl
+    except OSError:
+        pass
+    return False
+
+
+def build():
+    subprocess.run(["make", "-s", "-C", _HERE], check=True)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        name = "liboracle_fma.so" if _cpu_has_fma() else "liboracle_generic.so"
+        path = os.path.join(_HERE, "_build", name)
+        if not os.path.exists(path):
+            build()
+        L = ctypes.CDLL(path)
+        f32p, i64p = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int64)
+        L.oracle_knn_graph.argtypes = [f32p] + [ctypes.c_int] * 5 + [i64p, f32p]
+        L.oracle_knn_graph.restype = ctypes.c_int
+        L.oracle_flat_search_l2.argtypes = [f32p, ctypes.c_int64, f32p, ctypes.c_int, ctypes.c_int,
+                                            ctypes.c_int, ctypes.c_int64, f32p, i64p]
+        L.oracle_flat_search_l2.restype = ctypes.c_int
+        L.oracle_merge_topk.argtypes = [f32p, i64p, ctypes.c_int, ctypes.c_int, ctypes.c_int, f32p, i64p]
+        L.oracle_merge_topk.restype = None
+        L.oracle_row_sqnorm.argtypes = [f32p, ctypes.c_int64, ctypes.c_int, f32p]
+        L.oracle_row_sqnorm.restype = None
+        _LIB = L
+    return _LIB
+
+
+def _f32(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+def _i64(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
+
+
+def knn_graph(x, k, normalize=True, return_dist=False):
+    """x (B,C,N) f32 -> idx int64 (B,N,k) with the arithmetic fixed in csrc/knn_graph.c."""
+    x, xp = _f32(x)
+    B, C, N = x.shape
+    idx = np.empty((B, N, k), dtype=np.int64)
+    dist = np.empty((B, N, k), dtype=np.float32)
+    rc = lib().oracle_knn_graph(xp, B, C, N, k, int(normalize), _i64(idx),
+                                dist.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+    if rc != 0:
+        raise ValueError(f"oracle_knn_graph failed ({rc})")
+    return (idx, dist) if return_dist else idx
+
+
+def flat_search_l2(db, q, k, id_base=0):
+    """db (n,d), q (nq,d) -> (dist f32 (nq,k) ascending, ids int64 (nq,k)); csrc/flat_search.c."""
+    db, dbp = _f32(db)
+    q, qp = _f32(q)
+    n, d = db.shape
+    nq = q.shape[0]
+    od = np.empty((nq, k), dtype=np.float32)
+    oi = np.empty((nq, k), dtype=np.int64)
+    rc = lib().oracle_flat_search_l2(dbp, n, qp, nq, d, k, id_base,
+                                     od.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), _i64(oi))
+    if rc != 0:
+        raise ValueError(f"oracle_flat_search_l2 failed ({rc})")
+    return od, oi
+
+
+def merge_topk(pd, pi):
+    """(P,nq,k) partial lists -> (nq,k)."""
+    pd, pdp = _f32(pd)
+    pi = np.ascontiguousarray(pi, dtype=np.int64)
+    P, nq, k = pd.shape
+    od = np.empty((nq, k), dtype=np.float32)
+    oi = np.empty((nq, k), dtype=np.int64)
+    lib().oracle_merge_topk(pdp, _i64(pi), P, nq, k, od.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), _i64(oi))
+    return od, oi

@@ -1,0 +1,312 @@
+"""CPU tests: the oracle against the golden vectors produced from the reference (make_golden.py)."""
+import numpy as np
+import pytest
+import torch
+
+from _common import (filled_state_dict, golden, hash_ints, hash_normalish, hash_uniform,
+                     knn_margin_mask, manifest_shapes, simclr_inputs)
+from oracle import model as om
+from oracle import native, retrieval
+
+CFG = dict(fs=16000, n_fft=1024, hop_len=512, win_len=1024, n_mels=64, n_frames=32, overlap=0.9, tau=0.05)
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+# ---------------------------------------------------------------- peak extractor
+def test_peak_extractor_matches_reference():
+    g = golden("peak_extractor.npz")
+    shapes = {"peak_extractor.convs.0.weight": (8, 3, 7, 7), "peak_extractor.convs.0.bias": (8,)}
+    from _hashfill import fill_state_dict
+    # the golden module was filled with prefix 'pe' on its own (un-prefixed) key names
+    raw = fill_state_dict({"convs.0.weight": (8, 3, 7, 7), "convs.0.bias": (8,)}, "pe")
+    sd = {"peak_extractor." + k: t(v) for k, v in raw.items()}
+    assert set(sd) == set(shapes)
+    spec = t(40.0 * hash_uniform("in:peak.spec", (2, 64, 32)) - 30.0)
+    spec3 = t(40.0 * hash_uniform("in:peak.spec3", (3, 64, 32)) - 30.0)
+    np.testing.assert_allclose(om.peak_extract(sd, spec).numpy(), g["out"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(om.peak_extract(sd, spec3).numpy(), g["out3"], rtol=1e-5, atol=1e-5)
+
+
+# ---------------------------------------------------------------- k-NN graph
+KNN_SHAPES = [(64, 1024), (128, 512), (256, 256), (512, 128), (24, 100)]
+
+
+@pytest.mark.parametrize("C,N", KNN_SHAPES)
+def test_knn_c_oracle_exact_on_integer_goldens(C, N):
+    """Integer features: every product/sum is exact in f32, so the reference's result is unique up to
+    genuine ties; on tie-free nodes the C oracle must equal the reference index-for-index."""
+    g = golden("knn_graph.npz")
+    xi = hash_ints(f"in:knn.int.{C}.{N}", (2, C, N, 1), -8, 8).astype(np.float32)
+    ok, _ = knn_margin_mask(xi, 3, tol=0.5, normalize=False)
+    assert ok.mean() > 0.9
+    got = native.knn_graph(xi[..., 0], 3, normalize=False)
+    assert np.array_equal(got[ok], g[f"int_{C}_{N}"][ok].astype(np.int64))
+
+
+@pytest.mark.parametrize("C,N", KNN_SHAPES)
+def test_knn_c_oracle_f32_goldens(C, N):
+    """f32 features through normalise + knn: equal to the reference outside near-ties (gap > 1e-5)."""
+    g = golden("knn_graph.npz")
+    xf = hash_normalish(f"in:knn.f32.{C}.{N}", (2, C, N, 1))
+    ok, _ = knn_margin_mask(xf, 3, tol=1e-5)
+    assert ok.mean() > 0.98
+    ref = g[f"f32_{C}_{N}"].astype(np.int64)
+    got = native.knn_graph(xf[..., 0], 3)
+    assert np.array_equal(got[ok], ref[ok])
+    # self is always the first neighbour
+    assert np.array_equal(got[..., 0][ok], np.broadcast_to(np.arange(N), (2, N))[ok])
+    # the torch restatement reproduces the reference exactly (same ops, same host)
+    tor = om.knn_graph_torch(t(xf[..., 0]), 3).numpy()
+    assert np.array_equal(tor[ok], ref[ok])
+
+
+def test_knn_k5_and_ties():
+    g = golden("knn_graph.npz")
+    xf = hash_normalish("in:knn.f32.k5", (2, 32, 200, 1))
+    ok, _ = knn_margin_mask(xf, 5, tol=1e-5)
+    got = native.knn_graph(xf[..., 0], 5)
+    assert np.array_equal(got[ok], g["f32_k5"].astype(np.int64)[ok])
+    # duplicated nodes: ties resolve to the lowest index
+    x = np.zeros((1, 4, 6), dtype=np.float32)
+    x[0, :, :] = np.array([[1, 1, 1, 0, 0, 0]] * 4, dtype=np.float32)
+    x[0, 0, 3:] = 1.0
+    idx = native.knn_graph(x, 3, normalize=False)
+    assert idx[0, 0].tolist() == [0, 1, 2] and idx[0, 2].tolist() == [0, 1, 2]
+    assert idx[0, 4].tolist() == [3, 4, 5]
+
+
+# ---------------------------------------------------------------- gather / MRConv
+def test_gather_and_max_relative():
+    g = golden("mrconv.npz")
+    B, C, N, K = 2, 8, 64, 3
+    x = t(hash_normalish("in:mr.x", (B, C, N, 1)))[..., 0]
+    idx = hash_ints("in:mr.idx", (B, N, K), 0, N - 1).astype(np.int64)
+    idx[:, :, 0] = np.arange(N)[None, :]
+    idx = t(idx)
+    np.testing.assert_array_equal(om.gather_nodes(x, idx).numpy(), g["sel"])
+    xr = x.clone().requires_grad_(True)
+    inter = om.max_relative(xr, idx)
+    np.testing.assert_array_equal(inter.detach().numpy(), g["inter"][..., 0])
+    inter.backward(t(hash_normalish("in:mr.gi", (B, 2 * C, N, 1)))[..., 0])
+    np.testing.assert_allclose(xr.grad.numpy(), g["dx_inter"][..., 0], rtol=1e-6, atol=1e-6)
+
+
+def test_mrconv_full():
+    g = golden("mrconv.npz")
+    B, C, N, K = 2, 8, 64, 3
+    shapes = {"nn.0.weight": (16, 4, 1, 1), "nn.0.bias": (16,), "nn.1.weight": (16,), "nn.1.bias": (16,),
+              "nn.1.running_mean": (16,), "nn.1.running_var": (16,), "nn.1.num_batches_tracked": ()}
+    sd = filled_state_dict(shapes, "mr", requires_grad=True)
+    x = t(hash_normalish("in:mr.x", (B, C, N, 1))).requires_grad_(True)
+    idx = hash_ints("in:mr.idx", (B, N, K), 0, N - 1).astype(np.int64)
+    idx[:, :, 0] = np.arange(N)[None, :]
+    m = om.max_relative(x[..., 0], t(idx)).unsqueeze(-1)
+    y = torch.relu(om._bn(sd, "nn.1", om._conv1x1(sd, "nn.0", m, groups=4), True))
+    np.testing.assert_allclose(y.detach().numpy(), g["y"], rtol=1e-5, atol=1e-5)
+    y.backward(t(hash_normalish("in:mr.gy", tuple(y.shape))))
+    np.testing.assert_allclose(x.grad.numpy(), g["dx"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(sd["nn.0.weight"].grad.numpy(), g["dw"], rtol=1e-4, atol=1e-5)
+
+
+# ---------------------------------------------------------------- Grapher + FFN block
+def test_block_train_eval():
+    g = golden("block.npz")
+    C, N = 16, 64
+    keys = [str(k) for k in g["keys"]]
+    ref_shapes = {
+        "fc1.0.weight": (C, C, 1, 1), "fc1.0.bias": (C,), "fc2.0.weight": (C, 2 * C, 1, 1), "fc2.0.bias": (C,),
+        "graph_conv.gconv.nn.0.weight": (2 * C, C // 2, 1, 1), "graph_conv.gconv.nn.0.bias": (2 * C,)}
+    shapes = {}
+    for k in keys:
+        leaf = k.rsplit(".", 1)[-1]
+        if leaf == "relative_pos":
+            continue
+        body = k.split(".", 1)[1]
+        if k.startswith("0.") and body in ref_shapes:
+            shapes[k] = ref_shapes[body]
+        elif k in ("1.fc1.0.weight",):
+            shapes[k] = (4 * C, C, 1, 1)
+        elif k in ("1.fc2.0.weight",):
+            shapes[k] = (C, 4 * C, 1, 1)
+        elif leaf == "num_batches_tracked":
+            shapes[k] = ()
+        else:                                             # BN vectors
+            width = {"0.fc1.1": C, "0.fc2.1": C, "0.graph_conv.gconv.nn.1": 2 * C,
+                     "1.fc1.1": 4 * C, "1.fc2.1": C}[k.rsplit(".", 1)[0]]
+            shapes[k] = (width,)
+    sd = filled_state_dict(shapes, "blk")
+    xb = t(hash_normalish("in:blk.x", (3, C, N, 1)))
+    y = om.ffn(sd, "1.", om.grapher(sd, "0.", xb, 3, True), True)
+    np.testing.assert_allclose(y.numpy(), g["y_train"], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(sd["0.fc1.1.running_mean"].numpy(), g["fc1_running_mean"], rtol=1e-5, atol=1e-6)
+    y = om.ffn(sd, "1.", om.grapher(sd, "0.", xb, 3, False), False)
+    np.testing.assert_allclose(y.numpy(), g["y_eval"], rtol=2e-5, atol=2e-5)
+
+
+# ---------------------------------------------------------------- full model
+def test_manifest_schema():
+    shapes = manifest_shapes()
+    assert len(shapes) == 443
+    assert shapes["encoder.backbone.0.0.graph_conv.gconv.nn.0.weight"] == (128, 32, 1, 1)
+    assert shapes["encoder.backbone.12.conv.0.weight"] == (512, 256, 3, 3)
+    assert shapes["encoder.backbone.0.0.relative_pos"] == (1, 1024, 1024)
+    assert shapes["encoder.backbone.13.0.relative_pos"] == (1, 16, 16)
+    n_train = sum(int(np.prod(s)) for k, s in shapes.items()
+                  if k.rsplit(".", 1)[-1] in ("weight", "bias"))
+    assert n_train == 18367264                                   # SURVEY.md section 2a [probe]
+
+
+def test_simclr_forward_train_and_eval():
+    g = golden("simclr_forward.npz")
+    sd = filled_state_dict()
+    xi, xj = simclr_inputs()
+    with torch.no_grad():
+        h_i, h_j, z_i, z_j = om.simclr_forward(sd, xi, xj, True)
+    np.testing.assert_allclose(h_i.numpy(), g["h_i"], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(z_i.numpy(), g["z_i"], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(z_j.numpy(), g["z_j"], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(sd["encoder.stem.1.running_mean"].numpy(), g["stem_running_mean"],
+                               rtol=1e-5, atol=1e-6)
+    with torch.no_grad():
+        eh_i, _, ez_i, ez_j = om.simclr_forward(sd, xi, xj, False)
+    np.testing.assert_allclose(ez_i.numpy(), g["eval_z_i"], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(ez_j.numpy(), g["eval_z_j"], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(eh_i.numpy(), g["eval_h_i"], rtol=1e-3, atol=1e-4)
+
+
+def test_simclr_forward_with_c_knn_graph():
+    """Swapping torch's k-NN for the fully specified C oracle does not change the embeddings beyond
+    f32 noise on this input (no near-tie flips): ties the two k-NN statements together end to end."""
+    g = golden("simclr_forward.npz")
+    sd = filled_state_dict()
+    xi, xj = simclr_inputs()
+
+    def c_knn(x, k):
+        return torch.from_numpy(native.knn_graph(x.detach().numpy(), k))
+    with torch.no_grad():
+        _, _, z_i, z_j = om.simclr_forward(sd, xi, xj, True, idx_fn=c_knn)
+    np.testing.assert_allclose(z_i.numpy(), g["z_i"], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(z_j.numpy(), g["z_j"], rtol=1e-3, atol=1e-5)
+
+
+# ---------------------------------------------------------------- NT-Xent
+@pytest.mark.parametrize("B", [2, 8, 32])
+def test_ntxent_value_and_grads(B):
+    g = golden("ntxent.npz")
+    for fn in (om.ntxent_loop, om.ntxent):
+        a = t(g[f"zi_{B}"]).clone().requires_grad_(True)
+        b = t(g[f"zj_{B}"]).clone().requires_grad_(True)
+        loss = fn(a, b, 0.05)
+        loss.backward()
+        np.testing.assert_allclose(loss.item(), g[f"loss_{B}"], rtol=2e-6)
+        np.testing.assert_allclose(a.grad.numpy(), g[f"dzi_{B}"], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(b.grad.numpy(), g[f"dzj_{B}"], rtol=1e-4, atol=1e-6)
+
+
+def test_ntxent_unnormalised_inputs():
+    g = golden("ntxent.npz")
+    a = t(0.3 * hash_normalish("in:nt.raw.zi", (6, 16))).requires_grad_(True)
+    b = t(0.3 * hash_normalish("in:nt.raw.zj", (6, 16))).requires_grad_(True)
+    loss = om.ntxent(a, b, 0.5)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), g["loss_raw"], rtol=2e-6)
+    np.testing.assert_allclose(a.grad.numpy(), g["dzi_raw"], rtol=1e-4, atol=1e-7)
+
+
+# ---------------------------------------------------------------- one train step
+def test_train_step():
+    g = golden("train_step.npz")
+    sd = filled_state_dict(requires_grad=True)
+    params = om.trainable(sd)
+    assert sum(p.numel() for p in params.values()) == 18367264
+    opt = torch.optim.Adam(list(params.values()), lr=8e-5)
+    xi, xj = simclr_inputs()
+    # keep grads for inspection: run the step manually
+    opt.zero_grad()
+    _, _, z_i, z_j = om.simclr_forward(sd, xi, xj, True)
+    loss = om.ntxent(z_i, z_j, 0.05)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), g["loss"], rtol=1e-4)
+    probe = [str(p) for p in g["probe"]]
+    gn = np.array([sd[k].grad.double().norm().item() for k in probe])
+    np.testing.assert_allclose(gn, g["grad_norm"], rtol=5e-3)
+    for k in probe[:2]:
+        np.testing.assert_allclose(sd[k].grad.numpy(), g["grad:" + k], rtol=5e-3, atol=1e-6)
+    opt.step()
+    ps = np.array([sd[k].detach().double().sum().item() for k in probe])
+    np.testing.assert_allclose(ps, g["param_sum_after"], rtol=1e-5, atol=1e-3)
+
+
+# ---------------------------------------------------------------- log-mel (parity unpinned vs torchaudio)
+def _logmel_numpy(x, n_fft=1024, hop=512, n_mels=64, fs=16000):
+    """Independent float64 numpy implementation of the published definition."""
+    x = np.asarray(x, dtype=np.float64)
+    pad = n_fft // 2
+    xp = np.pad(x, (pad, pad), mode="reflect")
+    n_frames = 1 + len(x) // hop
+    win = 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(n_fft) / n_fft)          # periodic hann
+    frames = np.stack([xp[i * hop:i * hop + n_fft] * win for i in range(n_frames)])
+    power = np.abs(np.fft.rfft(frames, axis=1)) ** 2                         # (frames, 513)
+    freqs = np.linspace(0, fs // 2, n_fft // 2 + 1)
+    mmax = 2595.0 * np.log10(1.0 + (fs / 2) / 700.0)
+    fpts = 700.0 * (10.0 ** (np.linspace(0, mmax, n_mels + 2) / 2595.0) - 1.0)
+    fb = np.zeros((n_fft // 2 + 1, n_mels))
+    for m in range(n_mels):
+        lo, ce, hi = fpts[m], fpts[m + 1], fpts[m + 2]
+        fb[:, m] = np.maximum(0, np.minimum((freqs - lo) / (ce - lo), (hi - freqs) / (hi - ce)))
+    return 10.0 * np.log10(np.maximum(power @ fb, 1e-10)).T                  # (n_mels, frames)
+
+
+def test_logmel_against_independent_numpy():
+    x = 0.1 * hash_normalish("in:logmel.x", (3, 16000))
+    got = om.logmel(t(x), CFG).numpy()
+    assert got.shape == (3, 64, 32)
+    for b in range(3):
+        np.testing.assert_allclose(got[b], _logmel_numpy(x[b]), rtol=0, atol=2e-3)   # dB
+    fb = om.mel_filterbank().numpy()
+    assert fb.shape == (513, 64) and int((fb > 0).sum()) in (1000, 1001)     # sparse: ~3-42 bins per band
+
+
+def test_val_segments_shape():
+    x = 0.1 * hash_normalish("in:logmel.track", (1, 16000 * 5))
+    seg = om.val_segments(t(x), CFG)
+    frames = 1 + 80000 // 512
+    assert seg.shape == ((frames - 32) // 3 + 1, 64, 32)
+    full = om.logmel(t(x[0]), CFG)
+    np.testing.assert_array_equal(seg[2].numpy(), full[:, 6:38].numpy())
+
+
+# ---------------------------------------------------------------- flat search + eval (parity unpinned vs faiss)
+def test_flat_search_against_f64_and_ties():
+    db = hash_normalish("in:fs.db", (3000, 128)); db /= np.linalg.norm(db, axis=1, keepdims=True)
+    q = db[100:141] + 0.05 * hash_normalish("in:fs.q", (41, 128)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    d, i = native.flat_search_l2(db, q, 20)
+    d64, i64 = retrieval.exact_search_f64(db, q, 20)
+    assert np.array_equal(i[:, 0], np.arange(100, 141))
+    gap_ok = np.diff(d64, axis=1).min(axis=1) > 1e-5
+    assert gap_ok.mean() > 0.9
+    assert np.array_equal(i[gap_ok], i64[gap_ok])
+    np.testing.assert_allclose(d, d64, atol=5e-6)
+    # duplicates: lowest id first; k > n: padded with -1 / inf
+    dup = np.tile(db[:3], (4, 1)).astype(np.float32)
+    d, i = native.flat_search_l2(dup, db[:1], 5)
+    assert i[0].tolist()[:4] == [0, 3, 6, 9]
+    d, i = native.flat_search_l2(db[:3], db[:2], 5)
+    assert i[0, 3:].tolist() == [-1, -1] and np.isinf(d[0, 3:]).all()
+    # sharded search + merge == unsharded
+    parts = [native.flat_search_l2(db[s:s + 1000], q, 20, id_base=s) for s in (0, 1000, 2000)]
+    md, mi = native.merge_topk(np.stack([p[0] for p in parts]), np.stack([p[1] for p in parts]))
+    d, i = native.flat_search_l2(db, q, 20)
+    assert np.array_equal(mi, i) and np.array_equal(md, d)
+
+
+def test_eval_l2_planted_sequences():
+    dummy = hash_normalish("in:ev.dummy", (500, 128)); dummy /= np.linalg.norm(dummy, axis=1, keepdims=True)
+    db = hash_normalish("in:ev.db", (200, 128)); db /= np.linalg.norm(db, axis=1, keepdims=True)
+    query = db + 0.04 * hash_normalish("in:ev.noise", (200, 128)); query /= np.linalg.norm(query, axis=1, keepdims=True)
+    rates, raw, top1 = retrieval.eval_l2(query, db, dummy, np.arange(0, 150, 10), [1, 3, 5], k_probe=20)
+    assert rates.shape == (4, 3) and raw.shape == (15, 12)
+    assert (rates[0] == 100.0).all() and (top1[:, 0] == np.arange(0, 150, 10) + 500).all()
