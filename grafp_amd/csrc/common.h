@@ -1,0 +1,50 @@
+// common.h -- shared device/host helpers for libgrafp_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "grafp_hip.h"
+
+namespace grafp {
+
+void set_error(const char *fmt, ...);
+
+// MI355X: 8 XCDs with private L2s; block b is dispatched to XCD b % 8 (observed, speed only).
+// Remap so that each XCD owns one CONTIGUOUS range of logical tiles: tiles that share operand
+// panels (all query tiles of one clip, all query groups over one database slice) then hit the same L2.
+// Bijective for every n (cdna_hip_programming.md, "XCD swizzle must be bijective").
+__device__ __forceinline__ int xcd_remap(int bid, int n) {
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int q = n >> 3, r = n & 7;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + slot;
+}
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// exact-f32 MFMA: D(32x32) += A(32x2) * B(2x32); lane l supplies A[l&31][l>>5] and B[l>>5][l&31];
+// D[row][col]: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).  Bitwise a k-ordered fmaf chain.
+__device__ __forceinline__ f32x16 mfma32x32x2(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ int mfma_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
+
+}  // namespace grafp
+
+#define GRAFP_REQUIRE(cond, ...)              \
+    do {                                      \
+        if (!(cond)) {                        \
+            grafp::set_error(__VA_ARGS__);    \
+            return GRAFP_ERR_ARG;             \
+        }                                     \
+    } while (0)
+
+#define GRAFP_CHECK_LAUNCH(what)                                                      \
+    do {                                                                              \
+        hipError_t e__ = hipGetLastError();                                           \
+        if (e__ != hipSuccess) {                                                      \
+            grafp::set_error("%s: launch failed: %s", what, hipGetErrorString(e__));  \
+            return GRAFP_ERR_LAUNCH;                                                  \
+        }                                                                             \
+    } while (0)

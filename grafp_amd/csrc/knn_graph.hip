@@ -1,0 +1,228 @@
+// knn_graph.hip -- dynamic k-NN graph build (K3+K4+K5 of SURVEY.md section 2a), gfx950.
+//
+// Replaces DenseDilatedKnnGraph.forward + dense_knn_matrix + pairwise_distance
+// (/root/reference/encoder/gcn_lib/torch_edge.py:270-284, 70-103, 7-18): the reference materialises
+// the (B,N,N) distance matrix (1.07 GB at B=256, N=1024) and runs torch.topk over it; here a
+// workgroup owns 128 query nodes of one clip, streams the clip's candidates through LDS in
+// 32-channel x 128-node tiles, forms the Gram tile with exact-f32 MFMA (v_mfma_f32_32x32x2_f32:
+// bitwise a c-ordered fmaf chain, which is the order oracle/csrc/knn_graph.c fixes) and keeps a
+// per-lane top-k in registers.  Only (B,N,k) indices are written.
+//
+// Roofline: 2*N^2*C flops per clip against 4*C*N + 8*k*N bytes (63-468 flop/B) -> bound by the f32
+// matrix rate (157.3 TFLOP/s), not HBM.  See DESIGN.md "knn_topk_kernel".
+#include <math.h>
+
+#include "common.h"
+
+namespace grafp {
+
+constexpr int TQ = 128;  // query nodes per workgroup (32 per wave)
+constexpr int TR = 128;  // candidate nodes per pass
+constexpr int KC = 32;   // channels per LDS chunk
+
+// ---- pass 1: channel-L2 normalisation (torch_edge.py:281) and squared norms -------------------
+// One thread per node; lanes run over consecutive nodes so every load/store is coalesced.
+__global__ __launch_bounds__(256) void knn_normalize_kernel(const float *__restrict__ x, float *__restrict__ xn,
+                                                            float *__restrict__ sq, int C, int N, int normalize) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (n >= N) return;
+    const float *xb = x + (size_t)b * C * N + n;
+    float *ob = xn + (size_t)b * C * N + n;
+    float den = 1.0f;
+    if (normalize) {
+        float ss = 0.0f;
+        for (int c = 0; c < C; ++c) {
+            const float v = xb[(size_t)c * N];
+            ss = __builtin_fmaf(v, v, ss);
+        }
+        den = fmaxf(__fsqrt_rn(ss), 1e-12f);
+    }
+    float q = 0.0f;
+    for (int c = 0; c < C; ++c) {
+        float v = xb[(size_t)c * N];
+        if (normalize) v = __fdiv_rn(v, den);
+        ob[(size_t)c * N] = v;
+        q = __builtin_fmaf(v, v, q);
+    }
+    sq[(size_t)b * N + n] = q;
+}
+
+// ---- pass 2: Gram tiles + top-k ----------------------------------------------------------------
+template <int K>
+struct TopK {
+    float d[K];
+    int i[K];
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int t = 0; t < K; ++t) {
+            d[t] = INFINITY;
+            i[t] = 0x7fffffff;
+        }
+    }
+    // Compare-exchange chain (min/max + index selects, branch-free): the new element bubbles down,
+    // displacing larger entries.  Candidates arrive in ascending index order within a lane, so strict
+    // '<' keeps the lower index on ties.
+    __device__ __forceinline__ void push_ascending(float v, int vi) {
+#pragma unroll
+        for (int t = 0; t < K; ++t) {
+            const bool lt = v < d[t];
+            const float lo = fminf(v, d[t]), hi = fmaxf(v, d[t]);
+            const int ilo = lt ? vi : i[t], ihi = lt ? i[t] : vi;
+            d[t] = lo; i[t] = ilo;
+            v = hi; vi = ihi;
+        }
+    }
+    // arbitrary order: full (distance, index) lexicographic comparison
+    __device__ __forceinline__ void push_lex(float v, int vi) {
+#pragma unroll
+        for (int t = 0; t < K; ++t) {
+            const bool lt = v < d[t] || (v == d[t] && vi < i[t]);
+            const float lo = lt ? v : d[t], hi = lt ? d[t] : v;
+            const int ilo = lt ? vi : i[t], ihi = lt ? i[t] : vi;
+            d[t] = lo; i[t] = ilo;
+            v = hi; vi = ihi;
+        }
+    }
+};
+
+// Stage a KC x 128 tile of xn (channels c0.., nodes n0..) into LDS; zero-fill outside (C, N).
+__device__ __forceinline__ void stage_tile(float (*dst)[TR], const float *__restrict__ xb, int C, int N, int c0,
+                                           int n0, int tid, bool vec_ok) {
+#pragma unroll
+    for (int it = 0; it < (KC * TR / 4) / 256; ++it) {
+        const int i = tid + it * 256;
+        const int row = i / (TR / 4), c4 = i % (TR / 4);
+        const int c = c0 + row, n = n0 + c4 * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < C) {
+            const float *src = xb + (size_t)c * N + n;
+            if (vec_ok && n + 3 < N) {
+                v = *reinterpret_cast<const float4 *>(src);
+            } else {
+                if (n + 0 < N) v.x = src[0];
+                if (n + 1 < N) v.y = src[1];
+                if (n + 2 < N) v.z = src[2];
+                if (n + 3 < N) v.w = src[3];
+            }
+        }
+        *reinterpret_cast<float4 *>(&dst[row][c4 * 4]) = v;
+    }
+}
+
+template <int K>
+__global__ __launch_bounds__(256, 2) void knn_topk_kernel(const float *__restrict__ xn, const float *__restrict__ sq,
+                                                          int64_t *__restrict__ idx, int C, int N,
+                                                          int tiles_per_clip, int nblocks) {
+    __shared__ __attribute__((aligned(16))) float sA[KC][TR];  // candidates
+    __shared__ __attribute__((aligned(16))) float sB[KC][TQ];  // queries
+    __shared__ float sSq[TR];
+
+    const int bid = xcd_remap(blockIdx.x, nblocks);
+    const int b = bid / tiles_per_clip;
+    const int q0 = (bid % tiles_per_clip) * TQ;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const float *xb = xn + (size_t)b * C * N;
+    const float *sqb = sq + (size_t)b * N;
+    const bool vec_ok = (N & 3) == 0;
+
+    const int myq = q0 + wave * 32 + l31;
+    const float sq_q = myq < N ? sqb[myq] : 0.0f;
+    TopK<K> best;
+    best.init();
+
+    for (int r0 = 0; r0 < N; r0 += TR) {
+        f32x16 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+        for (int c0 = 0; c0 < C; c0 += KC) {
+            __syncthreads();  // previous chunk (and previous pass's sSq) fully consumed
+            stage_tile(sA, xb, C, N, c0, r0, tid, vec_ok);
+            stage_tile(sB, xb, C, N, c0, q0, tid, vec_ok);
+            if (c0 == 0 && tid < TR) sSq[tid] = (r0 + tid < N) ? sqb[r0 + tid] : INFINITY;
+            __syncthreads();
+#pragma unroll 4
+            for (int kk = 0; kk < KC; kk += 2) {
+                const float bq = sB[kk + half][wave * 32 + l31];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = mfma32x32x2(sA[kk + half][t * 32 + l31], bq, acc[t]);
+            }
+        }
+        // lane holds G[cand][query = myq] for 64 candidates, visited in ascending candidate order
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int loc = t * 32 + mfma_row(r, half);
+                const float d = (sq_q + (-2.0f * acc[t][r])) + sSq[loc];  // +inf beyond N: never inserted
+                best.push_ascending(d, r0 + loc);
+                if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // keep the 64 distances from being hoisted
+            }
+        }
+    }
+    // the two half-waves saw disjoint candidate subsets of the same query: merge them
+    float od[K];
+    int oi[K];
+#pragma unroll
+    for (int t = 0; t < K; ++t) {
+        od[t] = __shfl_xor(best.d[t], 32);
+        oi[t] = __shfl_xor(best.i[t], 32);
+    }
+#pragma unroll
+    for (int t = 0; t < K; ++t) best.push_lex(od[t], oi[t]);
+    if (half == 0 && myq < N) {
+        int64_t *o = idx + ((size_t)b * N + myq) * K;
+#pragma unroll
+        for (int t = 0; t < K; ++t) o[t] = (int64_t)best.i[t];
+    }
+}
+
+template <int K>
+static void launch_topk(const float *xn, const float *sq, int64_t *idx, int B, int C, int N, hipStream_t s) {
+    const int tiles = (N + TQ - 1) / TQ;
+    const int nblocks = B * tiles;
+    hipLaunchKernelGGL(knn_topk_kernel<K>, dim3(nblocks), dim3(256), 0, s, xn, sq, idx, C, N, tiles, nblocks);
+}
+
+}  // namespace grafp
+
+extern "C" size_t grafp_knn_graph_workspace(int B, int C, int N) {
+    if (B <= 0 || C <= 0 || N <= 0) return 0;
+    const size_t xn = ((size_t)B * C * N * sizeof(float) + 255) & ~(size_t)255;
+    const size_t sq = ((size_t)B * N * sizeof(float) + 255) & ~(size_t)255;
+    return xn + sq;
+}
+
+extern "C" int grafp_knn_graph_f32(const float *x, int B, int C, int N, int k, int normalize, int64_t *idx, void *ws,
+                                   size_t ws_bytes, grafp_stream_t stream) {
+    using namespace grafp;
+    GRAFP_REQUIRE(x && idx, "knn_graph: null pointer");
+    GRAFP_REQUIRE(B > 0 && C > 0 && N > 0, "knn_graph: bad shape B=%d C=%d N=%d", B, C, N);
+    GRAFP_REQUIRE(k >= 1 && k <= GRAFP_KNN_MAX_K && k <= N, "knn_graph: k=%d must be in [1, min(N=%d, %d)]", k, N,
+                  GRAFP_KNN_MAX_K);
+    const size_t need = grafp_knn_graph_workspace(B, C, N);
+    if (!ws || ws_bytes < need) {
+        set_error("knn_graph: workspace %zu bytes < required %zu", ws_bytes, need);
+        return GRAFP_ERR_WORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    float *xn = (float *)ws;
+    float *sq = (float *)((char *)ws + (((size_t)B * C * N * sizeof(float) + 255) & ~(size_t)255));
+    hipLaunchKernelGGL(knn_normalize_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, x, xn, sq, C, N, normalize);
+    GRAFP_CHECK_LAUNCH("knn_normalize_kernel");
+    switch (k) {
+        case 1: launch_topk<1>(xn, sq, idx, B, C, N, s); break;
+        case 2: launch_topk<2>(xn, sq, idx, B, C, N, s); break;
+        case 3: launch_topk<3>(xn, sq, idx, B, C, N, s); break;
+        case 4: launch_topk<4>(xn, sq, idx, B, C, N, s); break;
+        case 5: launch_topk<5>(xn, sq, idx, B, C, N, s); break;
+        case 6: launch_topk<6>(xn, sq, idx, B, C, N, s); break;
+        case 7: launch_topk<7>(xn, sq, idx, B, C, N, s); break;
+        default: launch_topk<8>(xn, sq, idx, B, C, N, s); break;
+    }
+    GRAFP_CHECK_LAUNCH("knn_topk_kernel");
+    return GRAFP_OK;
+}

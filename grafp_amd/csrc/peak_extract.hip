@@ -1,0 +1,174 @@
+// peak_extract.hip -- spectrogram -> point-cloud features (K2 of SURVEY.md section 2a), gfx950.
+//
+// Replaces GPUPeakExtractorv2.forward (/root/reference/peak_extractor.py:56-82): amin/amax/sub/div,
+// two cached positional ramps, cat, Conv2d(3->F, 7x7, stride (2,1), pad 3), ReLU, reshape = ~9 launches and a
+// (B,3,64,32) intermediate.  One workgroup per clip: the clip (8 KB) is staged once in LDS, min/max are
+// block-reduced, the zero-padded 3-channel image [T-ramp, F-ramp, (x-min)/(max-min)] is built in LDS and the
+// convolution + ReLU writes the (F, Ho*W) node features directly.  HBM: 8 192 B in, 32 768 B out per clip.
+// A constant clip gives 0/0 = NaN exactly as the reference does.
+#include <math.h>
+
+#include "common.h"
+
+namespace grafp {
+
+constexpr int PK_THREADS = 256;
+
+__device__ __forceinline__ float block_reduce(float v, bool is_max, float *scratch, int tid) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float u = __shfl_xor(v, o);
+        v = is_max ? fmaxf(v, u) : fminf(v, u);
+    }
+    __syncthreads();
+    if ((tid & 63) == 0) scratch[tid >> 6] = v;
+    __syncthreads();
+    float r = scratch[0];
+    for (int w = 1; w < PK_THREADS / 64; ++w) r = is_max ? fmaxf(r, scratch[w]) : fminf(r, scratch[w]);
+    return r;
+}
+
+// Build img[3][HP][WP] (zero padded) in LDS from one clip.  Returns nothing; ends with a barrier.
+__device__ __forceinline__ void build_image(float *img, float *scratch, const float *__restrict__ spec, int H, int W,
+                                            int ph, int pw, const float *__restrict__ t_ramp,
+                                            const float *__restrict__ f_ramp, int tid) {
+    const int HP = H + 2 * ph, WP = W + 2 * pw;
+    float lo = INFINITY, hi = -INFINITY;
+    for (int i = tid; i < H * W; i += PK_THREADS) {
+        const float v = spec[i];
+        lo = fminf(lo, v);
+        hi = fmaxf(hi, v);
+    }
+    lo = block_reduce(lo, false, scratch, tid);
+    hi = block_reduce(hi, true, scratch, tid);
+    const float range = hi - lo;
+    for (int i = tid; i < 3 * HP * WP; i += PK_THREADS) img[i] = 0.0f;
+    __syncthreads();
+    for (int i = tid; i < H * W; i += PK_THREADS) {
+        const int y = i / W, x = i - y * W;
+        const int o = (y + ph) * WP + x + pw;
+        img[o] = t_ramp[x];
+        img[HP * WP + o] = f_ramp[y];
+        img[2 * HP * WP + o] = __fdiv_rn(spec[i] - lo, range);
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(PK_THREADS) void peak_fwd_kernel(const float *__restrict__ spec, int H, int W,
+                                                              const float *__restrict__ weight,
+                                                              const float *__restrict__ bias, int F, int KH, int KW,
+                                                              int sh, int Ho, const float *__restrict__ t_ramp,
+                                                              const float *__restrict__ f_ramp,
+                                                              float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int ph = KH / 2, pw = KW / 2, HP = H + 2 * ph, WP = W + 2 * pw;
+    float *img = reinterpret_cast<float *>(smem);
+    float *sw = img + 3 * HP * WP;          // weights [F][3][KH][KW]
+    float *scratch = sw + F * 3 * KH * KW;  // [4]
+    const int tid = threadIdx.x, b = blockIdx.x;
+    for (int i = tid; i < F * 3 * KH * KW; i += PK_THREADS) sw[i] = weight[i];
+    build_image(img, scratch, spec + (size_t)b * H * W, H, W, ph, pw, t_ramp, f_ramp, tid);
+
+    float *ob = out + (size_t)b * F * Ho * W;
+    for (int i = tid; i < F * Ho * W; i += PK_THREADS) {
+        const int f = i / (Ho * W), r = i - f * (Ho * W);
+        const int y = r / W, x = r - y * W;
+        float acc = bias[f];
+        const float *wf = sw + f * 3 * KH * KW;
+        for (int ci = 0; ci < 3; ++ci)
+            for (int ky = 0; ky < KH; ++ky) {
+                const float *row = img + ci * HP * WP + (y * sh + ky) * WP + x;
+                const float *wr = wf + (ci * KH + ky) * KW;
+                for (int kx = 0; kx < KW; ++kx) acc = __builtin_fmaf(wr[kx], row[kx], acc);
+            }
+        ob[i] = fmaxf(acc, 0.0f);
+    }
+}
+
+// dweight/dbias += over clips b = blockIdx.x, blockIdx.x + gridDim.x, ...   (caller zeroes them)
+__global__ __launch_bounds__(PK_THREADS) void peak_bwd_kernel(const float *__restrict__ spec, int B, int H, int W,
+                                                              int F, int KH, int KW, int sh, int Ho,
+                                                              const float *__restrict__ t_ramp,
+                                                              const float *__restrict__ f_ramp,
+                                                              const float *__restrict__ out,
+                                                              const float *__restrict__ gout,
+                                                              float *__restrict__ dweight, float *__restrict__ dbias) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int ph = KH / 2, pw = KW / 2, HP = H + 2 * ph, WP = W + 2 * pw;
+    const int nW = F * 3 * KH * KW, nPos = Ho * W;
+    float *img = reinterpret_cast<float *>(smem);
+    float *sg = img + 3 * HP * WP;   // masked grad [F][Ho*W]
+    float *sacc = sg + F * nPos;     // [nW + F]
+    float *scratch = sacc + nW + F;  // [4]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < nW + F; i += PK_THREADS) sacc[i] = 0.0f;
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        __syncthreads();
+        build_image(img, scratch, spec + (size_t)b * H * W, H, W, ph, pw, t_ramp, f_ramp, tid);
+        const float *ob = out + (size_t)b * F * nPos, *gb = gout + (size_t)b * F * nPos;
+        for (int i = tid; i < F * nPos; i += PK_THREADS) sg[i] = ob[i] > 0.0f ? gb[i] : 0.0f;
+        __syncthreads();
+        for (int wi = tid; wi < nW + F; wi += PK_THREADS) {
+            float acc = 0.0f;
+            if (wi < nW) {
+                const int f = wi / (3 * KH * KW), r = wi - f * (3 * KH * KW);
+                const int ci = r / (KH * KW), r2 = r - ci * (KH * KW);
+                const int ky = r2 / KW, kx = r2 - ky * KW;
+                const float *g = sg + f * nPos;
+                for (int y = 0; y < Ho; ++y) {
+                    const float *row = img + ci * HP * WP + (y * sh + ky) * WP + kx;
+                    for (int x = 0; x < W; ++x) acc = __builtin_fmaf(g[y * W + x], row[x], acc);
+                }
+            } else {
+                const float *g = sg + (wi - nW) * nPos;
+                for (int p = 0; p < nPos; ++p) acc += g[p];
+            }
+            sacc[wi] += acc;
+        }
+    }
+    __syncthreads();
+    for (int wi = tid; wi < nW + F; wi += PK_THREADS) {
+        if (wi < nW) atomicAdd(&dweight[wi], sacc[wi]);
+        else atomicAdd(&dbias[wi - nW], sacc[wi]);
+    }
+}
+
+}  // namespace grafp
+
+extern "C" int grafp_peak_extract_fwd_f32(const float *spec, int B, int H, int W, const float *weight,
+                                          const float *bias, int F, int KH, int KW, int stride_h,
+                                          const float *t_ramp, const float *f_ramp, float *out,
+                                          grafp_stream_t stream) {
+    using namespace grafp;
+    GRAFP_REQUIRE(spec && weight && bias && t_ramp && f_ramp && out, "peak_extract_fwd: null pointer");
+    GRAFP_REQUIRE(B > 0 && H > 0 && W > 0 && F > 0 && KH > 0 && KW > 0 && stride_h > 0 && (KH & 1) && (KW & 1),
+                  "peak_extract_fwd: bad shape B=%d H=%d W=%d F=%d K=%dx%d stride=%d", B, H, W, F, KH, KW, stride_h);
+    const int ph = KH / 2, pw = KW / 2, Ho = (H + 2 * ph - KH) / stride_h + 1;
+    const size_t lds = ((size_t)3 * (H + 2 * ph) * (W + 2 * pw) + (size_t)F * 3 * KH * KW + 4) * sizeof(float);
+    GRAFP_REQUIRE(lds <= 160 * 1024, "peak_extract_fwd: needs %zu B of LDS (> 160 KiB)", lds);
+    (void)hipFuncSetAttribute((const void *)peak_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(peak_fwd_kernel, dim3(B), dim3(PK_THREADS), lds, (hipStream_t)stream, spec, H, W, weight, bias, F,
+                       KH, KW, stride_h, Ho, t_ramp, f_ramp, out);
+    GRAFP_CHECK_LAUNCH("peak_fwd_kernel");
+    return GRAFP_OK;
+}
+
+extern "C" int grafp_peak_extract_bwd_f32(const float *spec, int B, int H, int W, int F, int KH, int KW, int stride_h,
+                                          const float *t_ramp, const float *f_ramp, const float *out,
+                                          const float *grad_out, float *dweight, float *dbias,
+                                          grafp_stream_t stream) {
+    using namespace grafp;
+    GRAFP_REQUIRE(spec && t_ramp && f_ramp && out && grad_out && dweight && dbias, "peak_extract_bwd: null pointer");
+    GRAFP_REQUIRE(B > 0 && H > 0 && W > 0 && F > 0 && KH > 0 && KW > 0 && stride_h > 0 && (KH & 1) && (KW & 1),
+                  "peak_extract_bwd: bad shape B=%d H=%d W=%d F=%d K=%dx%d stride=%d", B, H, W, F, KH, KW, stride_h);
+    const int ph = KH / 2, pw = KW / 2, Ho = (H + 2 * ph - KH) / stride_h + 1;
+    const size_t lds = ((size_t)3 * (H + 2 * ph) * (W + 2 * pw) + (size_t)F * Ho * W + (size_t)F * 3 * KH * KW + F + 4) *
+                       sizeof(float);
+    GRAFP_REQUIRE(lds <= 160 * 1024, "peak_extract_bwd: needs %zu B of LDS (> 160 KiB)", lds);
+    (void)hipFuncSetAttribute((const void *)peak_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int blocks = B < 256 ? B : 256;
+    hipLaunchKernelGGL(peak_bwd_kernel, dim3(blocks), dim3(PK_THREADS), lds, (hipStream_t)stream, spec, B, H, W, F, KH,
+                       KW, stride_h, Ho, t_ramp, f_ramp, out, grad_out, dweight, dbias);
+    GRAFP_CHECK_LAUNCH("peak_bwd_kernel");
+    return GRAFP_OK;
+}

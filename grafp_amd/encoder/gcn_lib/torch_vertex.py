@@ -1,0 +1,92 @@
+"""Graph convolution blocks (mirror of encoder/gcn_lib/torch_vertex.py for the live 'mr' conv).
+
+MRConv2d's gather -> subtract -> max -> interleave (torch_vertex.py:21-32) is ops.max_relative (one HIP
+kernel forward, one backward); the grouped 1x1 conv + BN + ReLU that follows is a library GEMM.  Edge /
+GraphSAGE / GIN convs are unreachable in the reference (conv is hard-coded to 'mr',
+encoder/graph_encoder.py:123) and are not provided.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ... import ops
+from .._dense import batchnorm, pointwise
+from .pos_embed import get_2d_relative_pos_embed
+from .torch_edge import DenseDilatedKnnGraph
+from .torch_nn import BasicConv
+
+
+class MRConv2d(nn.Module):
+    """Max-Relative graph conv: nn( interleave(x, max_j (x_j - x_i)) )."""
+
+    def __init__(self, in_channels, out_channels, act="relu", norm=None, bias=True):
+        super().__init__()
+        self.nn = BasicConv([in_channels * 2, out_channels], act, norm, bias)
+
+    def aggregate(self, x, nn_idx):
+        return self.nn(ops.max_relative(x, nn_idx))
+
+    def forward(self, x, edge_index, y=None):
+        if y is not None:
+            raise NotImplementedError("r > 1 (separate y) is unreachable in GraFPrint")
+        out = self.aggregate(x.squeeze(-1) if x.dim() == 4 else x, edge_index[0])
+        return out.unsqueeze(-1) if x.dim() == 4 else out
+
+
+class GraphConv2d(nn.Module):
+    def __init__(self, in_channels, out_channels, conv="edge", act="relu", norm=None, bias=True):
+        super().__init__()
+        if conv != "mr":
+            raise NotImplementedError(f"conv:{conv} is not supported (GraFPrint hard-codes 'mr')")
+        self.gconv = MRConv2d(in_channels, out_channels, act, norm, bias)
+
+    def forward(self, x, edge_index, y=None):
+        return self.gconv(x, edge_index, y)
+
+
+class DyGraphConv2d(GraphConv2d):
+    """Rebuilds the k-NN graph from the current features on every call (torch_vertex.py:114-139)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=9, dilation=1, conv="edge", act="relu",
+                 norm=None, bias=True, stochastic=False, epsilon=0.0, r=1):
+        super().__init__(in_channels, out_channels, conv, act, norm, bias)
+        if r != 1:
+            raise NotImplementedError("r > 1 is unreachable in GraFPrint")
+        self.k, self.d, self.r = kernel_size, dilation, r
+        self.dilated_knn_graph = DenseDilatedKnnGraph(kernel_size, dilation, stochastic, epsilon)
+
+    def forward(self, x, relative_pos=None):
+        shape = x.shape
+        nodes = x.reshape(shape[0], shape[1], -1)
+        out = self.gconv.aggregate(nodes, self.dilated_knn_graph.neighbours(nodes))
+        return out.reshape(shape[0], -1, *shape[2:])
+
+
+class Grapher(nn.Module):
+    """fc1 -> dynamic graph conv -> fc2, plus the residual (torch_vertex.py:146-194)."""
+
+    def __init__(self, in_channels, kernel_size=9, dilation=1, conv="edge", act="relu", norm=None, bias=True,
+                 stochastic=False, epsilon=0.0, r=1, n=196, drop_path=0.0, relative_pos=False):
+        super().__init__()
+        if drop_path > 0.0:
+            raise NotImplementedError("drop_path > 0 never occurs in GraFPrint (idx is never incremented)")
+        self.channels, self.n, self.r = in_channels, n, r
+        self.fc1 = nn.Sequential(nn.Conv2d(in_channels, in_channels, 1), nn.BatchNorm2d(in_channels))
+        self.graph_conv = DyGraphConv2d(in_channels, in_channels * 2, kernel_size, dilation, conv, act, norm, bias,
+                                        stochastic, epsilon, r)
+        self.fc2 = nn.Sequential(nn.Conv2d(in_channels * 2, in_channels, 1), nn.BatchNorm2d(in_channels))
+        self.drop_path = nn.Identity()
+        self.relative_pos = None
+        if relative_pos:   # frozen, never read by forward: kept for state-dict compatibility only
+            table = torch.from_numpy(np.float32(get_2d_relative_pos_embed(in_channels, int(n ** 0.5))))
+            table = F.interpolate(table[None, None], size=(n, n // (r * r)), mode="bicubic", align_corners=False)
+            self.relative_pos = nn.Parameter(-table.squeeze(1), requires_grad=False)
+
+    def forward(self, x):
+        four_d = x.dim() == 4
+        h = x.squeeze(-1) if four_d else x
+        y = batchnorm(self.fc1[1], pointwise(self.fc1[0], h))
+        y = self.graph_conv(y)
+        y = batchnorm(self.fc2[1], pointwise(self.fc2[0], y)) + h
+        return y.unsqueeze(-1) if four_d else y

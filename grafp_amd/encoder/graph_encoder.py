@@ -1,0 +1,114 @@
+"""GraphEncoder backbone (mirror of encoder/graph_encoder.py:71-191).
+
+Same constructor, attributes (`stem`, `backbone`, `proj`) and state-dict keys as the reference; the
+forward keeps nodes as (B,C,N), builds every block's graph with the HIP k-NN kernel and runs the 1x1
+convolutions as plain GEMMs (see _dense.py).  12 Grapher+FFN blocks, k-NN graph rebuilt in each; N
+halves at each of the 3 Downsample modules (1024 -> 512 -> 256 -> 128 nodes).
+"""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ._dense import batchnorm, pointwise, strided3
+from .gcn_lib.torch_nn import act_layer
+from .gcn_lib.torch_vertex import Grapher
+
+_SIZES = {
+    "t": ([2, 2, 6, 2], [64, 128, 256, 512]),
+    "s": ([2, 2, 6, 2], [80, 160, 400, 640]),
+    "m": ([2, 2, 16, 2], [96, 192, 384, 768]),
+}
+
+
+class Downsample(nn.Module):
+    """3x3 stride-2 conv + BN over the (N,1) node grid: halves N, changes width."""
+
+    def __init__(self, in_dim=3, out_dim=768):
+        super().__init__()
+        self.conv = nn.Sequential(nn.Conv2d(in_dim, out_dim, 3, stride=2, padding=1), nn.BatchNorm2d(out_dim))
+
+    def forward(self, x):
+        four_d = x.dim() == 4
+        y = batchnorm(self.conv[1], strided3(self.conv[0], x.squeeze(-1) if four_d else x))
+        return y.unsqueeze(-1) if four_d else y
+
+
+class ChannelConv(nn.Module):
+    """Present in the reference (graph_encoder.py:31-43) but never instantiated."""
+
+    def __init__(self, in_dim, out_dim):
+        super().__init__()
+        self.conv = nn.Sequential(nn.Conv2d(in_dim, out_dim, kernel_size=1, bias=False), nn.BatchNorm2d(out_dim))
+
+    def forward(self, x):
+        four_d = x.dim() == 4
+        y = batchnorm(self.conv[1], pointwise(self.conv[0], x.squeeze(-1) if four_d else x))
+        return y.unsqueeze(-1) if four_d else y
+
+
+class FFN(nn.Module):
+    def __init__(self, in_features, hidden_features=None, out_features=None, act="relu", drop_path=0.0):
+        super().__init__()
+        if drop_path > 0.0:
+            raise NotImplementedError("drop_path > 0 never occurs in GraFPrint")
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.drop_path = nn.Identity()
+        self.act = act_layer(act)
+        self.fc1 = nn.Sequential(nn.Conv2d(in_features, hidden_features, 1, bias=False), nn.BatchNorm2d(hidden_features))
+        self.fc2 = nn.Sequential(nn.Conv2d(hidden_features, out_features, 1, bias=False), nn.BatchNorm2d(out_features))
+
+    def forward(self, x):
+        four_d = x.dim() == 4
+        h = x.squeeze(-1) if four_d else x
+        y = self.act(batchnorm(self.fc1[1], pointwise(self.fc1[0], h)))
+        y = batchnorm(self.fc2[1], pointwise(self.fc2[0], y)) + h
+        return y.unsqueeze(-1) if four_d else y
+
+
+class GraphEncoder(nn.Module):
+    def __init__(self, cfg, k=3, conv="mr", act="relu", norm="batch", bias=True, dropout=0.0, dilation=True,
+                 epsilon=0.2, drop_path=0.1, size="t", emb_dims=1024, in_channels=3):
+        super().__init__()
+        self.blocks, self.channels = _SIZES.get(size, ([2, 2, 18, 2], [128, 256, 512, 1024]))
+        self.k, self.act, self.norm, self.bias = int(k), act, norm, bias
+        self.drop_path, self.emb_dims, self.epsilon = drop_path, emb_dims, epsilon
+        self.dilation, self.dropout = dilation, dropout
+        self.num_blocks = sum(self.blocks)
+        self.conv = "mr"                      # the reference ignores its `conv` argument (:123)
+        n_nodes = cfg["n_mels"] * cfg["n_frames"] // cfg["peak_stride"]
+
+        self.stem = nn.Sequential(nn.Conv2d(in_channels, self.channels[0], kernel_size=1, bias=False),
+                                  nn.BatchNorm2d(self.channels[0]), nn.LeakyReLU(negative_slope=0.2))
+        # The reference never advances its block counter (:138-151): every block gets k neighbours,
+        # dilation 1 and drop-path 0, and its bookkeeping N shrinks 4x per stage (relative_pos shapes).
+        mods = []
+        for stage, (depth, width) in enumerate(zip(self.blocks, self.channels)):
+            if stage > 0:
+                mods.append(Downsample(self.channels[stage - 1], width))
+                n_nodes //= 4
+            for _ in range(depth):
+                mods.append(nn.Sequential(
+                    Grapher(width, self.k, 1, self.conv, act, norm, bias, False, epsilon, 1, n=n_nodes,
+                            drop_path=0.0, relative_pos=True),
+                    FFN(width, width * 4, width, act=act, drop_path=0.0)))
+        self.backbone = nn.Sequential(*mods)
+        self.proj = nn.Conv2d(self.channels[-1], 1024, 1, bias=True)
+
+    def model_init(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight)
+                m.weight.requires_grad = True
+                if m.bias is not None:
+                    m.bias.data.zero_()
+                    m.bias.requires_grad = True
+
+    def forward(self, x):
+        """x (B, C_in, N) node features -> (B, 1024)."""
+        if x.dim() == 4:
+            x = x.squeeze(-1)
+        x = F.leaky_relu(batchnorm(self.stem[1], pointwise(self.stem[0], x)), self.stem[2].negative_slope)
+        for mod in self.backbone:
+            x = mod(x)
+        return pointwise(self.proj, x).mean(dim=2)

@@ -1,0 +1,125 @@
+"""Retrieval evaluation (mirror of eval.py: get_index :9-123, load_memmap_data :126-168, eval_faiss :170-332).
+
+FAISS is replaced by an exact brute-force search resident on the MI355X (ops.FlatL2Index): every
+`index_type` maps to exact squared-L2 search, which is what 'l2' means in the reference and a superset
+in accuracy of its IVF/PQ/HNSW options.  The 2000 x 4 tiny `index.search` calls of the reference's double
+Python loop are batched into ONE search launch over all query segments; the sequence rerank
+(:262-301) then runs on the host over the returned candidates, with identical semantics.
+"""
+import os
+import time
+import uuid
+
+import numpy as np
+
+from .ops import FlatL2Index
+
+
+def get_index(index_type, train_data, train_data_shape, use_gpu=True, max_nitem_train=2e7, n_centroids=64):
+    """Returns an (empty) exact-L2 index of dimension train_data_shape[1].  No training step exists."""
+    mode = str(index_type).lower()
+    if mode != "l2":
+        print(f"index_type '{mode}' is served by exact brute-force L2 search on the GPU")
+    index = FlatL2Index(int(train_data_shape[1]))
+    index.nprobe = 20
+    return index
+
+
+def load_memmap_data(source_dir, fname, append_extra_length=None, shape_only=False, display=True):
+    """`<fname>_shape.npy` + `<fname>.mm` (float32 memmap) -> (data, shape); NaNs are zeroed in place."""
+    data_shape = np.load(os.path.join(source_dir, fname + "_shape.npy"))
+    if shape_only:
+        return data_shape
+    if append_extra_length:
+        data_shape[0] += append_extra_length
+    path = os.path.join(source_dir, fname + ".mm")
+    data = np.memmap(path, dtype="float32", mode="r+", shape=(int(data_shape[0]), int(data_shape[1])))
+    data[np.isnan(data)] = 0.0
+    if display:
+        print(f"Load {data_shape[0]:,} items from {path}.")
+    return data, data_shape
+
+
+def sequence_rerank(q, I, recon, sl):
+    """One (test id, query length) item of eval.py:272-290: offset-compensate the per-segment top-k ids,
+    take the unique non-negative candidates, score each by the mean over the sequence of
+    <q[t], recon[cid + t]>, return candidates ordered best-first (top 10)."""
+    I = I - np.arange(len(I))[:, None]
+    cand = np.unique(I[I >= 0])
+    if len(cand) == 0:
+        return cand
+    rows = cand[:, None] + np.arange(sl)[None, :]
+    valid = rows < recon.shape[0]
+    seq = recon[np.minimum(rows, recon.shape[0] - 1)]                      # (n_cand, sl, d)
+    dots = np.einsum("td,ctd->ct", q.astype(np.float64), seq.astype(np.float64))
+    dots = np.where(valid, dots, 0.0)
+    scores = dots.sum(axis=1) / np.maximum(valid.sum(axis=1), 1)           # np.mean(np.diag(q @ seq.T))
+    return cand[np.argsort(-scores, kind="stable")[:10]]
+
+
+def eval_faiss(emb_dir, emb_dummy_dir=None, index_type="ivfpq", nogpu=False, max_train=1e7, test_ids="icassp",
+               test_seq_len="1 3 5 9 11 19", k_probe=20, n_centroids=64):
+    """Segment/sequence-level search experiment; returns hit rates (4, n_lengths) in percent:
+    rows = top1 exact, top1 near, top3 exact, top10 exact.  Side-effect files as in the reference."""
+    if isinstance(test_seq_len, str):
+        test_seq_len = np.asarray(list(map(int, test_seq_len.split())))
+    test_seq_len = np.asarray(test_seq_len)
+    query, query_shape = load_memmap_data(emb_dir, "query")
+    db, db_shape = load_memmap_data(emb_dir, "db")
+    emb_dummy_dir = emb_dir if emb_dummy_dir is None else emb_dummy_dir
+    dummy_db, dummy_db_shape = load_memmap_data(emb_dummy_dir, "dummy_db")
+    n_dummy = int(dummy_db_shape[0])
+
+    index = get_index(index_type, dummy_db, dummy_db.shape, (not nogpu), max_train, n_centroids=n_centroids)
+    t0 = time.time()
+    index.add(np.asarray(dummy_db)); print(f"{len(dummy_db)} items from dummy DB")
+    index.add(np.asarray(db)); print(f"{len(db)} items from reference DB")
+    print(f"Added total {index.ntotal} items to DB. {time.time() - t0:>4.2f} sec.")
+    # the reference extends dummy_db.mm on disk to get a reconstruction table; a host array suffices
+    recon = np.concatenate([np.asarray(dummy_db), np.asarray(db)], axis=0)
+
+    if isinstance(test_ids, str):
+        if test_ids.lower() == "all":
+            test_ids = np.arange(0, len(query) - max(test_seq_len), 1)
+        elif test_ids.isnumeric():
+            np.random.seed(42)
+            test_ids = np.random.permutation(len(query) - max(test_seq_len))[:int(test_ids)]
+        else:
+            test_ids = np.load(test_ids)
+    test_ids = np.asarray(test_ids)
+    n_test, n_len = len(test_ids), len(test_seq_len)
+    gt_ids = test_ids + n_dummy
+    print(f"n_test: {n_test:n}")
+
+    # ---- one batched search over every query segment any (test id, length) item needs -----------
+    max_sl = int(max(test_seq_len))
+    seg_rows = np.unique((test_ids[:, None] + np.arange(max_sl)[None, :]).ravel())
+    seg_rows = seg_rows[seg_rows < len(query)]
+    row_of = {int(r): i for i, r in enumerate(seg_rows)}
+    t0 = time.time()
+    _, I_all = index.search(np.ascontiguousarray(query[seg_rows]), k_probe)
+    print(f"Searched {len(seg_rows):,} segments x top-{k_probe} in {time.time() - t0:>4.2f} sec.")
+
+    flags = np.zeros((4, n_test, n_len), dtype=int)
+    for ti, test_id in enumerate(test_ids):
+        gt = gt_ids[ti]
+        for si, sl in enumerate(test_seq_len):
+            assert test_id <= len(query)
+            rows = [row_of[int(r)] for r in range(test_id, min(test_id + sl, len(query)))]
+            q = np.asarray(query[test_id:test_id + sl, :])
+            pred = sequence_rerank(q, I_all[rows], recon, int(sl))
+            if len(pred) == 0:
+                continue
+            flags[0, ti, si] = int(gt == pred[0])
+            flags[1, ti, si] = int(pred[0] in (gt - 1, gt, gt + 1))
+            flags[2, ti, si] = int(gt in pred[:3])
+            flags[3, ti, si] = int(gt in pred[:10])
+
+    hit_rates = 100.0 * flags.mean(axis=1)
+    result_dir = emb_dir + f"/{uuid.uuid4().hex[:8]}"
+    os.makedirs(result_dir, exist_ok=True)
+    np.save(f"{result_dir}/hit_rates.npy", hit_rates)
+    np.save(f"{result_dir}/raw_score.npy", np.concatenate(list(flags), axis=1))
+    np.save(f"{emb_dir}/test_ids.npy", test_ids)
+    print(f"Saved test_ids, hit-rates and raw score to {result_dir}.")
+    return hit_rates

@@ -1,0 +1,387 @@
+"""Torch-facing wrappers over the C ABI (include/grafp_hip.h).
+
+PyTorch is used here for device memory, the current HIP stream and autograd plumbing only; every
+computation below runs in libgrafp_hip.so.  There is no CPU path: tensors that are not on a HIP device
+raise immediately.
+"""
+import contextlib
+import ctypes
+import math
+
+import numpy as np
+import torch
+from torch.amp import custom_bwd, custom_fwd
+
+from ._lib import check, lib
+
+_vp = ctypes.c_void_p
+
+
+def _require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "grafp_amd ops run only on a HIP device (MI355X): got a CPU tensor and there is no CPU "
+                "fallback by design (the CPU restatement lives in oracle/ and is test infrastructure).")
+
+
+def _p(t):
+    return _vp(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return _vp(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32c(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+# ------------------------------------------------------------------------------------------------
+# Optional per-kernel timing with HIP events on the launch stream (bench.py's roofline block)
+# ------------------------------------------------------------------------------------------------
+_TIMED = {}     # name -> list of (start_event, end_event, meta)
+
+
+@contextlib.contextmanager
+def time_kernels(*names):
+    """Record HIP events around every launch of the named ops inside the block.
+    Yields a dict name -> list[(start, end, meta)]; call `elapsed_ms(events)` after a synchronize."""
+    for n in names:
+        _TIMED[n] = []
+    try:
+        yield _TIMED
+    finally:
+        for n in names:
+            _TIMED.pop(n, None)
+
+
+@contextlib.contextmanager
+def _timed(name, meta=None):
+    rec = _TIMED.get(name)
+    if rec is None:
+        yield
+        return
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    yield
+    e.record()
+    rec.append((s, e, meta))
+
+
+def elapsed_ms(events):
+    return [s.elapsed_time(e) for s, e, _ in events]
+
+
+# ------------------------------------------------------------------------------------------------
+# K1 / K1b  log-mel
+# ------------------------------------------------------------------------------------------------
+_MEL_PLANS = {}
+
+
+def mel_filterbank(n_freqs, n_mels, sample_rate, f_min=0.0, f_max=None):
+    """HTK triangular filterbank, norm=None, in f32 exactly as torchaudio==2.3.0 builds it
+    (`melscale_fbanks`; the reference gets it through MelSpectrogram, modules/transformations.py:51)."""
+    f_max = float(sample_rate // 2) if f_max is None else float(f_max)
+    freqs = torch.linspace(0, sample_rate // 2, n_freqs)
+    mel_lo = 2595.0 * math.log10(1.0 + f_min / 700.0)
+    mel_hi = 2595.0 * math.log10(1.0 + f_max / 700.0)
+    pts = 700.0 * (10.0 ** (torch.linspace(mel_lo, mel_hi, n_mels + 2) / 2595.0) - 1.0)
+    width = pts[1:] - pts[:-1]
+    slope = pts.unsqueeze(0) - freqs.unsqueeze(1)
+    rising = slope[:, 2:] / width[1:]
+    falling = (-1.0 * slope[:, :-2]) / width[:-1]
+    return torch.clamp(torch.minimum(falling, rising), min=0.0)
+
+
+class _MelPlan:
+    def __init__(self, device, fs, n_fft, win_len, n_mels):
+        win = torch.hann_window(win_len)                       # periodic, as torch.stft's default use
+        if win_len < n_fft:
+            left = (n_fft - win_len) // 2
+            win = torch.nn.functional.pad(win, (left, n_fft - win_len - left))
+        j = torch.arange(n_fft // 2, dtype=torch.float64)
+        ang = 2.0 * math.pi * j / n_fft
+        tw = torch.stack((torch.cos(ang), -torch.sin(ang)), dim=1).to(torch.float32)
+        fb = mel_filterbank(n_fft // 2 + 1, n_mels, fs)
+        nz = fb > 0
+        any_nz = nz.any(dim=0)
+        lo = torch.where(any_nz, nz.to(torch.int32).argmax(dim=0), torch.ones(n_mels, dtype=torch.int64))
+        hi = torch.where(any_nz, fb.shape[0] - 1 - nz.flip(0).to(torch.int32).argmax(dim=0),
+                         torch.zeros(n_mels, dtype=torch.int64))
+        self.window = win.to(device).contiguous()
+        self.twiddle = tw.to(device).contiguous()
+        self.fb = fb.to(device).contiguous()
+        self.band_lo = lo.to(torch.int32).to(device).contiguous()
+        self.band_hi = hi.to(torch.int32).to(device).contiguous()
+
+
+def _mel_plan(device, fs, n_fft, win_len, n_mels):
+    key = (str(device), fs, n_fft, win_len, n_mels)
+    if key not in _MEL_PLANS:
+        _MEL_PLANS[key] = _MelPlan(device, fs, n_fft, win_len, n_mels)
+    return _MEL_PLANS[key]
+
+
+def logmel(wav, fs=16000, n_fft=1024, win_len=1024, hop=512, n_mels=64):
+    """(B, T) or (T,) waveform -> (B, n_mels, 1 + T // hop) dB (or (n_mels, frames) for 1-D input)."""
+    _require_gpu(wav)
+    squeeze = wav.dim() == 1
+    x = _f32c(wav.reshape(-1, wav.shape[-1]))
+    B, T = x.shape
+    plan = _mel_plan(x.device, fs, n_fft, win_len, n_mels)
+    out = torch.empty((B, n_mels, 1 + T // hop), dtype=torch.float32, device=x.device)
+    with _timed("logmel", (B, T)):
+        check(lib.grafp_logmel_f32(_p(x), x.stride(0), B, T, n_fft, hop, n_mels, _p(plan.window), _p(plan.twiddle),
+                                   _p(plan.fb), _p(plan.band_lo), _p(plan.band_hi), _p(out), _stream()), "logmel")
+    return out[0] if squeeze else out
+
+
+def unfold_segments(spec, size, step):
+    """(n_mels, n_frames) -> contiguous (n_seg, n_mels, size); values of
+    `spec.transpose(1,0).unfold(0, size, step)` (modules/transformations.py:89-90)."""
+    _require_gpu(spec)
+    s = _f32c(spec)
+    n_mels, n_frames = s.shape
+    if n_frames < size:
+        return torch.empty((0, n_mels, size), dtype=torch.float32, device=s.device)
+    n_seg = (n_frames - size) // step + 1
+    seg = torch.empty((n_seg, n_mels, size), dtype=torch.float32, device=s.device)
+    check(lib.grafp_unfold_segments_f32(_p(s), n_mels, n_frames, size, step, _p(seg), _stream()), "unfold_segments")
+    return seg
+
+
+# ------------------------------------------------------------------------------------------------
+# K2  peak extractor
+# ------------------------------------------------------------------------------------------------
+_RAMPS = {}
+
+
+def _ramps(device, H, W):
+    key = (str(device), H, W)
+    if key not in _RAMPS:
+        _RAMPS[key] = (torch.linspace(0, 1, steps=W).to(device), torch.linspace(0, 1, steps=H).to(device))
+    return _RAMPS[key]
+
+
+class _PeakExtract(torch.autograd.Function):
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, spec, weight, bias, stride_h):
+        _require_gpu(spec, weight, bias)
+        spec, weight, bias = _f32c(spec), _f32c(weight), _f32c(bias)
+        B, H, W = spec.shape
+        F, cin, KH, KW = weight.shape
+        if cin != 3:
+            raise ValueError("peak extractor expects 3 input planes [T-ramp, F-ramp, spectrogram]")
+        Ho = (H + 2 * (KH // 2) - KH) // stride_h + 1
+        t_ramp, f_ramp = _ramps(spec.device, H, W)
+        out = torch.empty((B, F, Ho * W), dtype=torch.float32, device=spec.device)
+        with _timed("peak_extract_fwd", (B,)):
+            check(lib.grafp_peak_extract_fwd_f32(_p(spec), B, H, W, _p(weight), _p(bias), F, KH, KW, stride_h,
+                                                 _p(t_ramp), _p(f_ramp), _p(out), _stream()), "peak_extract_fwd")
+        ctx.save_for_backward(spec, out)
+        ctx.geom = (B, H, W, F, KH, KW, stride_h)
+        return out
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, grad_out):
+        spec, out = ctx.saved_tensors
+        B, H, W, F, KH, KW, stride_h = ctx.geom
+        g = _f32c(grad_out)
+        dw = torch.zeros((F, 3, KH, KW), dtype=torch.float32, device=spec.device)
+        db = torch.zeros((F,), dtype=torch.float32, device=spec.device)
+        t_ramp, f_ramp = _ramps(spec.device, H, W)
+        with _timed("peak_extract_bwd", (B,)):
+            check(lib.grafp_peak_extract_bwd_f32(_p(spec), B, H, W, F, KH, KW, stride_h, _p(t_ramp), _p(f_ramp),
+                                                 _p(out), _p(g), _p(dw), _p(db), _stream()), "peak_extract_bwd")
+        return None, dw, db, None
+
+
+def peak_extract(spec, weight, bias, stride_h):
+    """(B,H,W) log-mel -> (B,F,Ho*W) node features; differentiable w.r.t. weight and bias."""
+    return _PeakExtract.apply(spec, weight, bias, int(stride_h))
+
+
+# ------------------------------------------------------------------------------------------------
+# K3-K5  k-NN graph
+# ------------------------------------------------------------------------------------------------
+def knn_graph(x, k, normalize=True):
+    """x (B,C,N) or (B,C,N,1) -> int64 (B,N,k) nearest-neighbour indices (ascending distance, ties to
+    the lowest index).  Non-differentiable, as in the reference (torch_edge.py:78 `no_grad`)."""
+    _require_gpu(x)
+    if x.dim() == 4:
+        x = x.squeeze(-1)
+    x = _f32c(x)
+    B, C, N = x.shape
+    idx = torch.empty((B, N, k), dtype=torch.int64, device=x.device)
+    nbytes = lib.grafp_knn_graph_workspace(B, C, N)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
+    with _timed("knn_graph", (B, C, N, k)):
+        check(lib.grafp_knn_graph_f32(_p(x), B, C, N, k, int(bool(normalize)), _p(idx), _p(ws), nbytes, _stream()),
+              "knn_graph")
+    return idx
+
+
+# ------------------------------------------------------------------------------------------------
+# K6-K7  gather + max-relative
+# ------------------------------------------------------------------------------------------------
+class _MaxRelative(torch.autograd.Function):
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, x, idx):
+        _require_gpu(x, idx)
+        x = _f32c(x)
+        idx = idx.to(torch.int64).contiguous()
+        B, C, N = x.shape
+        K = idx.shape[-1]
+        if tuple(idx.shape) != (B, N, K):
+            raise ValueError(f"idx shape {tuple(idx.shape)} does not match x {(B, C, N)}")
+        out = torch.empty((B, 2 * C, N), dtype=torch.float32, device=x.device)
+        with _timed("mrconv_fwd", (B, C, N, K)):
+            check(lib.grafp_mrconv_fwd_f32(_p(x), _p(idx), B, C, N, K, _p(out), _stream()), "mrconv_fwd")
+        ctx.save_for_backward(x, idx)
+        return out
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, grad_out):
+        x, idx = ctx.saved_tensors
+        B, C, N = x.shape
+        K = idx.shape[-1]
+        g = _f32c(grad_out)
+        dx = torch.empty_like(x)
+        with _timed("mrconv_bwd", (B, C, N, K)):
+            check(lib.grafp_mrconv_bwd_f32(_p(x), _p(idx), _p(g), B, C, N, K, _p(dx), _stream()), "mrconv_bwd")
+        return dx, None
+
+
+def max_relative(x, idx):
+    """x (B,C,N), idx (B,N,K) -> (B,2C,N): channel 2c = x[c], channel 2c+1 = max_k(x[c, idx] - x[c])."""
+    return _MaxRelative.apply(x, idx)
+
+
+# ------------------------------------------------------------------------------------------------
+# K12  NT-Xent
+# ------------------------------------------------------------------------------------------------
+class _NTXent(torch.autograd.Function):
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, z_i, z_j, tau, zi_all, zj_all, row_begin):
+        _require_gpu(z_i, z_j)
+        n_local, D = z_i.shape
+        if zi_all is None:
+            zi_all, zj_all, row_begin = z_i, z_j, 0
+        zi_all, zj_all = _f32c(zi_all), _f32c(zj_all)
+        B_all = zi_all.shape[0]
+        npart = lib.grafp_ntxent_num_partials(n_local)
+        part = torch.empty((npart,), dtype=torch.float32, device=z_i.device)
+        dzi = torch.empty((n_local, D), dtype=torch.float32, device=z_i.device)
+        dzj = torch.empty((n_local, D), dtype=torch.float32, device=z_i.device)
+        nbytes = lib.grafp_ntxent_workspace(B_all)
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=z_i.device)
+        with _timed("ntxent", (B_all, n_local, D)):
+            check(lib.grafp_ntxent_fwd_bwd_f32(_p(zi_all), _p(zj_all), B_all, D, row_begin, n_local, float(tau),
+                                               _p(part), _p(dzi), _p(dzj), _p(ws), nbytes, _stream()), "ntxent")
+        ctx.save_for_backward(dzi, dzj)
+        return part.sum() / (2.0 * B_all)
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, g):
+        dzi, dzj = ctx.saved_tensors
+        return g * dzi, g * dzj, None, None, None, None
+
+
+def ntxent(z_i, z_j, tau, zi_all=None, zj_all=None, row_begin=0):
+    """NT-Xent of (z_i, z_j) (each (B,D)).  With zi_all/zj_all (the all-gathered embeddings, no grad) the
+    negatives are global: the value is this rank's share of the global mean loss and backward yields the
+    gradient of the GLOBAL loss w.r.t. the local rows."""
+    return _NTXent.apply(z_i, z_j, float(tau), zi_all, zj_all, int(row_begin))
+
+
+# ------------------------------------------------------------------------------------------------
+# K13  brute-force search
+# ------------------------------------------------------------------------------------------------
+def row_sqnorm(m):
+    _require_gpu(m)
+    m = _f32c(m)
+    out = torch.empty((m.shape[0],), dtype=torch.float32, device=m.device)
+    check(lib.grafp_row_sqnorm_f32(_p(m), m.shape[0], m.shape[1], _p(out), _stream()), "row_sqnorm")
+    return out
+
+
+def search_l2(db, db_sqnorm, q, k, id_base=0, max_queries_per_launch=16384):
+    """Exact squared-L2 top-k of q (nq,128) against the resident db (n,128): (dist f32, ids int64), (nq,k)."""
+    _require_gpu(db, db_sqnorm, q)
+    q = _f32c(q)
+    n, d = db.shape
+    nq = q.shape[0]
+    out_d = torch.empty((nq, k), dtype=torch.float32, device=db.device)
+    out_i = torch.empty((nq, k), dtype=torch.int64, device=db.device)
+    for s in range(0, nq, max_queries_per_launch):
+        e = min(nq, s + max_queries_per_launch)
+        nbytes = lib.grafp_knn_search_workspace(n, e - s, d, k)
+        ws = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=db.device)
+        with _timed("knn_search", (n, e - s, k)):
+            check(lib.grafp_knn_search_l2_f32(_p(db), _p(db_sqnorm), n, _p(q[s:e]), e - s, d, k, int(id_base),
+                                              _p(out_d[s:e]), _p(out_i[s:e]), _p(ws), nbytes, _stream()),
+                  "knn_search_l2")
+    return out_d, out_i
+
+
+def merge_topk(part_d, part_i):
+    """(P,nq,k) partial lists (id < 0 = empty) -> (nq,k) by (distance, id)."""
+    _require_gpu(part_d, part_i)
+    part_d = _f32c(part_d)
+    part_i = part_i.to(torch.int64).contiguous()
+    P, nq, k = part_d.shape
+    out_d = torch.empty((nq, k), dtype=torch.float32, device=part_d.device)
+    out_i = torch.empty((nq, k), dtype=torch.int64, device=part_d.device)
+    with _timed("merge_topk", (P, nq, k)):
+        check(lib.grafp_merge_topk(_p(part_d), _p(part_i), P, nq, k, _p(out_d), _p(out_i), _stream()), "merge_topk")
+    return out_d, out_i
+
+
+class FlatL2Index:
+    """Drop-in for the subset of faiss.IndexFlatL2 that eval.py uses: d, ntotal, add(x), search(q, k).
+    The database lives in HBM; `add` also computes the per-row squared norms once."""
+
+    def __init__(self, d=128, device=None, id_base=0):
+        if not torch.cuda.is_available():
+            raise RuntimeError("FlatL2Index needs a HIP device: there is no CPU fallback")
+        self.d = d
+        self.device = torch.device(device if device is not None else "cuda")
+        self.id_base = int(id_base)
+        self._chunks = []
+        self._db = None
+        self._sq = None
+        self.ntotal = 0
+        self.nprobe = 1            # attribute assigned at eval.py:122; meaningless for exact search
+
+    def add(self, x):
+        t = torch.as_tensor(np.ascontiguousarray(x) if isinstance(x, np.ndarray) else x)
+        t = t.to(self.device, dtype=torch.float32).reshape(-1, self.d).contiguous()
+        self._chunks.append(t)
+        self.ntotal += t.shape[0]
+        self._db = None
+
+    def _materialise(self):
+        if self._db is None:
+            self._db = self._chunks[0] if len(self._chunks) == 1 else torch.cat(self._chunks, dim=0)
+            self._chunks = [self._db]
+            self._sq = row_sqnorm(self._db)
+        return self._db, self._sq
+
+    def search(self, q, k):
+        """numpy in -> numpy out (D float32 (nq,k), I int64 (nq,k)), like faiss; tensors in -> tensors out."""
+        as_numpy = isinstance(q, np.ndarray)
+        qt = torch.as_tensor(np.ascontiguousarray(q) if as_numpy else q).to(self.device, dtype=torch.float32)
+        if self.ntotal == 0:
+            D = torch.full((qt.shape[0], k), float("inf"), device=self.device)
+            I = torch.full((qt.shape[0], k), -1, dtype=torch.int64, device=self.device)
+        else:
+            db, sq = self._materialise()
+            D, I = search_l2(db, sq, qt.reshape(-1, self.d), k, self.id_base)
+        return (D.cpu().numpy(), I.cpu().numpy()) if as_numpy else (D, I)

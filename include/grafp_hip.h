@@ -1,0 +1,142 @@
+/* grafp_hip.h -- C ABI of libgrafp_hip.so, the MI355X (gfx950) hot path of GraFPrint.
+ *
+ * The reference (chymaera96/GraFP) is pure Python/PyTorch and has no FFI: its "operator interface"
+ * for this path is a set of torch calls inside Python modules.  Each entry point below replaces one
+ * such call site (cited per function, paths relative to the reference root) and is bound from
+ * Python with ctypes (grafp_amd/_lib.py; INTEGRATION.md shows the reference-side stubs).
+ *
+ * Conventions (all entry points):
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless it says "host";
+ *   - the CALLER owns every buffer, including the scratch `ws` whose size the matching
+ *     *_workspace() function returns (bytes; 256-byte alignment is sufficient);
+ *   - no allocation, no global mutable state, no implicit synchronisation: work is enqueued on
+ *     `stream` (a hipStream_t passed as void*; NULL = the default stream) and is hipGraph-capturable;
+ *   - returns GRAFP_OK (0) or a negative GRAFP_ERR_* code; grafp_last_error() then holds a
+ *     thread-local human-readable message;
+ *   - layouts are the reference's: activations (B, C, N) channel-major f32 (the reference's
+ *     (B,C,N,1) with the trailing 1 dropped), edge indices int64, fingerprints (n, d) row-major f32.
+ */
+#ifndef GRAFP_HIP_H
+#define GRAFP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GRAFP_OK 0
+#define GRAFP_ERR_ARG (-1)       /* bad argument (shape, alignment, unsupported size) */
+#define GRAFP_ERR_WORKSPACE (-2) /* workspace missing or too small */
+#define GRAFP_ERR_LAUNCH (-3)    /* HIP launch failed (message holds hipGetErrorString) */
+
+#define GRAFP_ABI_VERSION 1
+#define GRAFP_KNN_MAX_K 8     /* edges per node supported by grafp_knn_graph_f32 */
+#define GRAFP_SEARCH_MAX_K 32 /* results per query supported by grafp_knn_search_l2_f32 */
+
+typedef void *grafp_stream_t; /* hipStream_t */
+
+int grafp_abi_version(void);
+const char *grafp_last_error(void);
+
+/* ---- K1: log-mel spectrogram ---------------------------------------------------------------
+ * Replaces torchaudio MelSpectrogram(sample_rate, win_length, hop_length, n_fft, n_mels) ->
+ * AmplitudeToDB() as constructed at modules/transformations.py:50-57 and applied at :78,:83
+ * (batched 1 s clips) and :89,:111 (whole track).  Centred reflect-padded STFT (radix-2 FFT in LDS,
+ * two real frames per complex transform), |.|^2, sparse triangular mel filterbank, 10*log10(max(.,1e-10)).
+ *   wav      (B, T) f32, row stride wav_stride elements          T > n_fft/2
+ *   window   (n_fft) f32       analysis window, already zero-padded to n_fft
+ *   twiddle  (n_fft/2, 2) f32  (cos, -sin)(2*pi*j/n_fft)
+ *   fb       (n_fft/2+1, n_mels) f32 dense filterbank; band_lo/band_hi (n_mels) int32 = first/last
+ *            bin with a non-zero weight per band (band_hi < band_lo for an empty band)
+ *   out      (B, n_mels, n_frames) f32, n_frames = 1 + T / hop
+ * n_fft in {256, 512, 1024, 2048}. */
+int grafp_logmel_f32(const float *wav, int64_t wav_stride, int B, int T, int n_fft, int hop, int n_mels,
+                     const float *window, const float *twiddle, const float *fb, const int32_t *band_lo,
+                     const int32_t *band_hi, float *out, grafp_stream_t stream);
+
+/* Whole-track segmentation, modules/transformations.py:89-90 (`transpose(1,0).unfold(0, size, step)`),
+ * materialised contiguously: spec (n_mels, n_frames) -> seg (n_seg, n_mels, size),
+ * n_seg = (n_frames - size) / step + 1. */
+int grafp_unfold_segments_f32(const float *spec, int n_mels, int n_frames, int size, int step, float *seg,
+                              grafp_stream_t stream);
+
+/* ---- K2: peak extractor ----------------------------------------------------------------------
+ * Replaces GPUPeakExtractorv2.forward, peak_extractor.py:56-82: per-clip min-max normalisation,
+ * [T-ramp, F-ramp, spec] stack, Conv2d(3 -> F, (KH,KW), stride (sh,1), pad (KH/2,KW/2)) + ReLU, flatten.
+ *   spec (B,H,W)  weight (F,3,KH,KW)  bias (F)  out (B,F,Ho*W), Ho = (H + 2*(KH/2) - KH)/sh + 1
+ *   t_ramp (W) = linspace(0,1,W), f_ramp (H) = linspace(0,1,H)   (peak_extractor.py:36-42), KH, KW odd
+ * Backward (spec carries no gradient, train.py:66-67): dweight/dbias are ACCUMULATED into (the caller
+ * zeroes them); `out` is the forward result (ReLU mask). */
+int grafp_peak_extract_fwd_f32(const float *spec, int B, int H, int W, const float *weight, const float *bias,
+                               int F, int KH, int KW, int stride_h, const float *t_ramp, const float *f_ramp,
+                               float *out, grafp_stream_t stream);
+int grafp_peak_extract_bwd_f32(const float *spec, int B, int H, int W, int F, int KH, int KW, int stride_h,
+                               const float *t_ramp, const float *f_ramp, const float *out, const float *grad_out,
+                               float *dweight, float *dbias, grafp_stream_t stream);
+
+/* ---- K3-K5: dynamic k-NN graph ---------------------------------------------------------------
+ * Replaces DenseDilatedKnnGraph.forward (encoder/gcn_lib/torch_edge.py:270-284, y=None, dilation 1):
+ * channel L2-normalise (:281) -> pairwise_distance (:7-18) -> topk(-dist,k) (:100).  The N x N matrix
+ * is never materialised (exact-f32 MFMA tiles + register top-k).  Arithmetic order is the one fixed
+ * in oracle/csrc/knn_graph.c; ties -> lowest index.  Centre indices (edge_index[1]) are arange(N)
+ * and are not written.
+ *   x (B,C,N) f32   idx (B,N,k) int64   1 <= k <= min(N, GRAFP_KNN_MAX_K)
+ *   normalize != 0 applies the L2 normalisation (0 = dense_knn_matrix alone). */
+size_t grafp_knn_graph_workspace(int B, int C, int N);
+int grafp_knn_graph_f32(const float *x, int B, int C, int N, int k, int normalize, int64_t *idx, void *ws,
+                        size_t ws_bytes, grafp_stream_t stream);
+
+/* ---- K6-K7: edge gather + max-relative aggregation -------------------------------------------
+ * Replaces batched_index_select x2 (encoder/gcn_lib/torch_nn.py:79-98) + max over k of (x_j - x_i)
+ * + channel interleave (torch_vertex.py:21-32):
+ *   out[b,2c,n] = x[b,c,n] ; out[b,2c+1,n] = max_k ( x[b,c,idx[b,n,k]] - x[b,c,n] )
+ * Backward: dx[b,c,n] = g[b,2c,n] - g[b,2c+1,n] + sum over m whose arg-max neighbour (first maximum)
+ * is n of g[b,2c+1,m].  Indices outside [0,N) are clamped.
+ *   x (B,C,N) f32   idx (B,N,K) int64   out/grad_out (B,2C,N) f32   dx (B,C,N) f32 */
+int grafp_mrconv_fwd_f32(const float *x, const int64_t *idx, int B, int C, int N, int K, float *out,
+                         grafp_stream_t stream);
+int grafp_mrconv_bwd_f32(const float *x, const int64_t *idx, const float *grad_out, int B, int C, int N, int K,
+                         float *dx, grafp_stream_t stream);
+
+/* ---- K12: NT-Xent loss, fused forward + backward ----------------------------------------------
+ * Replaces ntxent_loss (simclr/ntxent.py:4-29; called train.py:71).  Rows of the similarity matrix
+ * are the 2*B_all embeddings (view i then view j; the loss is invariant to the reference's
+ * interleaved order), S = z z^T / tau, loss_r = logsumexp_{c != r} S_rc - S_{r,partner(r)}.  S is
+ * computed in exact-f32 MFMA tiles and never written.  Data-parallel form: every rank passes the
+ * ALL-GATHERED embeddings and its own pair range [row_begin, row_begin + n_local); it receives the
+ * gradient of the GLOBAL mean loss w.r.t. its own rows (no backward collective is needed) and its
+ * share of the loss.  Single GPU: row_begin = 0, n_local = B_all.
+ *   zi_all, zj_all (B_all, D) f32, D % 32 == 0, D <= 128
+ *   loss_partial   (grafp_ntxent_num_partials(n_local)) f32: sum(loss_partial) / (2*B_all) = the
+ *                  local rows' share of the mean loss
+ *   dzi, dzj       (n_local, D) f32 gradient of the mean loss (unit upstream gradient) */
+size_t grafp_ntxent_workspace(int B_all);
+int grafp_ntxent_num_partials(int n_local);
+int grafp_ntxent_fwd_bwd_f32(const float *zi_all, const float *zj_all, int B_all, int D, int row_begin,
+                             int n_local, float tau, float *loss_partial, float *dzi, float *dzj, void *ws,
+                             size_t ws_bytes, grafp_stream_t stream);
+
+/* ---- K13: brute-force fingerprint search ------------------------------------------------------
+ * Replaces faiss.IndexFlatL2 add/search as used at eval.py:54,212-213,269-270: exact squared-L2
+ * top-k, ascending, ids = row index + id_base, ties -> lowest id, id -1 / dist +inf when fewer than
+ * k rows exist.  Arithmetic order fixed in oracle/csrc/flat_search.c.
+ *   grafp_row_sqnorm_f32: the `index.add` step -- per-row squared norms of the resident database.
+ *   db (n,d) f32   db_sqnorm (n) f32   q (nq,d) f32   d == 128   1 <= k <= GRAFP_SEARCH_MAX_K
+ *   out_dist (nq,k) f32   out_ids (nq,k) int64 */
+int grafp_row_sqnorm_f32(const float *m, int64_t n, int d, float *out, grafp_stream_t stream);
+size_t grafp_knn_search_workspace(int64_t n, int nq, int d, int k);
+int grafp_knn_search_l2_f32(const float *db, const float *db_sqnorm, int64_t n, const float *q, int nq, int d,
+                            int k, int64_t id_base, float *out_dist, int64_t *out_ids, void *ws,
+                            size_t ws_bytes, grafp_stream_t stream);
+
+/* Merge P partial result lists (e.g. one per database shard/GPU after an all-gather):
+ *   part_dist (P,nq,k) f32, part_ids (P,nq,k) int64 (id < 0 = empty) -> out (nq,k), by (dist,id). */
+int grafp_merge_topk(const float *part_dist, const int64_t *part_ids, int P, int nq, int k, float *out_dist,
+                     int64_t *out_ids, grafp_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRAFP_HIP_H */

@@ -1,0 +1,307 @@
+"""GPU parity tests: every HIP kernel, called through the C ABI (grafp_amd.ops -> libgrafp_hip.so),
+against the oracle on the same seeded inputs.  Bit-exact for index-valued results; stated tolerances for
+floating point.  Run with `pytest -m gpu` on an MI355X."""
+import numpy as np
+import pytest
+import torch
+
+from _common import golden, hash_ints, hash_normalish, hash_uniform, knn_margin_mask
+
+pytestmark = pytest.mark.gpu
+
+CFG = dict(fs=16000, n_fft=1024, hop_len=512, win_len=1024, n_mels=64, n_frames=32, overlap=0.9, tau=0.05)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+# =============================================================== k-NN graph (bit-exact)
+@pytest.mark.parametrize("C,N,B,k", [(64, 1024, 3, 3), (128, 512, 2, 3), (256, 256, 2, 3), (512, 128, 3, 3),
+                                      (24, 100, 2, 3), (3, 101, 2, 2), (40, 37, 1, 5), (8, 8, 2, 8), (16, 300, 2, 1)])
+def test_knn_graph_bit_exact_vs_c_oracle(dev, C, N, B, k):
+    from grafp_amd import ops
+    from oracle import native
+    x = hash_normalish(f"gpu:knn.{C}.{N}", (B, C, N))
+    want = native.knn_graph(x, k, normalize=True)
+    got = ops.knn_graph(t(x).to(dev), k, normalize=True).cpu().numpy()
+    assert got.dtype == np.int64 and got.shape == (B, N, k)
+    mism = np.argwhere(got != want)
+    assert len(mism) == 0, f"{len(mism)} of {got.size} indices differ; first {mism[:5].tolist()}"
+    # un-normalised entry (dense_knn_matrix) on integer features, including genuine ties
+    xi = hash_ints(f"gpu:knn.int.{C}.{N}", (B, C, N), -3, 3).astype(np.float32)
+    want = native.knn_graph(xi, k, normalize=False)
+    got = ops.knn_graph(t(xi).to(dev), k, normalize=False).cpu().numpy()
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("C,N", [(64, 1024), (128, 512), (256, 256), (512, 128), (24, 100)])
+def test_knn_graph_matches_reference_goldens(dev, C, N):
+    """Against what the reference itself produced (tests/golden/knn_graph.npz), outside near-ties."""
+    from grafp_amd import ops
+    g = golden("knn_graph.npz")
+    xf = hash_normalish(f"in:knn.f32.{C}.{N}", (2, C, N, 1))
+    ok, _ = knn_margin_mask(xf, 3, tol=1e-5)
+    got = ops.knn_graph(t(xf).to(dev), 3).cpu().numpy()
+    assert np.array_equal(got[ok], g[f"f32_{C}_{N}"].astype(np.int64)[ok])
+    xi = hash_ints(f"in:knn.int.{C}.{N}", (2, C, N, 1), -8, 8).astype(np.float32)
+    ok, _ = knn_margin_mask(xi, 3, tol=0.5, normalize=False)
+    got = ops.knn_graph(t(xi).to(dev), 3, normalize=False).cpu().numpy()
+    assert np.array_equal(got[ok], g[f"int_{C}_{N}"].astype(np.int64)[ok])
+
+
+def test_knn_graph_full_batch_properties(dev):
+    """BASELINE config-2 size (B=256, stage 0): size-independent properties + a sampled exact check."""
+    from grafp_amd import ops
+    from oracle import native
+    gen = torch.Generator().manual_seed(0)
+    x = torch.randn(256, 64, 1024, generator=gen)
+    idx = ops.knn_graph(x.to(dev), 3).cpu()
+    assert idx.min() >= 0 and idx.max() < 1024
+    assert bool((idx[:, :, 0] == torch.arange(1024)).all())          # self first
+    assert bool((idx[:, :, 1] != idx[:, :, 2]).all())
+    for b in (0, 97, 255):
+        assert np.array_equal(idx[b].numpy(), native.knn_graph(x[b:b + 1].numpy(), 3)[0])
+
+
+def test_knn_graph_errors(dev):
+    from grafp_amd import ops
+    with pytest.raises(RuntimeError, match="k="):
+        ops.knn_graph(torch.zeros(1, 4, 4, device=dev), 9)
+    with pytest.raises(RuntimeError, match="CPU tensor"):
+        ops.knn_graph(torch.zeros(1, 4, 16), 3)
+
+
+# =============================================================== MRConv gather / max-relative
+@pytest.mark.parametrize("B,C,N,K", [(2, 64, 1024, 3), (3, 128, 512, 3), (2, 256, 256, 3), (2, 512, 128, 3),
+                                      (2, 10, 101, 3), (1, 7, 33, 5), (2, 8, 64, 1)])
+def test_max_relative_forward_backward(dev, B, C, N, K):
+    from grafp_amd import ops
+    from oracle import model as om
+    x = t(hash_normalish(f"gpu:mr.x.{C}.{N}", (B, C, N)))
+    idx = hash_ints(f"gpu:mr.idx.{C}.{N}", (B, N, K), 0, N - 1).astype(np.int64)
+    idx[:, :, 0] = np.arange(N)[None, :]
+    idx = t(idx)
+    g = t(hash_normalish(f"gpu:mr.g.{C}.{N}", (B, 2 * C, N)))
+    xr = x.clone().requires_grad_(True)
+    want = om.max_relative(xr, idx)
+    want.backward(g)
+    xg = x.to(dev).requires_grad_(True)
+    got = ops.max_relative(xg, idx.to(dev))
+    got.backward(g.to(dev))
+    assert torch.equal(got.detach().cpu(), want.detach())             # sub + max: exact
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_max_relative_golden(dev):
+    from grafp_amd import ops
+    g = golden("mrconv.npz")
+    B, C, N, K = 2, 8, 64, 3
+    x = t(hash_normalish("in:mr.x", (B, C, N, 1)))[..., 0].to(dev).requires_grad_(True)
+    idx = hash_ints("in:mr.idx", (B, N, K), 0, N - 1).astype(np.int64)
+    idx[:, :, 0] = np.arange(N)[None, :]
+    out = ops.max_relative(x, t(idx).to(dev))
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), g["inter"][..., 0])
+    out.backward(t(hash_normalish("in:mr.gi", (B, 2 * C, N, 1)))[..., 0].to(dev))
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g["dx_inter"][..., 0], rtol=1e-6, atol=1e-6)
+
+
+# =============================================================== NT-Xent
+@pytest.mark.parametrize("B,D,tau", [(2, 128, 0.05), (8, 128, 0.05), (32, 128, 0.05), (256, 128, 0.05),
+                                      (100, 128, 0.05), (33, 32, 0.5), (70, 64, 0.1)])
+def test_ntxent_vs_oracle(dev, B, D, tau):
+    """Tolerance: loss 2e-5 relative, gradients 1e-4 relative + 1e-7 absolute (f32 exp/log, different
+    summation order)."""
+    from grafp_amd import ops
+    from oracle import model as om
+    zi = hash_normalish(f"gpu:nt.zi.{B}.{D}", (B, D)); zj = zi + 0.3 * hash_normalish(f"gpu:nt.zj.{B}.{D}", (B, D))
+    zi /= np.linalg.norm(zi, axis=1, keepdims=True); zj /= np.linalg.norm(zj, axis=1, keepdims=True)
+    a = t(zi).clone().requires_grad_(True); b = t(zj).clone().requires_grad_(True)
+    want = om.ntxent(a, b, tau); want.backward()
+    ag = t(zi).to(dev).requires_grad_(True); bg = t(zj).to(dev).requires_grad_(True)
+    got = ops.ntxent(ag, bg, tau); got.backward()
+    np.testing.assert_allclose(got.item(), want.item(), rtol=2e-5)
+    np.testing.assert_allclose(ag.grad.cpu().numpy(), a.grad.numpy(), rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(bg.grad.cpu().numpy(), b.grad.numpy(), rtol=1e-4, atol=1e-7)
+
+
+def test_ntxent_reference_goldens(dev):
+    from grafp_amd.simclr.ntxent import ntxent_loss
+    g = golden("ntxent.npz")
+    for B in (2, 8, 32):
+        a = t(g[f"zi_{B}"]).to(dev).requires_grad_(True); b = t(g[f"zj_{B}"]).to(dev).requires_grad_(True)
+        loss = ntxent_loss(a, b, {"tau": 0.05}); loss.backward()
+        np.testing.assert_allclose(loss.item(), g[f"loss_{B}"], rtol=2e-5)
+        np.testing.assert_allclose(a.grad.cpu().numpy(), g[f"dzi_{B}"], rtol=1e-4, atol=1e-7)
+        np.testing.assert_allclose(b.grad.cpu().numpy(), g[f"dzj_{B}"], rtol=1e-4, atol=1e-7)
+
+
+def test_ntxent_local_rows_global_columns(dev):
+    """The data-parallel form: shares of the loss add up to the global loss; local gradients are the
+    corresponding slices of the global gradient (no backward collective needed)."""
+    from grafp_amd import ops
+    B, D, R = 96, 128, 3
+    zi = hash_normalish("gpu:nt.dp.zi", (B, D)); zj = hash_normalish("gpu:nt.dp.zj", (B, D))
+    zi /= np.linalg.norm(zi, axis=1, keepdims=True); zj /= np.linalg.norm(zj, axis=1, keepdims=True)
+    zi_all, zj_all = t(zi).to(dev), t(zj).to(dev)
+    a = zi_all.clone().requires_grad_(True); b = zj_all.clone().requires_grad_(True)
+    full = ops.ntxent(a, b, 0.05); full.backward()
+    total = 0.0
+    for r in range(R):
+        lo, hi = r * B // R, (r + 1) * B // R
+        al = zi_all[lo:hi].clone().requires_grad_(True); bl = zj_all[lo:hi].clone().requires_grad_(True)
+        part = ops.ntxent(al, bl, 0.05, zi_all, zj_all, lo); part.backward()
+        total += part.item()
+        np.testing.assert_allclose(al.grad.cpu().numpy(), a.grad[lo:hi].cpu().numpy(), rtol=1e-5, atol=1e-8)
+        np.testing.assert_allclose(bl.grad.cpu().numpy(), b.grad[lo:hi].cpu().numpy(), rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(total, full.item(), rtol=1e-5)
+
+
+# =============================================================== log-mel + segmentation
+def test_logmel_vs_oracle(dev):
+    """Tolerance: 2e-3 dB absolute (f32 FFT of different radix/order than torch.stft's)."""
+    from grafp_amd import ops
+    from oracle import model as om
+    x = 0.1 * hash_normalish("gpu:logmel.x", (5, 16000))
+    x[4] *= 0.01                                             # a quiet clip
+    want = om.logmel(t(x), CFG).numpy()
+    got = ops.logmel(t(x).to(dev)).cpu().numpy()
+    assert got.shape == (5, 64, 32)
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-3)
+    z = ops.logmel(torch.zeros(1, 16000, device=dev)).cpu().numpy()
+    assert np.allclose(z, -100.0)                            # 10*log10(1e-10)
+
+
+def test_whole_track_segments_vs_oracle(dev):
+    from grafp_amd.modules.transformations import GPUTransformNeuralfp
+    from oracle import model as om
+    cfg = dict(CFG, arch="grafp", dur=1.0)
+    x = 0.1 * hash_normalish("gpu:logmel.track", (1, 16000 * 7 + 123))
+    want = om.val_segments(t(x), CFG).numpy()
+    aug = GPUTransformNeuralfp(cfg, None, None, train=False)
+    Xi, Xj = aug(t(x).to(dev), None)
+    assert Xi.shape == want.shape and Xi.is_contiguous()
+    np.testing.assert_allclose(Xi.cpu().numpy(), want, rtol=0, atol=2e-3)
+    assert Xj is Xi
+    tr = GPUTransformNeuralfp(cfg, None, None, train=True)
+    a, b = tr(t(x[:, :16000]).to(dev), t(x[:, 16000:32000]).to(dev))
+    np.testing.assert_allclose(b.cpu().numpy(), om.logmel(t(x[:, 16000:32000]), CFG).numpy(), atol=2e-3)
+
+
+# =============================================================== peak extractor
+def test_peak_extract_forward_backward(dev):
+    """Tolerance 1e-4 relative / 1e-5 absolute (147-term f32 dot products in a different order)."""
+    from grafp_amd import ops
+    from oracle import model as om
+    for name, B in (("a", 2), ("b", 5)):
+        spec = t(40.0 * hash_uniform(f"gpu:peak.spec.{name}", (B, 64, 32)) - 30.0)
+        w = t(0.1 * hash_normalish("gpu:peak.w", (8, 3, 7, 7))).requires_grad_(True)
+        bias = t(0.05 * hash_normalish("gpu:peak.b", (8,))).requires_grad_(True)
+        sd = {"peak_extractor.convs.0.weight": w, "peak_extractor.convs.0.bias": bias}
+        want = om.peak_extract(sd, spec)
+        g = t(hash_normalish(f"gpu:peak.g.{name}", tuple(want.shape)))
+        want.backward(g)
+        wg = w.detach().to(dev).requires_grad_(True); bg = bias.detach().to(dev).requires_grad_(True)
+        got = ops.peak_extract(spec.to(dev), wg, bg, 2)
+        got.backward(g.to(dev))
+        np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().numpy(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(wg.grad.cpu().numpy(), w.grad.numpy(), rtol=1e-3, atol=1e-4)
+        np.testing.assert_allclose(bg.grad.cpu().numpy(), bias.grad.numpy(), rtol=1e-3, atol=1e-4)
+        w.grad = None; bias.grad = None
+
+
+def test_peak_extract_reference_golden(dev):
+    from _hashfill import fill_state_dict
+    from grafp_amd import ops
+    g = golden("peak_extractor.npz")
+    raw = fill_state_dict({"convs.0.weight": (8, 3, 7, 7), "convs.0.bias": (8,)}, "pe")
+    spec = t(40.0 * hash_uniform("in:peak.spec", (2, 64, 32)) - 30.0).to(dev)
+    out = ops.peak_extract(spec, t(raw["convs.0.weight"]).to(dev), t(raw["convs.0.bias"]).to(dev), 2)
+    np.testing.assert_allclose(out.cpu().numpy(), g["out"], rtol=1e-4, atol=1e-5)
+
+
+# =============================================================== brute-force search (bit-exact ids and distances)
+def _planted(n, nq, seed, noise=0.05):
+    db = hash_normalish(f"gpu:sr.db.{seed}", (n, 128)); db /= np.linalg.norm(db, axis=1, keepdims=True)
+    rows = (np.arange(nq) * 7919) % n
+    q = db[rows] + noise * hash_normalish(f"gpu:sr.q.{seed}", (nq, 128))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    return db.astype(np.float32), q.astype(np.float32), rows
+
+
+@pytest.mark.parametrize("n,nq,k", [(1000, 1, 20), (1000, 5, 1), (5000, 41, 20), (5000, 70, 20), (20000, 300, 20),
+                                     (777, 33, 32), (129, 64, 7), (50000, 41, 20)])
+def test_search_bit_exact_vs_c_oracle(dev, n, nq, k):
+    from grafp_amd import ops
+    from oracle import native
+    db, q, rows = _planted(n, nq, f"{n}.{nq}")
+    want_d, want_i = native.flat_search_l2(db, q, k)
+    dbt = t(db).to(dev)
+    got_d, got_i = ops.search_l2(dbt, ops.row_sqnorm(dbt), t(q).to(dev), k)
+    got_d, got_i = got_d.cpu().numpy(), got_i.cpu().numpy()
+    mism = np.argwhere(got_i != want_i)
+    assert len(mism) == 0, f"{len(mism)} ids differ; first {mism[:5].tolist()}"
+    assert np.array_equal(got_d, want_d)
+    assert np.array_equal(got_i[:, 0], rows)                          # planted answers
+
+
+def test_search_edge_cases(dev):
+    from grafp_amd import ops
+    from oracle import native
+    db, q, _ = _planted(300, 9, "edge")
+    dup = np.tile(db[:25], (8, 1))                                    # every row 8 times: ties -> lowest id
+    dupt = t(dup).to(dev)
+    d, i = ops.search_l2(dupt, ops.row_sqnorm(dupt), t(db[:9]).to(dev), 20)
+    wd, wi = native.flat_search_l2(dup, db[:9], 20)
+    assert np.array_equal(i.cpu().numpy(), wi) and np.array_equal(d.cpu().numpy(), wd)
+    small = t(db[:5]).to(dev)                                         # fewer rows than k: -1 / inf padding
+    d, i = ops.search_l2(small, ops.row_sqnorm(small), t(q).to(dev), 20)
+    assert (i[:, 5:] == -1).all() and torch.isinf(d[:, 5:]).all() and (i[:, :5] >= 0).all()
+    idx = ops.FlatL2Index(128)                                        # faiss-like surface, numpy in/out
+    idx.add(db[:100]); idx.add(db[100:])
+    D, I = idx.search(q, 20)
+    wd, wi = native.flat_search_l2(db, q, 20)
+    assert isinstance(I, np.ndarray) and np.array_equal(I, wi) and np.array_equal(D, wd)
+
+
+def test_merge_topk_and_sharded_search(dev):
+    from grafp_amd import ops
+    from oracle import native
+    db, q, _ = _planted(9000, 50, "shard")
+    parts_d, parts_i = [], []
+    for s in range(0, 9000, 3000):
+        sh = t(db[s:s + 3000]).to(dev)
+        d, i = ops.search_l2(sh, ops.row_sqnorm(sh), t(q).to(dev), 20, id_base=s)
+        parts_d.append(d); parts_i.append(i)
+    md, mi = ops.merge_topk(torch.stack(parts_d), torch.stack(parts_i))
+    wd, wi = native.flat_search_l2(db, q, 20)
+    assert np.array_equal(mi.cpu().numpy(), wi) and np.array_equal(md.cpu().numpy(), wd)
+    od, oi = native.merge_topk(torch.stack(parts_d).cpu().numpy(), torch.stack(parts_i).cpu().numpy())
+    assert np.array_equal(mi.cpu().numpy(), oi) and np.array_equal(md.cpu().numpy(), od)
+
+
+def test_search_1m_planted_top1(dev):
+    """BASELINE config 4 size: 1 000 000 x 128 database resident on the GPU; planted noisy queries must
+    come back top-1, and a sample of queries must match the CPU oracle exactly."""
+    from grafp_amd import ops
+    from oracle import native
+    gen = torch.Generator(device="cpu").manual_seed(2)
+    db = torch.nn.functional.normalize(torch.randn(1_000_000, 128, generator=gen), dim=1)
+    rows = torch.randint(0, 1_000_000, (4096,), generator=gen)
+    q = torch.nn.functional.normalize(db[rows] + 0.03 * torch.randn(4096, 128, generator=gen), dim=1)
+    dbt = db.to(dev)
+    sq = ops.row_sqnorm(dbt)
+    d, i = ops.search_l2(dbt, sq, q.to(dev), 20)
+    assert torch.equal(i[:, 0].cpu(), rows)
+    assert bool((d[:, 1:] >= d[:, :-1]).all())                        # sorted ascending
+    for nq in (1, 41):
+        dd, ii = ops.search_l2(dbt, sq, q[:nq].to(dev), 20)
+        wd, wi = native.flat_search_l2(db.numpy(), q[:nq].numpy(), 20)
+        assert np.array_equal(ii.cpu().numpy(), wi) and np.array_equal(dd.cpu().numpy(), wd)
+        assert torch.equal(ii.cpu(), i[:nq].cpu())                    # batch-size independent
