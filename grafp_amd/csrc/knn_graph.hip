@@ -60,17 +60,22 @@ struct TopK {
             i[t] = 0x7fffffff;
         }
     }
-    // Compare-exchange chain (min/max + index selects, branch-free): the new element bubbles down,
-    // displacing larger entries.  Candidates arrive in ascending index order within a lane, so strict
-    // '<' keeps the lower index on ties.
+    // Sorted insert as a carry chain of plain selects (branch-free).  `take` compares the ORIGINAL new
+    // value with each OLD slot: in a sorted list that predicate is monotone (false...false,true...true),
+    // so the first true slot receives the new element and every later slot receives its predecessor.
+    // Candidates arrive in ascending index order within a lane, so strict '<' keeps the lower index on
+    // ties, and a displaced (older) element always moves down regardless of ties.
     __device__ __forceinline__ void push_ascending(float v, int vi) {
+        const float v0 = v;
 #pragma unroll
         for (int t = 0; t < K; ++t) {
-            const bool lt = v < d[t];
-            const float lo = fminf(v, d[t]), hi = fmaxf(v, d[t]);
-            const int ilo = lt ? vi : i[t], ihi = lt ? i[t] : vi;
-            d[t] = lo; i[t] = ilo;
-            v = hi; vi = ihi;
+            const bool take = v0 < d[t];
+            const float od = d[t];
+            const int oi = i[t];
+            d[t] = take ? v : od;
+            i[t] = take ? vi : oi;
+            v = take ? od : v;
+            vi = take ? oi : vi;
         }
     }
     // arbitrary order: full (distance, index) lexicographic comparison

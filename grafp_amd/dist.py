@@ -1,0 +1,183 @@
+"""Data parallelism: one process per GPU, torch.distributed over RCCL (backend "nccl" on ROCm) / xGMI.
+
+The reference's only multi-GPU mechanism is nn.DataParallel (train.py:165-168): per step it broadcasts
+the 82.7 MB state dict, scatters the batch, gathers h/z to GPU 0 (which makes the NT-Xent negatives
+global, train.py:69-71) and reduces 73.5 MB of gradients to GPU 0.  Here:
+  * parameters are replicated once (DDP style), BatchNorm statistics stay per replica as under DataParallel;
+  * ONE all-gather of the stacked (z_i, z_j) per step (2 * B/R * 128 f32 per rank: latency-bound, so both
+    views travel in a single call); each rank then evaluates its own rows against the global columns with
+    ops.ntxent, whose backward already returns d(global loss)/d(local z): no collective in backward;
+  * gradients live in ONE flat f32 buffer (parameter .grad tensors are views into it) and are summed
+    with a few large all-reduces launched from autograd hooks as soon as a bucket is complete (overlap
+    with the rest of backward).  xGMI is point-to-point, ring collectives are per-link bound (~153 GB/s):
+    few, large buckets (default 4 x ~18 MB) keep the ring busy without paying per-call latency 100+ times;
+  * the fingerprint database is sharded by contiguous row ranges; a search is a local top-k, one
+    all-gather of (nq, k) candidates and a local merge.
+Everything that touches a collective takes the compute step as an argument, so the plumbing is testable
+on CPU with the gloo backend (tests/test_dist_cpu.py) without any CPU fallback in the product path.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as set by torch.distributed.run.  Returns (rank, world, device)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local)
+        device = torch.device("cuda", local)
+    else:
+        device = torch.device("cpu")
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        backend = backend or ("nccl" if device.type == "cuda" else "gloo")
+        kw = {"device_id": device} if backend == "nccl" else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, world, device
+
+
+def world_size(group=None):
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank_of(group=None):
+    return dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
+
+
+def all_gather_embeddings(z_i, z_j, group=None):
+    """(B_loc, D) x 2 -> (R*B_loc, D) x 2, rank-major, detached.  One collective for both views."""
+    R = world_size(group)
+    zi, zj = z_i.detach().float().contiguous(), z_j.detach().float().contiguous()
+    if R == 1:
+        return zi, zj
+    mine = torch.stack((zi, zj), dim=0)                                   # (2, B_loc, D)
+    out = torch.empty((R,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
+    dist.all_gather_into_tensor(out, mine, group=group)
+    out = out.permute(1, 0, 2, 3)                                         # (2, R, B_loc, D)
+    return out[0].reshape(-1, zi.shape[1]).contiguous(), out[1].reshape(-1, zi.shape[1]).contiguous()
+
+
+def ntxent_global(z_i, z_j, tau, group=None, loss_fn=None):
+    """NT-Xent with negatives from every rank.  Returns this rank's SHARE of the global mean loss (the
+    shares sum to the loss the reference computes on the gathered batch); backward gives the gradient of the
+    GLOBAL loss w.r.t. the local embeddings.  loss_fn(z_i, z_j, tau, zi_all, zj_all, row_begin)."""
+    if loss_fn is None:
+        from . import ops
+        loss_fn = ops.ntxent
+    zi_all, zj_all = all_gather_embeddings(z_i, z_j, group)
+    return loss_fn(z_i, z_j, tau, zi_all, zj_all, rank_of(group) * z_i.shape[0])
+
+
+class GradSync:
+    """Flat-buffer gradient all-reduce (SUM) with bucketed launch from autograd hooks.
+
+    The sum (not the mean) is the right reduction: each rank back-propagates d(global loss)/d(z_local),
+    so the per-rank parameter gradients are the disjoint terms of the full gradient, exactly what
+    DataParallel's reduce-to-GPU-0 adds up (train.py:165-168)."""
+
+    def __init__(self, params, group=None, n_buckets=4, overlap=True):
+        self.group = group
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("no trainable parameters")
+        dev, total = self.params[0].device, sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.world = world_size(group)
+        # gradients become ready roughly in reverse registration order: lay the buffer out that way so
+        # every bucket is a contiguous slice that completes early
+        order = list(reversed(self.params))
+        per_bucket = (total + n_buckets - 1) // max(1, n_buckets)
+        self.bounds, self._bucket_of, off, b_lo = [], {}, 0, 0
+        for p in order:
+            n = p.numel()
+            p.grad = self.flat[off:off + n].view_as(p)
+            self._bucket_of[id(p)] = len(self.bounds)
+            off += n
+            if off - b_lo >= per_bucket:
+                self.bounds.append((b_lo, off))
+                b_lo = off
+        if b_lo < off:
+            self.bounds.append((b_lo, off))
+        self._size = [0] * len(self.bounds)
+        for p in self.params:
+            self._size[self._bucket_of[id(p)]] += 1
+        self._left, self._handles, self._fired = list(self._size), [], [False] * len(self.bounds)
+        self._hooks = []
+        if overlap and self.world > 1:
+            for p in self.params:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    def zero(self):
+        """Use instead of optimizer.zero_grad(): keeps every .grad a view of the flat buffer."""
+        self.flat.zero_()
+
+    def _launch(self, b):
+        lo, hi = self.bounds[b]
+        self._handles.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self._fired[b] = True
+
+    def _on_grad(self, p):
+        b = self._bucket_of[id(p)]
+        self._left[b] -= 1
+        if self._left[b] == 0 and not self._fired[b]:
+            self._launch(b)
+
+    def finish(self):
+        """Call after backward(): launches whatever has not fired, waits for all buckets."""
+        if self.world > 1:
+            for b in range(len(self.bounds)):
+                if not self._fired[b]:
+                    self._launch(b)
+            for h in self._handles:
+                h.wait()
+        self._handles, self._left, self._fired = [], list(self._size), [False] * len(self.bounds)
+
+
+def shard_range(n, rank, world):
+    """Contiguous row range [lo, hi) of rank `rank` out of `world` for an n-row database."""
+    per = (n + world - 1) // world
+    lo = min(n, rank * per)
+    return lo, min(n, lo + per)
+
+
+class ShardedFlatL2Index:
+    """Row-sharded exact search: every rank holds rows shard_range(n, rank, world) of the database.
+    search(q, k): local top-k (ids offset by the shard start) -> all-gather of (nq, k) dist+ids -> merge.
+    `local_index_factory(id_base)` and `merge_fn(part_d, part_i)` default to the HIP implementations."""
+
+    def __init__(self, d=128, group=None, local_index_factory=None, merge_fn=None):
+        self.d, self.group = d, group
+        self.rank, self.world = rank_of(group), world_size(group)
+        self._factory, self._merge = local_index_factory, merge_fn
+        self.local = None
+        self.ntotal = 0
+
+    def add_global(self, x):
+        """Every rank passes the SAME full (n, d) array (host or memmap); each keeps only its rows."""
+        n = len(x)
+        lo, hi = shard_range(n, self.rank, self.world)
+        if self._factory is None:
+            from .ops import FlatL2Index
+            self._factory = lambda id_base: FlatL2Index(self.d, id_base=id_base)
+        self.local = self._factory(lo + self.ntotal)
+        self.local.add(x[lo:hi])
+        self.ntotal += n
+
+    def search(self, q, k):
+        D, I = self.local.search(q, k)
+        if self.world == 1:
+            return D, I
+        D, I = torch.as_tensor(D), torch.as_tensor(I)
+        gd = torch.empty((self.world,) + tuple(D.shape), dtype=D.dtype, device=D.device)
+        gi = torch.empty((self.world,) + tuple(I.shape), dtype=I.dtype, device=I.device)
+        dist.all_gather_into_tensor(gd, D.contiguous(), group=self.group)
+        dist.all_gather_into_tensor(gi, I.contiguous(), group=self.group)
+        if self._merge is None:
+            from .ops import merge_topk
+            self._merge = merge_topk
+        return self._merge(gd, gi)

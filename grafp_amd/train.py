@@ -1,0 +1,69 @@
+"""Training-step harness (counterpart of train.py:56-82, 164-177 for synthetic or pre-loaded waveforms).
+
+Step semantics reproduced: zero grads -> (no_grad) log-mel of both views -> SimCLR forward, the two views
+sequentially -> NT-Xent on the whole (global) batch -> backward -> Adam step; fp32 parameters, optional bf16
+autocast for the GEMMs (the graph build, gather and loss kernels always run in f32).  The reference's
+per-step `loss.item()` host sync (train.py:80) is NOT reproduced: the loss stays on the device.
+"""
+import contextlib
+
+import torch
+
+from . import dist as gdist
+from .encoder.graph_encoder import GraphEncoder
+from .modules.transformations import GPUTransformNeuralfp
+from .simclr.ntxent import ntxent_loss
+from .simclr.simclr import SimCLR
+
+
+def build_model(cfg, k=3, device=None):
+    model = SimCLR(cfg, encoder=GraphEncoder(cfg=cfg, in_channels=cfg["n_filters"], k=k))   # == train.py:164
+    return model.to(device) if device is not None else model
+
+
+class Trainer:
+    def __init__(self, cfg, model, device, amp_dtype=None, group=None, lr=None, n_buckets=4):
+        self.cfg, self.model, self.device, self.group = cfg, model, device, group
+        self.amp_dtype = amp_dtype
+        self.world = gdist.world_size(group)
+        self.augment = GPUTransformNeuralfp(cfg, None, None, train=True)
+        self.opt = torch.optim.Adam(model.parameters(), lr=lr or cfg["lr"])             # train.py:174
+        self.sched = torch.optim.lr_scheduler.CosineAnnealingLR(self.opt, T_max=cfg["T_max"], eta_min=cfg["min_lr"])
+        self.sync = gdist.GradSync(model.parameters(), group=group, n_buckets=n_buckets)
+
+    def _autocast(self):
+        if self.amp_dtype is None:
+            return contextlib.nullcontext()
+        return torch.autocast(device_type="cuda", dtype=self.amp_dtype)
+
+    def step(self, x_i, x_j):
+        """x_i, x_j: (B_local, T) waveforms already on the device.  Returns this rank's share of the loss
+        (a 0-d device tensor; the shares sum to the global mean loss)."""
+        self.model.train()
+        self.sync.zero()
+        with torch.no_grad():
+            X_i, X_j = self.augment(x_i, x_j)
+        with self._autocast():
+            _, _, z_i, z_j = self.model(X_i, X_j)
+        if self.world > 1:
+            loss = gdist.ntxent_global(z_i, z_j, self.cfg["tau"], self.group)
+        else:
+            loss = ntxent_loss(z_i, z_j, self.cfg)
+        loss.backward()
+        self.sync.finish()
+        self.opt.step()
+        return loss.detach()
+
+    def checkpoint(self, epoch, loss_log, hit_rate_log, hit_rates=None):
+        """The dict layout of train.py:212-220."""
+        return {"epoch": epoch, "loss": loss_log, "valid_acc": hit_rate_log, "hit_rate": hit_rates,
+                "state_dict": self.model.state_dict(), "optimizer": self.opt.state_dict(),
+                "scheduler": self.sched.state_dict()}
+
+
+def synthetic_batch(batch, seed, device, n_samples=16000):
+    """x_i = 0.1*randn, x_j = x_i + 0.03*randn (CPU generator, then copied)."""
+    gen = torch.Generator().manual_seed(seed)
+    x_i = 0.1 * torch.randn(batch, n_samples, generator=gen)
+    x_j = x_i + 0.03 * torch.randn(batch, n_samples, generator=gen)
+    return x_i.to(device), x_j.to(device)

@@ -116,19 +116,21 @@ def test_max_relative_golden(dev):
 @pytest.mark.parametrize("B,D,tau", [(2, 128, 0.05), (8, 128, 0.05), (32, 128, 0.05), (256, 128, 0.05),
                                       (100, 128, 0.05), (33, 32, 0.5), (70, 64, 0.1)])
 def test_ntxent_vs_oracle(dev, B, D, tau):
-    """Tolerance: loss 2e-5 relative, gradients 1e-4 relative + 1e-7 absolute (f32 exp/log, different
-    summation order)."""
+    """Tolerance: loss 2e-5 relative, gradients 1e-4 relative + 1e-5 of the largest gradient entry (f32
+    exp/log, different summation order)."""
     from grafp_amd import ops
     from oracle import model as om
-    zi = hash_normalish(f"gpu:nt.zi.{B}.{D}", (B, D)); zj = zi + 0.3 * hash_normalish(f"gpu:nt.zj.{B}.{D}", (B, D))
+    zi = hash_normalish(f"gpu:nt.zi.{B}.{D}", (B, D)); zj = zi + 2.0 * hash_normalish(f"gpu:nt.zj.{B}.{D}", (B, D))
     zi /= np.linalg.norm(zi, axis=1, keepdims=True); zj /= np.linalg.norm(zj, axis=1, keepdims=True)
     a = t(zi).clone().requires_grad_(True); b = t(zj).clone().requires_grad_(True)
     want = om.ntxent(a, b, tau); want.backward()
     ag = t(zi).to(dev).requires_grad_(True); bg = t(zj).to(dev).requires_grad_(True)
     got = ops.ntxent(ag, bg, tau); got.backward()
+    assert want.item() > 1e-3                                         # a non-trivial loss
     np.testing.assert_allclose(got.item(), want.item(), rtol=2e-5)
-    np.testing.assert_allclose(ag.grad.cpu().numpy(), a.grad.numpy(), rtol=1e-4, atol=1e-7)
-    np.testing.assert_allclose(bg.grad.cpu().numpy(), b.grad.numpy(), rtol=1e-4, atol=1e-7)
+    gmax = float(a.grad.abs().max())
+    np.testing.assert_allclose(ag.grad.cpu().numpy(), a.grad.numpy(), rtol=1e-4, atol=1e-5 * gmax)
+    np.testing.assert_allclose(bg.grad.cpu().numpy(), b.grad.numpy(), rtol=1e-4, atol=1e-5 * gmax)
 
 
 def test_ntxent_reference_goldens(dev):
