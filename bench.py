@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py -- GraFPrint contrastive training step on N MI355X GPUs of one node (one process per GPU).
+
+    python bench.py [--gpus 1] [--steps 20] [--warmup 5]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = zero-grad -> log-mel of both views -> SimCLR forward (peak extractor, 12 Grapher+FFN blocks with a
+k-NN graph rebuilt in each, projector) for both views -> NT-Xent over the GLOBAL batch -> backward -> gradient
+all-reduce -> Adam.  Inputs are synthetic 1 s clips already resident in HBM; weights
+are randomly initialised (the architecture and shapes are config/grafp.yaml's).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_F32_MATRIX_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, = f32 vector peak
+PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch-per-gpu", type=int, default=256,
+                    help="positive pairs per GPU and step (weak scaling; BASELINE config 2 = 256 on 1 GPU)")
+    ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16", help="GEMM compute dtype (autocast)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-retrieval", action="store_true")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=25.0)
+    return ap.parse_args()
+
+
+def knn_flops(meta):
+    B, C, N, _k = meta
+    return 2.0 * N * N * C * B
+
+
+def mrconv_bytes(meta, backward=False):
+    B, C, N, K = meta
+    return (4.0 * C * N + 8.0 * K * N + 8.0 * C * N) * B      # x + idx + interleaved (B,2C,N); bwd same order
+
+
+def summarise_kernels(timed):
+    """name -> dict(calls, total_ms, avg_us, achieved, unit, peak, frac, bound) from HIP-event records."""
+    from grafp_amd import ops
+    out = {}
+    for name, ev in timed.items():
+        if not ev:
+            continue
+        ms = ops.elapsed_ms(ev)
+        tot = sum(ms)
+        row = {"calls": len(ev), "total_ms": round(tot, 4), "avg_us": round(1e3 * tot / len(ev), 2)}
+        if name == "knn_topk":
+            fl = sum(knn_flops(m) for _, _, m in ev)
+            row.update(bound="mfma", achieved=round(fl / (tot * 1e-3) / 1e12, 3), unit="TFLOP/s",
+                       peak=PEAK_F32_MATRIX_TFLOPS)
+        elif name in ("mrconv_fwd", "mrconv_bwd"):
+            by = sum(mrconv_bytes(m) for _, _, m in ev)
+            row.update(bound="hbm", achieved=round(by / (tot * 1e-3) / 1e9, 1), unit="GB/s", peak=PEAK_HBM_GBS)
+        elif name == "logmel":
+            by = sum(B * (4.0 * T + 4.0 * 64 * (1 + T // 512)) for _, _, (B, T) in ev)
+            row.update(bound="hbm", achieved=round(by / (tot * 1e-3) / 1e9, 1), unit="GB/s", peak=PEAK_HBM_GBS)
+        elif name == "peak_extract_fwd":
+            by = sum(B * (8192.0 + 32768.0) for _, _, (B,) in ev)
+            row.update(bound="hbm", achieved=round(by / (tot * 1e-3) / 1e9, 1), unit="GB/s", peak=PEAK_HBM_GBS)
+        if "achieved" in row:
+            row["frac"] = round(row["achieved"] / row["peak"], 4)
+        out[name] = row
+    return out
+
+
+def cpu_baseline(cfg, seconds):
+    """The oracle's CPU train step (test infrastructure used ONLY as the reported baseline): B = 32 pairs,
+    log-mel -> peak extractor -> GraphEncoder -> projector -> NT-Xent, fwd + bwd + Adam, f32, all host
+    threads.  1 warm-up step, then timed steps until >= 3 steps or `seconds` have elapsed."""
+    from grafp_amd.train import build_model
+    from oracle import model as om
+    B = 32
+    torch.manual_seed(0)
+    sd = {k: v.clone() for k, v in build_model(dict(cfg, bsz_train=B)).state_dict().items()}
+    for k, v in sd.items():
+        if v.is_floating_point() and k.rsplit(".", 1)[-1] not in ("running_mean", "running_var", "relative_pos"):
+            v.requires_grad_(True)
+    params = list(om.trainable(sd).values())
+    opt = torch.optim.Adam(params, lr=cfg["lr"])
+    gen = torch.Generator().manual_seed(0)
+    x_i = 0.1 * torch.randn(B, 16000, generator=gen)
+    x_j = x_i + 0.03 * torch.randn(B, 16000, generator=torch.Generator().manual_seed(1))
+
+    def step():
+        with torch.no_grad():
+            S_i, S_j = om.logmel(x_i, cfg), om.logmel(x_j, cfg)
+        return om.train_step(sd, opt, S_i, S_j, cfg["tau"])
+    step()
+    n, t0 = 0, time.perf_counter()
+    while n < 3 or (time.perf_counter() - t0 < seconds and n < 50):
+        step()
+        n += 1
+        if time.perf_counter() - t0 > 4 * seconds:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": round(B * n / dt, 3), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle CPU step, B=32 pairs (64 clip-views), fwd+bwd+Adam, f32, 1 warm-up + {n} timed "
+                      f"steps in {dt:.1f} s"}
+
+
+def retrieval_probe(device):
+    """Secondary metric of BASELINE.json: exact top-20 search QPS on a 1 000 000 x 128 resident database
+    (L2-normalised randn, seed 2), planted noisy queries; batch sizes 1, 41, 4096."""
+    from grafp_amd import ops
+    gen = torch.Generator(device=device).manual_seed(2)
+    n = 1_000_000
+    db = torch.nn.functional.normalize(torch.randn(n, 128, generator=gen, device=device), dim=1)
+    rows = torch.randint(0, n, (4096,), generator=gen, device=device)
+    q = torch.nn.functional.normalize(db[rows] + 0.05 * torch.randn(4096, 128, generator=gen, device=device), dim=1)
+    sq = ops.row_sqnorm(db)
+    res = {"db": "1000000x128 f32 resident", "k": 20}
+    for nq, reps in ((1, 20), (41, 20), (4096, 5)):
+        ops.search_l2(db, sq, q[:nq], 20)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            _, I = ops.search_l2(db, sq, q[:nq], 20)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        res[f"qps_nq{nq}"] = round(nq / dt, 1)
+        res[f"ms_per_batch_nq{nq}"] = round(dt * 1e3, 4)
+        if nq == 4096:
+            res["top1_hit_rate"] = round(float((I[:, 0] == rows).float().mean().item()), 4)
+            res["tflops_nq4096"] = round(2.0 * 128 * n * nq / dt / 1e12, 2)
+        if nq == 1:
+            res["db_stream_GBps_nq1"] = round(n * 516.0 / dt / 1e9, 1)
+    return res
+
+
+def main():
+    args = parse()
+    from grafp_amd import dist as gdist
+    from grafp_amd import ops
+    from grafp_amd.train import Trainer, build_model, synthetic_batch
+    from grafp_amd.util import load_config
+
+    rank, world, device = gdist.init_from_env()
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (the hot path has no CPU fallback)"
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.backends.cudnn.benchmark = False
+    cfg = load_config()
+    cfg["bsz_train"] = args.batch_per_gpu * world
+    B = args.batch_per_gpu
+
+    torch.manual_seed(1234)                                   # identical initial weights on every rank
+    model = build_model(cfg, device=device)
+    amp = torch.bfloat16 if args.dtype == "bf16" else None
+    trainer = Trainer(cfg, model, device, amp_dtype=amp)
+    x_i, x_j = synthetic_batch(B, seed=100 + rank, device=device)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.step(x_i, x_j)
+    barrier()
+    names = ("knn_topk", "knn_normalize", "mrconv_fwd", "mrconv_bwd", "ntxent", "logmel", "peak_extract_fwd",
+             "peak_extract_bwd")
+    with ops.time_kernels(*names) as timed:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = trainer.step(x_i, x_j)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        kernels = summarise_kernels(timed)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        loss_sum = loss.clone()
+        dist.all_reduce(loss_sum)
+        loss = loss_sum
+    elapsed = float(t.item())
+
+    if rank == 0:
+        clips = B * world * args.steps
+        dom = kernels.get("knn_topk", {})
+        roof = {"kernel": "knn_topk_kernel", "bound": "mfma", "achieved": dom.get("achieved"),
+                "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": dom.get("frac"), "traffic": None,
+                "avg_launch_us": dom.get("avg_us"), "launches": dom.get("calls"),
+                "note": "exact-f32 MFMA (v_mfma_f32_32x32x2_f32); algorithmic flops 2*N^2*C per clip per block; "
+                        "HIP events on the launch stream inside the timed region"}
+        line = {
+            "metric": "clips/sec contrastive step", "value": round(clips / elapsed, 2), "unit": "clips/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"fma_small-shaped contrastive step, {B} pairs/GPU x {world} GPU "
+                                   f"(global batch {B * world}), 1 s clips @16 kHz, mel->kNN-graph->GNN->NT-Xent, "
+                                   "fwd+bwd+Adam, random-init GraphEncoder-t (18.4M params)",
+                       "global_batch": B * world, "parallelism": f"dp{world}", "k": 3},
+            "loss": round(float(loss.item()), 5),
+            "roofline": roof,
+            "kernels": kernels,
+        }
+        if world == 1 and not args.no_retrieval:
+            line["retrieval"] = retrieval_probe(device)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg, args.cpu_baseline_seconds)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -28,6 +28,8 @@ SIGNATURES = {
     "grafp_peak_extract_fwd_f32": (_I, [_P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
     "grafp_peak_extract_bwd_f32": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "grafp_knn_graph_workspace": (_Z, [_I, _I, _I]),
+    "grafp_knn_normalize_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
+    "grafp_knn_topk_f32": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
     "grafp_knn_graph_f32": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _Z, _P]),
     "grafp_mrconv_fwd_f32": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
     "grafp_mrconv_bwd_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),

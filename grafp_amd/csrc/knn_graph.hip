@@ -201,23 +201,8 @@ extern "C" size_t grafp_knn_graph_workspace(int B, int C, int N) {
     return xn + sq;
 }
 
-extern "C" int grafp_knn_graph_f32(const float *x, int B, int C, int N, int k, int normalize, int64_t *idx, void *ws,
-                                   size_t ws_bytes, grafp_stream_t stream) {
+static int knn_topk_launch(const float *xn, const float *sq, int B, int C, int N, int k, int64_t *idx, hipStream_t s) {
     using namespace grafp;
-    GRAFP_REQUIRE(x && idx, "knn_graph: null pointer");
-    GRAFP_REQUIRE(B > 0 && C > 0 && N > 0, "knn_graph: bad shape B=%d C=%d N=%d", B, C, N);
-    GRAFP_REQUIRE(k >= 1 && k <= GRAFP_KNN_MAX_K && k <= N, "knn_graph: k=%d must be in [1, min(N=%d, %d)]", k, N,
-                  GRAFP_KNN_MAX_K);
-    const size_t need = grafp_knn_graph_workspace(B, C, N);
-    if (!ws || ws_bytes < need) {
-        set_error("knn_graph: workspace %zu bytes < required %zu", ws_bytes, need);
-        return GRAFP_ERR_WORKSPACE;
-    }
-    hipStream_t s = (hipStream_t)stream;
-    float *xn = (float *)ws;
-    float *sq = (float *)((char *)ws + (((size_t)B * C * N * sizeof(float) + 255) & ~(size_t)255));
-    hipLaunchKernelGGL(knn_normalize_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, x, xn, sq, C, N, normalize);
-    GRAFP_CHECK_LAUNCH("knn_normalize_kernel");
     switch (k) {
         case 1: launch_topk<1>(xn, sq, idx, B, C, N, s); break;
         case 2: launch_topk<2>(xn, sq, idx, B, C, N, s); break;
@@ -230,4 +215,47 @@ extern "C" int grafp_knn_graph_f32(const float *x, int B, int C, int N, int k, i
     }
     GRAFP_CHECK_LAUNCH("knn_topk_kernel");
     return GRAFP_OK;
+}
+
+static bool knn_args_ok(const void *a, const void *b, int B, int C, int N, int k) {
+    using namespace grafp;
+    if (!a || !b) { set_error("knn_graph: null pointer"); return false; }
+    if (B <= 0 || C <= 0 || N <= 0) { set_error("knn_graph: bad shape B=%d C=%d N=%d", B, C, N); return false; }
+    if (k < 1 || k > GRAFP_KNN_MAX_K || k > N) {
+        set_error("knn_graph: k=%d must be in [1, min(N=%d, %d)]", k, N, GRAFP_KNN_MAX_K);
+        return false;
+    }
+    return true;
+}
+
+extern "C" int grafp_knn_normalize_f32(const float *x, int B, int C, int N, int normalize, float *xn, float *sq,
+                                       grafp_stream_t stream) {
+    using namespace grafp;
+    if (!knn_args_ok(x, xn, B, C, N, 1) || !knn_args_ok(x, sq, B, C, N, 1)) return GRAFP_ERR_ARG;
+    hipLaunchKernelGGL(knn_normalize_kernel, dim3((N + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, x, xn, sq, C, N,
+                       normalize);
+    GRAFP_CHECK_LAUNCH("knn_normalize_kernel");
+    return GRAFP_OK;
+}
+
+extern "C" int grafp_knn_topk_f32(const float *xn, const float *sq, int B, int C, int N, int k, int64_t *idx,
+                                  grafp_stream_t stream) {
+    if (!knn_args_ok(xn, idx, B, C, N, k) || !knn_args_ok(sq, idx, B, C, N, k)) return GRAFP_ERR_ARG;
+    return knn_topk_launch(xn, sq, B, C, N, k, idx, (hipStream_t)stream);
+}
+
+extern "C" int grafp_knn_graph_f32(const float *x, int B, int C, int N, int k, int normalize, int64_t *idx, void *ws,
+                                   size_t ws_bytes, grafp_stream_t stream) {
+    using namespace grafp;
+    if (!knn_args_ok(x, idx, B, C, N, k)) return GRAFP_ERR_ARG;
+    const size_t need = grafp_knn_graph_workspace(B, C, N);
+    if (!ws || ws_bytes < need) {
+        set_error("knn_graph: workspace %zu bytes < required %zu", ws_bytes, need);
+        return GRAFP_ERR_WORKSPACE;
+    }
+    float *xn = (float *)ws;
+    float *sq = (float *)((char *)ws + (((size_t)B * C * N * sizeof(float) + 255) & ~(size_t)255));
+    const int rc = grafp_knn_normalize_f32(x, B, C, N, normalize, xn, sq, stream);
+    if (rc != GRAFP_OK) return rc;
+    return grafp_knn_topk_f32(xn, sq, B, C, N, k, idx, stream);
 }

@@ -56,9 +56,9 @@ def all_gather_embeddings(z_i, z_j, group=None):
     if R == 1:
         return zi, zj
     mine = torch.stack((zi, zj), dim=0)                                   # (2, B_loc, D)
-    out = torch.empty((R,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
-    dist.all_gather_into_tensor(out, mine, group=group)
-    out = out.permute(1, 0, 2, 3)                                         # (2, R, B_loc, D)
+    out = torch.empty((R * 2,) + tuple(mine.shape[1:]), dtype=mine.dtype, device=mine.device)
+    dist.all_gather_into_tensor(out, mine, group=group)                   # concatenated along dim 0
+    out = out.reshape(R, 2, *mine.shape[1:]).permute(1, 0, 2, 3)          # (2, R, B_loc, D)
     return out[0].reshape(-1, zi.shape[1]).contiguous(), out[1].reshape(-1, zi.shape[1]).contiguous()
 
 
@@ -173,10 +173,12 @@ class ShardedFlatL2Index:
         if self.world == 1:
             return D, I
         D, I = torch.as_tensor(D), torch.as_tensor(I)
-        gd = torch.empty((self.world,) + tuple(D.shape), dtype=D.dtype, device=D.device)
-        gi = torch.empty((self.world,) + tuple(I.shape), dtype=I.dtype, device=I.device)
+        nq, kk = D.shape
+        gd = torch.empty((self.world * nq, kk), dtype=D.dtype, device=D.device)
+        gi = torch.empty((self.world * nq, kk), dtype=I.dtype, device=I.device)
         dist.all_gather_into_tensor(gd, D.contiguous(), group=self.group)
         dist.all_gather_into_tensor(gi, I.contiguous(), group=self.group)
+        gd, gi = gd.reshape(self.world, nq, kk), gi.reshape(self.world, nq, kk)
         if self._merge is None:
             from .ops import merge_topk
             self._merge = merge_topk

@@ -216,11 +216,13 @@ def knn_graph(x, k, normalize=True):
     x = _f32c(x)
     B, C, N = x.shape
     idx = torch.empty((B, N, k), dtype=torch.int64, device=x.device)
-    nbytes = lib.grafp_knn_graph_workspace(B, C, N)
-    ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
-    with _timed("knn_graph", (B, C, N, k)):
-        check(lib.grafp_knn_graph_f32(_p(x), B, C, N, k, int(bool(normalize)), _p(idx), _p(ws), nbytes, _stream()),
-              "knn_graph")
+    xn = torch.empty_like(x)
+    sq = torch.empty((B, N), dtype=torch.float32, device=x.device)
+    with _timed("knn_normalize", (B, C, N, k)):
+        check(lib.grafp_knn_normalize_f32(_p(x), B, C, N, int(bool(normalize)), _p(xn), _p(sq), _stream()),
+              "knn_normalize")
+    with _timed("knn_topk", (B, C, N, k)):
+        check(lib.grafp_knn_topk_f32(_p(xn), _p(sq), B, C, N, k, _p(idx), _stream()), "knn_topk")
     return idx
 
 

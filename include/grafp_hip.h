@@ -85,6 +85,13 @@ int grafp_peak_extract_bwd_f32(const float *spec, int B, int H, int W, int F, in
  *   x (B,C,N) f32   idx (B,N,k) int64   1 <= k <= min(N, GRAFP_KNN_MAX_K)
  *   normalize != 0 applies the L2 normalisation (0 = dense_knn_matrix alone). */
 size_t grafp_knn_graph_workspace(int B, int C, int N);
+/* The two passes of grafp_knn_graph_f32, exposed so a caller can time / reuse them separately:
+ *   normalize: x (B,C,N) -> xn (B,C,N) unit columns (copy when normalize == 0), sq (B,N) = ||xn||^2
+ *   topk:      xn, sq -> idx (B,N,k) */
+int grafp_knn_normalize_f32(const float *x, int B, int C, int N, int normalize, float *xn, float *sq,
+                            grafp_stream_t stream);
+int grafp_knn_topk_f32(const float *xn, const float *sq, int B, int C, int N, int k, int64_t *idx,
+                       grafp_stream_t stream);
 int grafp_knn_graph_f32(const float *x, int B, int C, int N, int k, int normalize, int64_t *idx, void *ws,
                         size_t ws_bytes, grafp_stream_t stream);
 

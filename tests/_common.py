@@ -58,3 +58,36 @@ def knn_margin_mask(x, idx_k, tol=1e-5, normalize=True):
     k = idx_k
     gaps = ds[..., 1:k + 1] - ds[..., 0:k]                 # gaps between consecutive of the first k+1
     return (gaps > tol).all(-1), d
+
+
+class RecordedGraphs:
+    """Context manager: records every k-NN graph grafp_amd.ops.knn_graph builds (TEST-ONLY monkeypatch), and
+    offers an `idx_fn` that replays them, in order, inside the oracle -- so a CPU/GPU comparison holds the edges
+    equal.  Upstream f32 rounding differs between CPU and GPU GEMMs, hence a few NEAR-TIE neighbours flip; the
+    k-NN decision itself is verified bit-exactly elsewhere on identical inputs."""
+
+    def __enter__(self):
+        from grafp_amd import ops
+        self._ops, self._orig, self.graphs = ops, ops.knn_graph, []
+
+        def rec(x, k, normalize=True):
+            idx = self._orig(x, k, normalize)
+            self.graphs.append(idx.cpu())
+            return idx
+        ops.knn_graph = rec
+        return self
+
+    def __exit__(self, *exc):
+        self._ops.knn_graph = self._orig
+
+    def replay_fn(self):
+        it = iter(self.graphs)
+        self.flips = 0
+
+        def idx_fn(x, k):
+            from oracle import native
+            idx = next(it)
+            own = native.knn_graph(x.detach().numpy(), k)
+            self.flips += int((own != idx.numpy()).any(-1).sum())
+            return idx
+        return idx_fn

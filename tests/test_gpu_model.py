@@ -1,0 +1,264 @@
+"""GPU tests of the assembled path: module mirror + HIP ops against the reference's golden outputs and the
+oracle; retrieval evaluation end to end; database writers; bf16 mode.  `pytest -m gpu`."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from _common import RecordedGraphs, filled_state_dict, golden, hash_normalish, simclr_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _filled_model(dev, B=4):
+    from grafp_amd.train import build_model
+    from grafp_amd.util import load_config
+    cfg = load_config()
+    cfg["bsz_train"] = B
+    model = build_model(cfg)
+    sd = model.state_dict()
+    sd.update(filled_state_dict())
+    model.load_state_dict(sd)
+    return cfg, model.to(dev)
+
+
+def _rel_l2(got, want):
+    got = got.detach().cpu().numpy() if torch.is_tensor(got) else got
+    want = want.detach().cpu().numpy() if torch.is_tensor(want) else want
+    return (np.linalg.norm(got - want, axis=-1) / np.linalg.norm(want, axis=-1)).max()
+
+
+def test_simclr_forward_vs_oracle_with_equal_edges(dev):
+    """f32 parity bar: with the k-NN edges held equal (replayed in the oracle), every embedding agrees to
+    1e-4 relative L2 (BASELINE bar: 1e-3), train and eval mode."""
+    from oracle import model as om
+    cfg, model = _filled_model(dev)
+    xi, xj = simclr_inputs()
+    for train in (True, False):
+        model.train(train)
+        sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+        with RecordedGraphs() as rg, torch.no_grad():
+            h_i, h_j, z_i, z_j = model(xi.to(dev), xj.to(dev))
+        assert len(rg.graphs) == 24
+        with torch.no_grad():
+            o = om.simclr_forward(sd, xi, xj, train, idx_fn=rg.replay_fn())
+        for got, want in zip((h_i, h_j, z_i, z_j), o):
+            assert _rel_l2(got, want) <= 1e-4
+        assert rg.flips <= 200                      # near-ties only: <= 0.2% of the ~98k node decisions
+        if train:
+            np.testing.assert_allclose(model.encoder.stem[1].running_mean.cpu().numpy(),
+                                       sd["encoder.stem.1.running_mean"].numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_simclr_forward_matches_reference_golden(dev):
+    """The reference's own SimCLR.forward output (tests/golden/simclr_forward.npz, produced on CPU).  A
+    near-tie neighbour flipping between CPU and GPU moves an embedding by ~1e-3, so the bar against the golden
+    is 5e-3 relative L2 per vector (observed: 1e-6 without a flip, 0.7-1.4e-3 with one); the tight bar is the
+    equal-edges test above."""
+    g = golden("simclr_forward.npz")
+    cfg, model = _filled_model(dev)
+    xi, xj = simclr_inputs()
+    model.train()
+    with torch.no_grad():
+        h_i, h_j, z_i, z_j = model(xi.to(dev), xj.to(dev))
+    for got, want in ((z_i, g["z_i"]), (z_j, g["z_j"]), (h_i, g["h_i"]), (h_j, g["h_j"])):
+        assert _rel_l2(got, want) <= 5e-3
+    np.testing.assert_allclose(model.encoder.stem[1].running_mean.cpu().numpy(), g["stem_running_mean"], rtol=1e-5, atol=1e-6)
+    model.eval()
+    with torch.no_grad():
+        eh_i, _, ez_i, ez_j = model(xi.to(dev), xj.to(dev))
+    for got, want in ((ez_i, g["eval_z_i"]), (ez_j, g["eval_z_j"]), (eh_i, g["eval_h_i"])):
+        assert _rel_l2(got, want) <= 5e-3
+
+
+def test_train_step_vs_oracle_with_equal_edges(dev):
+    """One full step (fwd + NT-Xent + bwd) against the oracle's autograd with edges held equal: loss 1e-5,
+    every parameter gradient within 3e-2 relative L2 (median 8e-3)."""
+    from grafp_amd.simclr.ntxent import ntxent_loss
+    from oracle import model as om
+    cfg, model = _filled_model(dev)
+    model.train()
+    xi, xj = simclr_inputs()
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    for k, v in sd.items():
+        if v.is_floating_point() and k.rsplit(".", 1)[-1] not in ("running_mean", "running_var", "relative_pos"):
+            v.requires_grad_(True)
+    with RecordedGraphs() as rg:
+        _, _, z_i, z_j = model(xi.to(dev), xj.to(dev))
+    loss = ntxent_loss(z_i, z_j, cfg)
+    loss.backward()
+    _, _, oz_i, oz_j = om.simclr_forward(sd, xi, xj, True, idx_fn=rg.replay_fn())
+    oloss = om.ntxent(oz_i, oz_j, cfg["tau"])
+    oloss.backward()
+    np.testing.assert_allclose(loss.item(), oloss.item(), rtol=1e-4)
+    # Metric: relative L2 error per gradient tensor.  (Max-abs is the wrong yardstick: a pre-activation within
+    # rounding of zero flips a ReLU / arg-max mask -- about one per layer among ~1e6 activations, also between two
+    # CPU formulations of the same network -- and moves single entries by a few % while leaving norms intact.)
+    # Conv biases feeding a train-mode BatchNorm have a mathematically ZERO gradient (pure rounding noise on both
+    # sides): tensors whose norm is < 1e-4 of the largest are compared on that absolute scale.
+    gnorm = max(float(sd[n].grad.norm()) for n, p in model.named_parameters() if p.requires_grad)
+    rows = []
+    for name, p in model.named_parameters():
+        if p.requires_grad:
+            want = sd[name].grad
+            rows.append((float((p.grad.cpu() - want).norm()) / max(float(want.norm()), 1e-4 * gnorm), name))
+    rows.sort(reverse=True)
+    assert rows[0][0] <= 3e-2, rows[:5]          # earliest layers accumulate every downstream mask flip
+    assert np.median([r[0] for r in rows]) <= 8e-3
+
+
+def test_train_step_matches_reference_golden(dev):
+    """The reference's own train step (golden produced on CPU): loss, gradient norms and post-Adam parameter
+    sums; element-wise gradients to 5% of their max-norm (near-tie flips re-route a few gradient paths)."""
+    from grafp_amd.simclr.ntxent import ntxent_loss
+    g = golden("train_step.npz")
+    cfg, model = _filled_model(dev)
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=8e-5)
+    xi, xj = simclr_inputs()
+    opt.zero_grad()
+    _, _, z_i, z_j = model(xi.to(dev), xj.to(dev))
+    loss = ntxent_loss(z_i, z_j, cfg)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), g["loss"], rtol=1e-3)
+    probe = [str(p) for p in g["probe"]]
+    params = dict(model.named_parameters())
+    gn = np.array([params[k].grad.double().norm().item() for k in probe])
+    np.testing.assert_allclose(gn, g["grad_norm"], rtol=2e-2)
+    for k in probe[:2]:
+        want = g["grad:" + k]
+        assert np.abs(params[k].grad.cpu().numpy() - want).max() <= 0.05 * np.abs(want).max()
+    opt.step()
+    # Adam's first step moves every weight by ~lr * sign(grad): entries whose gradient is ~0 can take the other
+    # sign after a near-tie flip, so the sums agree to a few 1e-3 absolute rather than to rounding
+    ps = np.array([params[k].detach().double().sum().item() for k in probe])
+    np.testing.assert_allclose(ps, g["param_sum_after"], rtol=1e-4, atol=2e-2)
+
+
+def test_block_golden(dev):
+    """One Grapher+FFN block (C=16, N=64) against the reference, train and eval."""
+    from torch import nn
+    from grafp_amd.encoder.gcn_lib.torch_vertex import Grapher
+    from grafp_amd.encoder.graph_encoder import FFN
+    g = golden("block.npz")
+    C, N = 16, 64
+    blk = nn.Sequential(Grapher(C, 3, 1, "mr", "relu", "batch", True, False, 0.2, 1, n=N, drop_path=0.0, relative_pos=True),
+                        FFN(C, 4 * C, C, act="relu"))
+    assert sorted(blk.state_dict().keys()) == [str(k) for k in g["keys"]]
+    shapes = {k: tuple(v.shape) for k, v in blk.state_dict().items()}
+    sd = blk.state_dict(); sd.update(filled_state_dict(shapes, "blk")); blk.load_state_dict(sd)
+    blk = blk.to(dev)
+    x = torch.from_numpy(hash_normalish("in:blk.x", (3, C, N, 1))).to(dev)
+    blk.train()
+    with torch.no_grad():
+        y = blk(x)
+    assert y.shape == (3, C, N, 1)
+    np.testing.assert_allclose(y.cpu().numpy(), g["y_train"], rtol=2e-5, atol=2e-5)
+    blk.eval()
+    with torch.no_grad():
+        y = blk(x)
+    np.testing.assert_allclose(y.cpu().numpy(), g["y_eval"], rtol=2e-5, atol=2e-5)
+
+
+def test_bf16_autocast_mode(dev):
+    """Throughput mode: bf16 GEMMs (autocast), f32 graph build / gather / loss.  The 1e-3 embedding bar is an
+    f32 property: under bf16 ~13% of the nodes change a neighbour in block 1 and nearly all by block 12, and a
+    random-init network amplifies the rounding itself (measured, scratch analysis in DESIGN.md).  Checked here:
+    the mode runs end to end, stays finite, and with the f32 graphs replayed stays directionally close."""
+    cfg, model = _filled_model(dev)
+    xi, xj = simclr_inputs()
+    model.train()
+    with RecordedGraphs() as rg, torch.no_grad():
+        _, _, z32, _ = model(xi.to(dev), xj.to(dev))
+    from grafp_amd import ops
+    it, orig = iter(rg.graphs), ops.knn_graph
+    ops.knn_graph = lambda x, k, normalize=True: next(it).to(x.device)
+    try:
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            _, _, z16r, _ = model(xi.to(dev), xj.to(dev))
+    finally:
+        ops.knn_graph = orig
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        _, _, z16, _ = model(xi.to(dev), xj.to(dev))
+    cos_r = torch.nn.functional.cosine_similarity(z32.float(), z16r.float(), dim=1)
+    cos = torch.nn.functional.cosine_similarity(z32.float(), z16.float(), dim=1)
+    print("bf16 vs f32 cosine: own graphs", cos.cpu().numpy(), "f32 graphs replayed", cos_r.cpu().numpy())
+    assert torch.isfinite(z16).all() and float(cos_r.min()) > 0.95
+    np.testing.assert_allclose(z16.float().norm(dim=1).cpu().numpy(), 1.0, rtol=1e-2)
+
+
+def test_trainer_reduces_loss(dev):
+    from grafp_amd.train import Trainer, build_model, synthetic_batch
+    from grafp_amd.util import load_config
+    cfg = load_config(); cfg["bsz_train"] = 16
+    torch.manual_seed(0)
+    model = build_model(cfg, device=dev)
+    tr = Trainer(cfg, model, dev, lr=1e-3)
+    x_i, x_j = synthetic_batch(16, 5, dev)
+    losses = [float(tr.step(x_i, x_j)) for _ in range(6)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    ck = tr.checkpoint(1, losses, [])
+    assert set(ck) == {"epoch", "loss", "valid_acc", "hit_rate", "state_dict", "optimizer", "scheduler"}
+    assert len(ck["state_dict"]) == 443
+
+
+def test_eval_faiss_end_to_end_vs_oracle(dev, tmp_path):
+    """query/db/dummy_db memmaps -> eval_faiss (GPU search, batched) == the oracle's restatement of
+    eval.py (per-item search + rerank): identical hit-rate table and raw flags."""
+    from grafp_amd.eval import eval_faiss
+    from grafp_amd.fpdb import _write_memmap
+    from oracle import retrieval
+    dummy = hash_normalish("ev:dummy", (3000, 128)); dummy /= np.linalg.norm(dummy, axis=1, keepdims=True)
+    db = hash_normalish("ev:db", (400, 128)); db /= np.linalg.norm(db, axis=1, keepdims=True)
+    query = db + 0.12 * hash_normalish("ev:noise", (400, 128)); query /= np.linalg.norm(query, axis=1, keepdims=True)
+    for name, arr in (("dummy_db", dummy), ("db", db), ("query", query)):
+        _write_memmap(str(tmp_path / name), arr.astype(np.float32))
+    test_ids = np.arange(0, 350, 7)
+    np.save(tmp_path / "ids.npy", test_ids)
+    rates = eval_faiss(str(tmp_path), test_ids=str(tmp_path / "ids.npy"), test_seq_len="1 3 5 11", index_type="l2",
+                       nogpu=True)
+    want, raw, _ = retrieval.eval_l2(query.astype(np.float32), db.astype(np.float32), dummy.astype(np.float32),
+                                     test_ids, [1, 3, 5, 11])
+    assert rates.shape == (4, 4)
+    np.testing.assert_array_equal(rates, want)
+    res_dirs = [d for d in os.listdir(tmp_path) if os.path.isdir(tmp_path / d)]
+    assert len(res_dirs) == 1
+    np.testing.assert_array_equal(np.load(tmp_path / res_dirs[0] / "raw_score.npy"), raw)
+    assert np.array_equal(np.load(tmp_path / "test_ids.npy"), test_ids)
+    # 'all' and numeric id selections run too
+    r2 = eval_faiss(str(tmp_path), test_ids="20", test_seq_len=[1, 5], index_type="ivfpq")
+    assert r2.shape == (4, 2) and (r2[3] >= r2[0]).all()
+
+
+def test_db_writers(dev, tmp_path):
+    """create_dummy_db / create_fp_db / create_db: on-disk format and contents == direct model output."""
+    from grafp_amd.fpdb import create_db, create_dummy_db, create_fp_db
+    from grafp_amd.eval import load_memmap_data
+    from grafp_amd.modules.transformations import GPUTransformNeuralfp
+    cfg, model = _filled_model(dev)
+    model.eval()
+    aug = GPUTransformNeuralfp(cfg, None, None, train=False)
+    tracks = [torch.from_numpy(0.1 * hash_normalish(f"dbw:{i}", (1, 16000 * 3 + 500 * i))) for i in range(3)]
+    create_dummy_db(tracks, augment=aug, model=model, output_root_dir=str(tmp_path), verbose=False)
+    create_fp_db(tracks, augment=aug, model=model, output_root_dir=str(tmp_path), verbose=False)
+    create_db(tracks, model, aug, str(tmp_path))
+    dd, shape = load_memmap_data(str(tmp_path), "dummy_db", display=False)
+    n_seg = sum((1 + t.shape[1] // 512 - 32) // 3 + 1 for t in tracks)
+    assert tuple(shape) == (n_seg, 128)
+    q, _ = load_memmap_data(str(tmp_path), "query", display=False)
+    d, _ = load_memmap_data(str(tmp_path), "db", display=False)
+    fp = np.load(tmp_path / "fingerprints.npy")
+    with torch.no_grad():
+        want = torch.cat([model.embed(aug(t.to(dev), None)[0])[1] for t in tracks]).cpu().numpy()
+    np.testing.assert_allclose(np.asarray(dd), want, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(fp, want, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(np.asarray(d), want, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(np.asarray(q), want, rtol=1e-5, atol=1e-6)     # identity augmentation
+    np.testing.assert_allclose(np.linalg.norm(want, axis=1), 1.0, rtol=1e-5)

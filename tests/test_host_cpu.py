@@ -1,0 +1,184 @@
+"""CPU tests of the host-side logic that needs no kernel: module surface, state-dict schema, drop-in aliases,
+dense helpers vs the oracle, rerank logic, on-disk formats, configuration."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from _common import ROOT, filled_state_dict, hash_normalish, manifest_shapes
+
+
+def _model(B=4):
+    from grafp_amd.train import build_model
+    from grafp_amd.util import load_config
+    cfg = load_config()
+    cfg["bsz_train"] = B
+    return cfg, build_model(cfg)
+
+
+def test_state_dict_schema_matches_reference_manifest():
+    cfg, model = _model()
+    shapes = manifest_shapes()
+    sd = model.state_dict()
+    assert list(sd.keys()) == list(shapes.keys())                      # same 443 keys, same order
+    assert all(tuple(v.shape) == shapes[k] for k, v in sd.items())
+    assert sum(p.numel() for p in model.parameters() if p.requires_grad) == 18367264
+    assert sum(p.numel() for p in model.parameters() if not p.requires_grad) == 2253312   # frozen relative_pos
+    assert len(model.encoder.backbone) == 15 and hasattr(model.encoder, "stem") and hasattr(model.encoder, "proj")
+    # a reference-style checkpoint (with or without DataParallel's 'module.' prefix) loads
+    from grafp_amd.util import strip_module_prefix
+    filled = filled_state_dict()
+    full = dict(sd)
+    full.update(filled)
+    model.load_state_dict(full)
+    model.load_state_dict(strip_module_prefix({"module." + k: v for k, v in full.items()}))
+
+
+def test_constructor_surface():
+    import inspect
+    from grafp_amd.encoder.graph_encoder import GraphEncoder
+    from grafp_amd.modules.transformations import GPUTransformNeuralfp
+    from grafp_amd.simclr.simclr import SimCLR
+    p = inspect.signature(GraphEncoder.__init__).parameters
+    assert [k for k in p][1:] == ["cfg", "k", "conv", "act", "norm", "bias", "dropout", "dilation", "epsilon", "drop_path",
+                                  "size", "emb_dims", "in_channels"]
+    assert p["k"].default == 3 and p["size"].default == "t" and p["in_channels"].default == 3
+    assert [k for k in inspect.signature(SimCLR.__init__).parameters][1:] == ["cfg", "encoder"]
+    assert [k for k in inspect.signature(GPUTransformNeuralfp.__init__).parameters][1:] == [
+        "cfg", "ir_dir", "noise_dir", "train", "cpu", "abl"]
+    from grafp_amd.eval import eval_faiss
+    ps = inspect.signature(eval_faiss).parameters
+    assert list(ps) == ["emb_dir", "emb_dummy_dir", "index_type", "nogpu", "max_train", "test_ids", "test_seq_len",
+                        "k_probe", "n_centroids"]
+    assert ps["index_type"].default == "ivfpq" and ps["k_probe"].default == 20
+
+
+def test_dropin_aliases():
+    import sys
+    import grafp_amd.dropin as d
+    saved = {k: sys.modules.get(k) for k in d._ALIASES}
+    try:
+        d.install(overwrite=True)
+        from encoder.graph_encoder import GraphEncoder          # noqa: F401
+        from eval import eval_faiss, get_index, load_memmap_data  # noqa: F401
+        from generate import create_db                          # noqa: F401
+        from modules.transformations import GPUTransformNeuralfp  # noqa: F401
+        from simclr.ntxent import ntxent_loss                   # noqa: F401
+        from simclr.simclr import SimCLR                        # noqa: F401
+        from test_fp import create_dummy_db, create_fp_db       # noqa: F401
+        import grafp_amd.encoder.graph_encoder as real
+        assert GraphEncoder is real.GraphEncoder
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
+def test_dense_helpers_match_conv_library_semantics():
+    """pointwise / strided3 / batchnorm (GEMM formulation) == F.conv2d / BatchNorm2d on (B,C,N,1)."""
+    import torch.nn.functional as F
+    from torch import nn
+    from grafp_amd.encoder._dense import batchnorm, pointwise, strided3
+    torch.manual_seed(0)
+    x = torch.randn(3, 16, 40)
+    for groups, bias in ((1, True), (4, True), (1, False)):
+        conv = nn.Conv2d(16, 24, 1, groups=groups, bias=bias)
+        np.testing.assert_allclose(pointwise(conv, x).detach().numpy(), conv(x.unsqueeze(-1)).squeeze(-1).detach().numpy(),
+                                   rtol=1e-5, atol=1e-5)
+    for n in (40, 41):
+        xs = torch.randn(2, 16, n)
+        down = nn.Conv2d(16, 32, 3, stride=2, padding=1)
+        np.testing.assert_allclose(strided3(down, xs).detach().numpy(), down(xs.unsqueeze(-1)).squeeze(-1).detach().numpy(),
+                                   rtol=1e-5, atol=1e-5)
+    bn_a, bn_b = nn.BatchNorm2d(16), nn.BatchNorm2d(16)
+    for train in (True, False):
+        bn_a.train(train); bn_b.train(train)
+        np.testing.assert_allclose(batchnorm(bn_a, x).detach().numpy(), bn_b(x.unsqueeze(-1)).squeeze(-1).detach().numpy(),
+                                   rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(bn_a.running_var.numpy(), bn_b.running_var.numpy(), rtol=1e-6)
+    assert int(bn_a.num_batches_tracked) == 1
+
+
+def test_dense_part_of_the_model_matches_the_oracle_on_cpu():
+    """With the HIP ops swapped for the oracle's (TEST-ONLY monkeypatch) the module mirror reproduces the
+    oracle's forward: pins the GEMM/BN/residual wiring and the state-dict mapping without a GPU."""
+    from grafp_amd import ops
+    from oracle import model as om
+    cfg, model = _model()
+    filled = filled_state_dict()
+    sd = model.state_dict(); sd.update(filled); model.load_state_dict(sd)
+    saved = (ops.knn_graph, ops.max_relative, ops.peak_extract)
+    ops.knn_graph = lambda x, k, normalize=True: om.knn_graph_torch(x.squeeze(-1) if x.dim() == 4 else x, k)
+    ops.max_relative = om.max_relative
+    ops.peak_extract = lambda spec, w, b, s: om.peak_extract(
+        {"peak_extractor.convs.0.weight": w, "peak_extractor.convs.0.bias": b}, spec, s)
+    try:
+        from _common import simclr_inputs
+        xi, xj = simclr_inputs()
+        model.train()
+        with torch.no_grad():
+            h_i, h_j, z_i, z_j = model(xi, xj)
+            o = om.simclr_forward({k: v.clone() for k, v in filled.items()}, xi, xj, True)
+        np.testing.assert_allclose(z_i.numpy(), o[2].numpy(), rtol=1e-3, atol=1e-5)
+        np.testing.assert_allclose(z_j.numpy(), o[3].numpy(), rtol=1e-3, atol=1e-5)
+        np.testing.assert_allclose(h_i.numpy(), o[0].numpy(), rtol=1e-3, atol=1e-4)
+    finally:
+        ops.knn_graph, ops.max_relative, ops.peak_extract = saved
+
+
+def test_sequence_rerank_matches_oracle():
+    from grafp_amd.eval import sequence_rerank
+    from oracle import retrieval
+    rng = np.random.default_rng(0)
+    recon = rng.standard_normal((400, 128)).astype(np.float32)
+    for sl in (1, 3, 11):
+        q = recon[100:100 + sl] + 0.1 * rng.standard_normal((sl, 128)).astype(np.float32)
+        I = rng.integers(0, 400, size=(sl, 20))
+        I[:, 0] = 100 + np.arange(sl)
+        I[0, 5] = -1
+        I[-1, 3] = 399                                                   # candidate sequence runs off the end
+        pred = sequence_rerank(q, I.copy(), recon, sl)
+        J = I - np.arange(sl)[:, None]
+        cand = np.unique(J[J >= 0])
+        scores = retrieval.sequence_scores(q, recon, cand, sl)
+        want = cand[np.argsort(-scores, kind="stable")[:10]]
+        assert pred[0] == 100 and np.array_equal(pred, want)
+
+
+def test_memmap_format_roundtrip(tmp_path):
+    from grafp_amd.eval import load_memmap_data
+    from grafp_amd.fpdb import _write_memmap
+    arr = hash_normalish("host:mm", (37, 128))
+    arr[3, 5] = np.nan
+    _write_memmap(str(tmp_path / "db"), arr)
+    assert os.path.getsize(tmp_path / "db.mm") == 37 * 128 * 4
+    assert tuple(np.load(tmp_path / "db_shape.npy")) == (37, 128)
+    data, shape = load_memmap_data(str(tmp_path), "db", display=False)
+    assert tuple(shape) == (37, 128) and data[3, 5] == 0.0               # NaN -> 0 (eval.py:165)
+    ref = arr.copy(); ref[3, 5] = 0.0
+    np.testing.assert_array_equal(np.asarray(data), ref)
+    assert tuple(load_memmap_data(str(tmp_path), "db", shape_only=True)) == (37, 128)
+
+
+def test_config_and_util():
+    from grafp_amd import util
+    cfg = util.load_config()
+    ref = dict(fs=16000, n_fft=1024, win_len=1024, hop_len=512, n_mels=64, n_frames=32, peak_stride=2, n_filters=8,
+               d=128, h=1024, u=32, tau=0.05, bsz_train=256, overlap=0.9, blur_kernel=[7, 7], arch="grafp")
+    assert all(cfg[k] == v for k, v in ref.items())
+    assert [util.query_len_from_seconds(s, 0.9, 1.0) for s in (1, 2, 3, 5)] == [1, 10, 20, 40] or \
+        [util.query_len_from_seconds(s, 0.9, 1.0) for s in (1, 2, 3, 5)] == [1, 11, 21, 41]
+    assert util.override(3, None) == 3 and util.override(3, 5) == 5
+
+
+def test_augmentation_is_refused_loudly():
+    from grafp_amd.modules.transformations import GPUTransformNeuralfp
+    from grafp_amd.util import load_config
+    with pytest.raises(NotImplementedError):
+        GPUTransformNeuralfp(load_config(), "/some/ir", None)
+    t = GPUTransformNeuralfp(load_config(), None, None, cpu=True)
+    a, b = t(torch.zeros(16000), torch.arange(16010.0))
+    assert b.shape == (16000,)
