@@ -1,0 +1,396 @@
+// bn.hip -- fused [conv bias] + BatchNorm + activation + residual on the (C, M = B*N) activation layout, gfx950.
+//
+// Replaces, around every 1x1 convolution of the GraFPrint encoder, the chain the reference runs as separate
+// library/elementwise launches: `+ bias` (Conv2d bias), BatchNorm2d (batch statistics in train mode,
+// /root/reference/encoder/gcn_lib/torch_vertex.py:152-162, torch_nn.py:56-60, encoder/graph_encoder.py:52-55,131-133),
+// ReLU / LeakyReLU(0.2), and the residual add (`torch_vertex.py:193`, `graph_encoder.py:65`).
+// With channels as ROWS of a (C, M) matrix a channel's statistics are a reduction over one contiguous row:
+//   forward  = stats pass (1 read) + apply pass (1 read [+1 residual read] + 1 write)
+//   backward = reduce pass (2 reads) + dx pass (2 reads + 1 write); the activation mask is recomputed, not stored.
+// HBM-bound: 12 (f32) / 6 (bf16) bytes per element forward.  Statistics use shifted sums (shift = first element
+// of the row) in f32, which removes the E[x^2] - E[x]^2 cancellation for rows with |mean| >> std.
+// A conv bias in front of a train-mode BatchNorm cancels in the output; it only shifts the running mean, and its
+// gradient is exactly zero -- so it is folded in here instead of costing an elementwise launch + a reduction.
+#include <math.h>
+
+#include "common.h"
+
+namespace grafp {
+
+constexpr int BN_THREADS = 256;
+
+template <typename T> struct BnIO;
+template <> struct BnIO<float> {
+    static constexpr int W = 4;
+    __device__ static void load(const float *p, float (&v)[4]) {
+        const float4 t = *reinterpret_cast<const float4 *>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+    __device__ static void store(float *p, const float (&v)[4]) {
+        *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    __device__ static float ld1(const float *p) { return *p; }
+    __device__ static void st1(float *p, float v) { *p = v; }
+};
+__device__ __forceinline__ unsigned short f2bf(float v) {
+    unsigned u = __float_as_uint(v);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+template <> struct BnIO<unsigned short> {
+    static constexpr int W = 8;
+    __device__ static void load(const unsigned short *p, float (&v)[8]) {
+        const uint4 t = *reinterpret_cast<const uint4 *>(p);
+        const unsigned w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[2 * i] = __uint_as_float(w[i] << 16);
+            v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+        }
+    }
+    __device__ static void store(unsigned short *p, const float (&v)[8]) {
+        unsigned w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = (unsigned)f2bf(v[2 * i]) | ((unsigned)f2bf(v[2 * i + 1]) << 16);
+        *reinterpret_cast<uint4 *>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    __device__ static float ld1(const unsigned short *p) { return __uint_as_float(((unsigned)*p) << 16); }
+    __device__ static void st1(unsigned short *p, float v) { *p = f2bf(v); }
+};
+
+__device__ __forceinline__ float2 block_sum2(float a, float b, float2 *scratch, int tid) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        a += __shfl_xor(a, o);
+        b += __shfl_xor(b, o);
+    }
+    __syncthreads();
+    if ((tid & 63) == 0) scratch[tid >> 6] = make_float2(a, b);
+    __syncthreads();
+    float2 r = scratch[0];
+    for (int w = 1; w < BN_THREADS / 64; ++w) {
+        r.x += scratch[w].x;
+        r.y += scratch[w].y;
+    }
+    return r;
+}
+
+__device__ __forceinline__ float act_fwd(float u, int act, float slope) {
+    return act == 0 ? u : (u > 0.0f ? u : (act == 1 ? 0.0f : u * slope));
+}
+__device__ __forceinline__ float act_grad(float u, int act, float slope) {
+    return act == 0 ? 1.0f : (u > 0.0f ? 1.0f : (act == 1 ? 0.0f : slope));
+}
+
+// ---- forward pass 1: partial shifted sums --------------------------------------------------------
+template <typename T, bool VEC>
+__global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(const T *__restrict__ x, int64_t M, int64_t chunk, int S,
+                                                              const float *__restrict__ pre_bias,
+                                                              float *__restrict__ part) {
+    __shared__ float2 scratch[BN_THREADS / 64];
+    const int c = blockIdx.y, s = blockIdx.x, tid = threadIdx.x;
+    const T *row = x + (size_t)c * M;
+    const float pb = pre_bias ? pre_bias[c] : 0.0f;
+    const float shift = BnIO<T>::ld1(row) + pb;
+    const int64_t lo = (int64_t)s * chunk, hi = (lo + chunk < M) ? lo + chunk : M;
+    float a = 0.0f, q = 0.0f;
+    constexpr int W = VEC ? BnIO<T>::W : 1;
+    for (int64_t m = lo + (int64_t)tid * W; m < hi; m += (int64_t)BN_THREADS * W) {
+        if (VEC && m + W <= hi) {
+            float v[BnIO<T>::W];
+            BnIO<T>::load(row + m, v);
+#pragma unroll
+            for (int i = 0; i < BnIO<T>::W; ++i) {
+                const float d = (v[i] + pb) - shift;
+                a += d;
+                q = __builtin_fmaf(d, d, q);
+            }
+        } else {
+            for (int i = 0; i < W && m + i < hi; ++i) {
+                const float d = (BnIO<T>::ld1(row + m + i) + pb) - shift;
+                a += d;
+                q = __builtin_fmaf(d, d, q);
+            }
+        }
+    }
+    const float2 r = block_sum2(a, q, scratch, tid);
+    if (tid == 0) {
+        part[((size_t)c * S + s) * 2 + 0] = r.x;
+        part[((size_t)c * S + s) * 2 + 1] = r.y;
+    }
+}
+
+// ---- forward pass 2: finalise statistics (train) or take running ones (eval), then apply -----------
+template <typename T, bool VEC>
+__global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const T *__restrict__ x, int64_t M, int64_t chunk, int S,
+                                                              const float *__restrict__ pre_bias,
+                                                              const float *__restrict__ gamma,
+                                                              const float *__restrict__ beta,
+                                                              const T *__restrict__ residual, int act, float slope,
+                                                              float eps, float momentum, int training,
+                                                              float *__restrict__ running_mean,
+                                                              float *__restrict__ running_var,
+                                                              const float *__restrict__ part, T *__restrict__ out,
+                                                              float *__restrict__ save_mean,
+                                                              float *__restrict__ save_invstd) {
+    const int c = blockIdx.y, s = blockIdx.x, tid = threadIdx.x;
+    const T *row = x + (size_t)c * M;
+    const float pb = pre_bias ? pre_bias[c] : 0.0f;
+    float mean, invstd;
+    if (training) {
+        float a = 0.0f, q = 0.0f;
+        for (int i = 0; i < S; ++i) {               // same order in every block of the row: identical statistics
+            a += part[((size_t)c * S + i) * 2 + 0];
+            q += part[((size_t)c * S + i) * 2 + 1];
+        }
+        const float shift = BnIO<T>::ld1(row) + pb;
+        const float dm = a / (float)M;
+        const float var = fmaxf(q / (float)M - dm * dm, 0.0f);
+        mean = shift + dm;
+        invstd = 1.0f / sqrtf(var + eps);
+        if (s == 0 && tid == 0) {
+            save_mean[c] = mean;
+            save_invstd[c] = invstd;
+            if (running_mean) {
+                const float unbiased = M > 1 ? var * ((float)M / (float)(M - 1)) : var;
+                running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * mean;
+                running_var[c] = (1.0f - momentum) * running_var[c] + momentum * unbiased;
+            }
+        }
+    } else {
+        mean = running_mean[c];
+        invstd = 1.0f / sqrtf(running_var[c] + eps);
+        if (s == 0 && tid == 0) {
+            save_mean[c] = mean;
+            save_invstd[c] = invstd;
+        }
+    }
+    const float g = gamma[c] * invstd;
+    const float off = beta[c] + (pb - mean) * g;      // z = act(x*g + off) + r
+    const T *rrow = residual ? residual + (size_t)c * M : nullptr;
+    T *orow = out + (size_t)c * M;
+    const int64_t lo = (int64_t)s * chunk, hi = (lo + chunk < M) ? lo + chunk : M;
+    constexpr int W = VEC ? BnIO<T>::W : 1;
+    for (int64_t m = lo + (int64_t)tid * W; m < hi; m += (int64_t)BN_THREADS * W) {
+        if (VEC && m + W <= hi) {
+            float v[BnIO<T>::W], r[BnIO<T>::W];
+            BnIO<T>::load(row + m, v);
+            if (rrow) BnIO<T>::load(rrow + m, r);
+#pragma unroll
+            for (int i = 0; i < BnIO<T>::W; ++i) {
+                v[i] = act_fwd(__builtin_fmaf(v[i], g, off), act, slope);
+                if (rrow) v[i] += r[i];
+            }
+            BnIO<T>::store(orow + m, v);
+        } else {
+            for (int i = 0; i < W && m + i < hi; ++i) {
+                float z = act_fwd(__builtin_fmaf(BnIO<T>::ld1(row + m + i), g, off), act, slope);
+                if (rrow) z += BnIO<T>::ld1(rrow + m + i);
+                BnIO<T>::st1(orow + m + i, z);
+            }
+        }
+    }
+}
+
+// ---- backward pass 1: partial sums of dy and dy * xhat ----------------------------------------------
+template <typename T, bool VEC>
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(const T *__restrict__ x, const T *__restrict__ dz,
+                                                                   int64_t M, int64_t chunk, int S,
+                                                                   const float *__restrict__ pre_bias,
+                                                                   const float *__restrict__ gamma,
+                                                                   const float *__restrict__ beta,
+                                                                   const float *__restrict__ save_mean,
+                                                                   const float *__restrict__ save_invstd, int act,
+                                                                   float slope, float *__restrict__ part) {
+    __shared__ float2 scratch[BN_THREADS / 64];
+    const int c = blockIdx.y, s = blockIdx.x, tid = threadIdx.x;
+    const T *row = x + (size_t)c * M, *grow = dz + (size_t)c * M;
+    const float pb = pre_bias ? pre_bias[c] : 0.0f;
+    const float mean = save_mean[c], invstd = save_invstd[c], ga = gamma[c], be = beta[c];
+    const int64_t lo = (int64_t)s * chunk, hi = (lo + chunk < M) ? lo + chunk : M;
+    float sd = 0.0f, sdx = 0.0f;
+    constexpr int W = VEC ? BnIO<T>::W : 1;
+    for (int64_t m = lo + (int64_t)tid * W; m < hi; m += (int64_t)BN_THREADS * W) {
+        if (VEC && m + W <= hi) {
+            float v[BnIO<T>::W], d[BnIO<T>::W];
+            BnIO<T>::load(row + m, v);
+            BnIO<T>::load(grow + m, d);
+#pragma unroll
+            for (int i = 0; i < BnIO<T>::W; ++i) {
+                const float xh = ((v[i] + pb) - mean) * invstd;
+                const float dy = d[i] * act_grad(__builtin_fmaf(xh, ga, be), act, slope);
+                sd += dy;
+                sdx = __builtin_fmaf(dy, xh, sdx);
+            }
+        } else {
+            for (int i = 0; i < W && m + i < hi; ++i) {
+                const float xh = ((BnIO<T>::ld1(row + m + i) + pb) - mean) * invstd;
+                const float dy = BnIO<T>::ld1(grow + m + i) * act_grad(__builtin_fmaf(xh, ga, be), act, slope);
+                sd += dy;
+                sdx = __builtin_fmaf(dy, xh, sdx);
+            }
+        }
+    }
+    const float2 r = block_sum2(sd, sdx, scratch, tid);
+    if (tid == 0) {
+        part[((size_t)c * S + s) * 2 + 0] = r.x;
+        part[((size_t)c * S + s) * 2 + 1] = r.y;
+    }
+}
+
+// ---- backward pass 2: dgamma, dbeta, dx ---------------------------------------------------------------
+template <typename T, bool VEC>
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_dx_kernel(const T *__restrict__ x, const T *__restrict__ dz,
+                                                               int64_t M, int64_t chunk, int S,
+                                                               const float *__restrict__ pre_bias,
+                                                               const float *__restrict__ gamma,
+                                                               const float *__restrict__ beta,
+                                                               const float *__restrict__ save_mean,
+                                                               const float *__restrict__ save_invstd, int act,
+                                                               float slope, int training,
+                                                               const float *__restrict__ part, T *__restrict__ dx,
+                                                               float *__restrict__ dgamma, float *__restrict__ dbeta) {
+    const int c = blockIdx.y, s = blockIdx.x, tid = threadIdx.x;
+    const T *row = x + (size_t)c * M, *grow = dz + (size_t)c * M;
+    T *orow = dx + (size_t)c * M;
+    const float pb = pre_bias ? pre_bias[c] : 0.0f;
+    const float mean = save_mean[c], invstd = save_invstd[c], ga = gamma[c], be = beta[c];
+    float sd = 0.0f, sdx = 0.0f;
+    for (int i = 0; i < S; ++i) {
+        sd += part[((size_t)c * S + i) * 2 + 0];
+        sdx += part[((size_t)c * S + i) * 2 + 1];
+    }
+    if (s == 0 && tid == 0) {
+        dgamma[c] = sdx;
+        dbeta[c] = sd;
+    }
+    // train: dx = ga*invstd * (dy - mean(dy) - xhat * mean(dy*xhat)); eval: dx = ga*invstd*dy
+    const float k = ga * invstd;
+    const float m1 = training ? sd / (float)M : 0.0f, m2 = training ? sdx / (float)M : 0.0f;
+    const int64_t lo = (int64_t)s * chunk, hi = (lo + chunk < M) ? lo + chunk : M;
+    constexpr int W = VEC ? BnIO<T>::W : 1;
+    for (int64_t m = lo + (int64_t)tid * W; m < hi; m += (int64_t)BN_THREADS * W) {
+        if (VEC && m + W <= hi) {
+            float v[BnIO<T>::W], d[BnIO<T>::W];
+            BnIO<T>::load(row + m, v);
+            BnIO<T>::load(grow + m, d);
+#pragma unroll
+            for (int i = 0; i < BnIO<T>::W; ++i) {
+                const float xh = ((v[i] + pb) - mean) * invstd;
+                const float dy = d[i] * act_grad(__builtin_fmaf(xh, ga, be), act, slope);
+                v[i] = k * ((dy - m1) - xh * m2);
+            }
+            BnIO<T>::store(orow + m, v);
+        } else {
+            for (int i = 0; i < W && m + i < hi; ++i) {
+                const float xh = ((BnIO<T>::ld1(row + m + i) + pb) - mean) * invstd;
+                const float dy = BnIO<T>::ld1(grow + m + i) * act_grad(__builtin_fmaf(xh, ga, be), act, slope);
+                BnIO<T>::st1(orow + m + i, k * ((dy - m1) - xh * m2));
+            }
+        }
+    }
+}
+
+struct BnPlan {
+    int S;
+    int64_t chunk;
+};
+static BnPlan bn_plan(int C, int64_t M, int W) {
+    const int64_t per_block = (int64_t)BN_THREADS * W * 4;      // >= 4 vector iterations per thread
+    int64_t S = (M + per_block - 1) / per_block;
+    const int64_t cap = 4096 / C > 1 ? 4096 / C : 1;            // ~4096 workgroups in flight overall
+    if (S > cap) S = cap;
+    if (S < 1) S = 1;
+    int64_t chunk = (M + S - 1) / S;
+    chunk = (chunk + W - 1) / W * W;                             // chunk boundaries stay vector-aligned
+    BnPlan p;
+    p.chunk = chunk;
+    p.S = (int)((M + chunk - 1) / chunk);
+    return p;
+}
+
+template <typename T>
+static bool bn_vec_ok(const void *a, const void *b, const void *c, const void *d, int64_t M) {
+    const uintptr_t m = (uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d;
+    return (M % BnIO<T>::W) == 0 && (m & 15) == 0;
+}
+
+}  // namespace grafp
+
+extern "C" size_t grafp_bn_workspace(int C, int64_t M) {
+    if (C <= 0 || M <= 0) return 0;
+    return (size_t)C * (size_t)(4096 / C > 1 ? 4096 / C : 1) * 2 * sizeof(float);
+}
+
+extern "C" int grafp_bn_fwd(const void *x, int dtype, int C, int64_t M, const float *pre_bias, const float *gamma,
+                            const float *beta, const void *residual, int act, float slope, float eps, float momentum,
+                            int training, float *running_mean, float *running_var, void *out, float *save_mean,
+                            float *save_invstd, void *ws, size_t ws_bytes, grafp_stream_t stream) {
+    using namespace grafp;
+    GRAFP_REQUIRE(x && gamma && beta && out && save_mean && save_invstd, "bn_fwd: null pointer");
+    GRAFP_REQUIRE(C > 0 && M > 0 && C <= 65535, "bn_fwd: bad shape C=%d M=%lld", C, (long long)M);
+    GRAFP_REQUIRE(dtype == GRAFP_F32 || dtype == GRAFP_BF16, "bn_fwd: dtype %d not in {f32, bf16}", dtype);
+    GRAFP_REQUIRE(act >= 0 && act <= 2, "bn_fwd: act %d not in {0 none, 1 relu, 2 leaky}", act);
+    GRAFP_REQUIRE(training || (running_mean && running_var), "bn_fwd: eval mode needs running statistics");
+    if (!ws || ws_bytes < grafp_bn_workspace(C, M)) {
+        set_error("bn_fwd: workspace %zu bytes < required %zu", ws_bytes, grafp_bn_workspace(C, M));
+        return GRAFP_ERR_WORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    float *part = (float *)ws;
+#define BN_FWD(T, VEC)                                                                                                 \
+    do {                                                                                                               \
+        const BnPlan p = bn_plan(C, M, BnIO<T>::W);                                                                    \
+        const dim3 grid(p.S, C);                                                                                       \
+        if (training)                                                                                                  \
+            hipLaunchKernelGGL((bn_stats_kernel<T, VEC>), grid, dim3(BN_THREADS), 0, s, (const T *)x, M, p.chunk, p.S,  \
+                               pre_bias, part);                                                                        \
+        hipLaunchKernelGGL((bn_apply_kernel<T, VEC>), grid, dim3(BN_THREADS), 0, s, (const T *)x, M, p.chunk, p.S,     \
+                           pre_bias, gamma, beta, (const T *)residual, act, slope, eps, momentum, training,            \
+                           running_mean, running_var, part, (T *)out, save_mean, save_invstd);                         \
+    } while (0)
+    if (dtype == GRAFP_F32) {
+        if (bn_vec_ok<float>(x, out, residual, nullptr, M)) BN_FWD(float, true); else BN_FWD(float, false);
+    } else {
+        if (bn_vec_ok<unsigned short>(x, out, residual, nullptr, M)) BN_FWD(unsigned short, true); else BN_FWD(unsigned short, false);
+    }
+#undef BN_FWD
+    GRAFP_CHECK_LAUNCH("bn_stats_kernel / bn_apply_kernel");
+    return GRAFP_OK;
+}
+
+extern "C" int grafp_bn_bwd(const void *x, const void *dz, int dtype, int C, int64_t M, const float *pre_bias,
+                            const float *gamma, const float *beta, const float *save_mean, const float *save_invstd,
+                            int act, float slope, int training, void *dx, float *dgamma, float *dbeta, void *ws,
+                            size_t ws_bytes, grafp_stream_t stream) {
+    using namespace grafp;
+    GRAFP_REQUIRE(x && dz && gamma && beta && save_mean && save_invstd && dx && dgamma && dbeta, "bn_bwd: null pointer");
+    GRAFP_REQUIRE(C > 0 && M > 0 && C <= 65535, "bn_bwd: bad shape C=%d M=%lld", C, (long long)M);
+    GRAFP_REQUIRE(dtype == GRAFP_F32 || dtype == GRAFP_BF16, "bn_bwd: dtype %d not in {f32, bf16}", dtype);
+    GRAFP_REQUIRE(act >= 0 && act <= 2, "bn_bwd: act %d not in {0 none, 1 relu, 2 leaky}", act);
+    if (!ws || ws_bytes < grafp_bn_workspace(C, M)) {
+        set_error("bn_bwd: workspace %zu bytes < required %zu", ws_bytes, grafp_bn_workspace(C, M));
+        return GRAFP_ERR_WORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    float *part = (float *)ws;
+#define BN_BWD(T, VEC)                                                                                                 \
+    do {                                                                                                               \
+        const BnPlan p = bn_plan(C, M, BnIO<T>::W);                                                                    \
+        const dim3 grid(p.S, C);                                                                                       \
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, VEC>), grid, dim3(BN_THREADS), 0, s, (const T *)x, (const T *)dz,  \
+                           M, p.chunk, p.S, pre_bias, gamma, beta, save_mean, save_invstd, act, slope, part);          \
+        hipLaunchKernelGGL((bn_bwd_dx_kernel<T, VEC>), grid, dim3(BN_THREADS), 0, s, (const T *)x, (const T *)dz, M,   \
+                           p.chunk, p.S, pre_bias, gamma, beta, save_mean, save_invstd, act, slope, training, part,    \
+                           (T *)dx, dgamma, dbeta);                                                                    \
+    } while (0)
+    if (dtype == GRAFP_F32) {
+        if (bn_vec_ok<float>(x, dz, dx, nullptr, M)) BN_BWD(float, true); else BN_BWD(float, false);
+    } else {
+        if (bn_vec_ok<unsigned short>(x, dz, dx, nullptr, M)) BN_BWD(unsigned short, true); else BN_BWD(unsigned short, false);
+    }
+#undef BN_BWD
+    GRAFP_CHECK_LAUNCH("bn_bwd_reduce_kernel / bn_bwd_dx_kernel");
+    return GRAFP_OK;
+}

@@ -21,26 +21,54 @@ constexpr int TR = 128;  // candidate nodes per pass
 constexpr int KC = 32;   // channels per LDS chunk
 
 // ---- pass 1: channel-L2 normalisation (torch_edge.py:281) and squared norms -------------------
-// One thread per node; lanes run over consecutive nodes so every load/store is coalesced.
-__global__ __launch_bounds__(256) void knn_normalize_kernel(const float *__restrict__ x, float *__restrict__ xn,
-                                                            float *__restrict__ sq, int C, int N, int normalize) {
+// One thread per node; lanes run over consecutive nodes so every load/store is coalesced.  The input may be
+// any (b, c) strided view with N contiguous -- (B,C,N) or the GEMM-friendly (C,B,N) -- in f32 or bf16; xn/sq are
+// always written as contiguous (B,C,N)/(B,N) f32 for pass 2.  Loads are issued 8 channels ahead of the
+// dependent fmaf chain (the chain order is still c ascending).
+__device__ __forceinline__ float ld_as_f32(const float *p) { return *p; }
+__device__ __forceinline__ float ld_as_f32(const unsigned short *p) { return __uint_as_float(((unsigned)*p) << 16); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void knn_normalize_kernel(const T *__restrict__ x, int64_t sb, int64_t sc,
+                                                            float *__restrict__ xn, float *__restrict__ sq, int C,
+                                                            int N, int normalize) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     const int b = blockIdx.y;
     if (n >= N) return;
-    const float *xb = x + (size_t)b * C * N + n;
+    const T *xb = x + (size_t)b * sb + n;
     float *ob = xn + (size_t)b * C * N + n;
     float den = 1.0f;
     if (normalize) {
         float ss = 0.0f;
-        for (int c = 0; c < C; ++c) {
-            const float v = xb[(size_t)c * N];
+        int c = 0;
+        for (; c + 8 <= C; c += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = ld_as_f32(xb + (size_t)(c + u) * sc);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) ss = __builtin_fmaf(v[u], v[u], ss);
+        }
+        for (; c < C; ++c) {
+            const float v = ld_as_f32(xb + (size_t)c * sc);
             ss = __builtin_fmaf(v, v, ss);
         }
         den = fmaxf(__fsqrt_rn(ss), 1e-12f);
     }
     float q = 0.0f;
-    for (int c = 0; c < C; ++c) {
-        float v = xb[(size_t)c * N];
+    int c = 0;
+    for (; c + 8 <= C; c += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = ld_as_f32(xb + (size_t)(c + u) * sc);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (normalize) v[u] = __fdiv_rn(v[u], den);
+            ob[(size_t)(c + u) * N] = v[u];
+            q = __builtin_fmaf(v[u], v[u], q);
+        }
+    }
+    for (; c < C; ++c) {
+        float v = ld_as_f32(xb + (size_t)c * sc);
         if (normalize) v = __fdiv_rn(v, den);
         ob[(size_t)c * N] = v;
         q = __builtin_fmaf(v, v, q);
@@ -228,14 +256,25 @@ static bool knn_args_ok(const void *a, const void *b, int B, int C, int N, int k
     return true;
 }
 
-extern "C" int grafp_knn_normalize_f32(const float *x, int B, int C, int N, int normalize, float *xn, float *sq,
-                                       grafp_stream_t stream) {
+extern "C" int grafp_knn_normalize_strided(const void *x, int dtype, int64_t stride_b, int64_t stride_c, int B, int C,
+                                           int N, int normalize, float *xn, float *sq, grafp_stream_t stream) {
     using namespace grafp;
     if (!knn_args_ok(x, xn, B, C, N, 1) || !knn_args_ok(x, sq, B, C, N, 1)) return GRAFP_ERR_ARG;
-    hipLaunchKernelGGL(knn_normalize_kernel, dim3((N + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, x, xn, sq, C, N,
-                       normalize);
+    GRAFP_REQUIRE(dtype == GRAFP_F32 || dtype == GRAFP_BF16, "knn_normalize: dtype %d not in {f32, bf16}", dtype);
+    const dim3 grid((N + 255) / 256, B);
+    if (dtype == GRAFP_F32)
+        hipLaunchKernelGGL(knn_normalize_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float *)x,
+                           stride_b, stride_c, xn, sq, C, N, normalize);
+    else
+        hipLaunchKernelGGL(knn_normalize_kernel<unsigned short>, grid, dim3(256), 0, (hipStream_t)stream,
+                           (const unsigned short *)x, stride_b, stride_c, xn, sq, C, N, normalize);
     GRAFP_CHECK_LAUNCH("knn_normalize_kernel");
     return GRAFP_OK;
+}
+
+extern "C" int grafp_knn_normalize_f32(const float *x, int B, int C, int N, int normalize, float *xn, float *sq,
+                                       grafp_stream_t stream) {
+    return grafp_knn_normalize_strided(x, GRAFP_F32, (int64_t)C * N, N, B, C, N, normalize, xn, sq, stream);
 }
 
 extern "C" int grafp_knn_topk_f32(const float *xn, const float *sq, int B, int C, int N, int k, int64_t *idx,

@@ -1,49 +1,71 @@
-"""Dense building blocks on the (B, C, N) node layout.
+"""Dense building blocks on the MI355X-first activation layout (C, B, N) -- "CBN".
 
-The reference keeps activations as (B,C,N,1) images and runs 1x1 `Conv2d`s (through the conv library);
-with N contiguous a 1x1 convolution is exactly the batched GEMM  W (Cout x Cin) @ X_b (Cin x N), so the
-parameter-holding nn.Conv2d / nn.BatchNorm2d modules are kept (state-dict schema)
-but applied functionally as plain library GEMMs (hipBLASLt/rocBLAS via torch.matmul) -- no conv
-library, no layout change, and bf16 autocast applies to them directly.
+The reference keeps activations as (B,C,N,1) images and runs 1x1 `Conv2d`s through the conv library.  Here an
+activation is a (C, M = B*N) matrix whose ROWS are channels (N contiguous inside each clip, clips side by side):
+
+  * a 1x1 convolution is ONE plain GEMM  W (Cout x Cin) @ X (Cin x M)  with M = B*N = 262 144 at B=256 -- not B
+    small batched GEMMs; its weight gradient is ONE GEMM with K = M (no (B,Cout,Cin) intermediate + reduction),
+    its input gradient one more; bf16 autocast applies to them directly;
+  * BatchNorm statistics are reductions over one contiguous row: fused with the conv bias, the activation and the
+    residual add in a single HIP kernel pair (ops.bn_act);
+  * the graph kernels (ops.knn_graph / ops.max_relative) address clip b, channel c at  c*B*N + b*N  -- no layout
+    or dtype copies anywhere in the block.
+
+The parameter-holding nn.Conv2d / nn.BatchNorm2d modules are kept (state-dict schema) and
+applied functionally.  `to_cbn` / `from_cbn` convert at the module boundary when a block is called on the
+reference's (B,C,N[,1]) layout directly.
 """
 import torch
 import torch.nn.functional as F
 
+from .. import ops
 
-def pointwise(conv, x):
-    """1x1 Conv2d (any `groups`) applied to x (B,Cin,N) -> (B,Cout,N)."""
-    B, cin, N = x.shape
+
+def to_cbn(x):
+    """(B,C,N) or (B,C,N,1) -> (C,B,N) contiguous."""
+    if x.dim() == 4:
+        x = x.squeeze(-1)
+    return x.permute(1, 0, 2).contiguous()
+
+
+def from_cbn(y, like):
+    """(C,B,N) -> the layout of `like` ((B,C,N) or (B,C,N,1))."""
+    y = y.permute(1, 0, 2).contiguous()
+    return y.unsqueeze(-1) if like.dim() == 4 else y
+
+
+def conv1x1(conv, x):
+    """1x1 Conv2d weights (any `groups`, bias NOT applied) on x (Cin,B,N) -> (Cout,B,N): one GEMM (a 4-batch GEMM
+    for the grouped conv of the max-relative block)."""
+    cin, B, N = x.shape
     cout, g = conv.out_channels, conv.groups
     w = conv.weight.reshape(cout, cin // g)
     if g == 1:
-        y = torch.matmul(w, x)
+        y = torch.mm(w, x.reshape(cin, B * N))
     else:
-        y = torch.matmul(w.reshape(g, cout // g, cin // g), x.reshape(B, g, cin // g, N)).reshape(B, cout, N)
-    if conv.bias is not None:
-        y = y + conv.bias.reshape(1, cout, 1).to(y.dtype)
-    return y
+        y = torch.bmm(w.reshape(g, cout // g, cin // g), x.reshape(g, cin // g, B * N))
+    return y.reshape(cout, B, N)
 
 
-def strided3(conv, x):
-    """Conv2d(k=3, stride=2, pad=1) applied to the (N,1) node grid (graph_encoder.py:21-24).  Only kernel
-    column 1 ever overlaps data (columns 0 and 2 see the zero padding of the width-1 axis), so the op is
-    a 3-tap stride-2 convolution along N: gather the three taps and run one GEMM with K = 3*Cin."""
-    B, cin, N = x.shape
+def conv3_stride2(conv, x):
+    """Conv2d(k=3, stride=2, pad=1) on the (N,1) node grid (graph_encoder.py:21-24), bias NOT applied.  Only kernel
+    column 1 ever overlaps data (columns 0 and 2 see the zero padding of the width-1 axis), so the op is a 3-tap
+    stride-2 convolution along N: gather the three taps, then one GEMM with K = 3*Cin (the conv library computes
+    3x the flops on zeros)."""
+    cin, B, N = x.shape
     cout = conv.out_channels
     n_out = (N - 1) // 2 + 1
     xp = F.pad(x, (1, 1))
-    taps = torch.cat([xp[:, :, t:t + 2 * n_out - 1:2] for t in range(3)], dim=1)      # (B, 3Cin, n_out)
-    w = conv.weight[:, :, :, 1].permute(0, 2, 1).reshape(cout, 3 * cin)                # [o][t*Cin + c]
-    y = torch.matmul(w, taps)
-    if conv.bias is not None:
-        y = y + conv.bias.reshape(1, cout, 1).to(y.dtype)
-    return y
+    taps = torch.cat([xp[:, :, t:t + 2 * n_out - 1:2] for t in range(3)], dim=0)       # (3Cin, B, n_out)
+    w = conv.weight[:, :, :, 1].permute(0, 2, 1).reshape(cout, 3 * cin)                 # [o][t*Cin + c]
+    return torch.mm(w, taps.reshape(3 * cin, B * n_out)).reshape(cout, B, n_out)
 
 
-def batchnorm(bn, x):
-    """nn.BatchNorm2d semantics (batch statistics + running-stat update in train mode) on (B,C,N)."""
-    use_batch = bn.training or not bn.track_running_stats
+def bn_act(bn, y, pre_bias=None, residual=None, act=ops.ACT_NONE, slope=0.0):
+    """nn.BatchNorm2d semantics (batch statistics + running-stat update in train mode) over the rows of y (C,B,N),
+    fused with the preceding conv's bias, the activation and the residual add."""
+    training = bn.training or not bn.track_running_stats
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
-    return F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, use_batch,
-                        0.0 if bn.momentum is None else bn.momentum, bn.eps)
+    return ops.bn_act(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, training,
+                      0.0 if bn.momentum is None else bn.momentum, bn.eps, pre_bias, residual, act, slope)

@@ -3,7 +3,8 @@ BasicConv, batched_index_select, MLP)."""
 import torch
 from torch import nn
 
-from .._dense import batchnorm, pointwise
+from ... import ops
+from .._dense import bn_act, conv1x1, from_cbn, to_cbn
 
 _ACTS = {
     "relu": lambda inplace, slope, n: nn.ReLU(inplace),
@@ -69,20 +70,33 @@ class BasicConv(nn.Sequential):
                 m.weight.data.fill_(1)
                 m.bias.data.zero_()
 
-    def forward(self, x):
-        four_d = x.dim() == 4
-        if four_d:
-            x = x.squeeze(-1)
-        for m in self:
+    def forward_cbn(self, x):
+        """x (Cin,B,N) -> (Cout,B,N).  [conv, BatchNorm, ReLU] triples run as GEMM + one fused kernel."""
+        mods, i = list(self), 0
+        while i < len(mods):
+            m = mods[i]
             if isinstance(m, nn.Conv2d):
-                x = pointwise(m, x)
-            elif isinstance(m, nn.BatchNorm2d):
-                x = batchnorm(m, x)
-            elif isinstance(m, (nn.InstanceNorm2d, nn.Dropout2d)):
-                x = m(x.unsqueeze(-1)).squeeze(-1)
+                y = conv1x1(m, x)
+                nxt = mods[i + 1] if i + 1 < len(mods) else None
+                if isinstance(nxt, nn.BatchNorm2d):
+                    act_mod = mods[i + 2] if i + 2 < len(mods) else None
+                    if isinstance(act_mod, nn.ReLU):
+                        x, i = bn_act(nxt, y, pre_bias=m.bias, act=ops.ACT_RELU), i + 3
+                    elif isinstance(act_mod, nn.LeakyReLU):
+                        x, i = bn_act(nxt, y, pre_bias=m.bias, act=ops.ACT_LEAKY, slope=act_mod.negative_slope), i + 3
+                    else:
+                        x, i = bn_act(nxt, y, pre_bias=m.bias), i + 2
+                    continue
+                x = y if m.bias is None else y + m.bias.reshape(-1, 1, 1).to(y.dtype)
+            elif isinstance(m, (nn.BatchNorm2d, nn.InstanceNorm2d, nn.Dropout2d)):
+                x = bn_act(m, x) if isinstance(m, nn.BatchNorm2d) else to_cbn(m(from_cbn(x, x.new_empty(0, 0, 0, 0))))
             else:
                 x = m(x)
-        return x.unsqueeze(-1) if four_d else x
+            i += 1
+        return x
+
+    def forward(self, x):
+        return from_cbn(self.forward_cbn(to_cbn(x)), x)
 
 
 def batched_index_select(x, idx):

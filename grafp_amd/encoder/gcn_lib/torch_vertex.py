@@ -11,7 +11,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ... import ops
-from .._dense import batchnorm, pointwise
+from .._dense import bn_act, conv1x1, from_cbn, to_cbn
 from .pos_embed import get_2d_relative_pos_embed
 from .torch_edge import DenseDilatedKnnGraph
 from .torch_nn import BasicConv
@@ -24,14 +24,14 @@ class MRConv2d(nn.Module):
         super().__init__()
         self.nn = BasicConv([in_channels * 2, out_channels], act, norm, bias)
 
-    def aggregate(self, x, nn_idx):
-        return self.nn(ops.max_relative(x, nn_idx))
+    def aggregate_cbn(self, x, nn_idx):
+        """x (C,B,N), nn_idx (B,N,k) -> (Cout,B,N)."""
+        return self.nn.forward_cbn(ops.max_relative(x, nn_idx, layout="cbn"))
 
     def forward(self, x, edge_index, y=None):
         if y is not None:
             raise NotImplementedError("r > 1 (separate y) is unreachable in GraFPrint")
-        out = self.aggregate(x.squeeze(-1) if x.dim() == 4 else x, edge_index[0])
-        return out.unsqueeze(-1) if x.dim() == 4 else out
+        return from_cbn(self.aggregate_cbn(to_cbn(x), edge_index[0]), x)
 
 
 class GraphConv2d(nn.Module):
@@ -56,10 +56,13 @@ class DyGraphConv2d(GraphConv2d):
         self.k, self.d, self.r = kernel_size, dilation, r
         self.dilated_knn_graph = DenseDilatedKnnGraph(kernel_size, dilation, stochastic, epsilon)
 
+    def forward_cbn(self, x):
+        return self.gconv.aggregate_cbn(x, self.dilated_knn_graph.neighbours(x, layout="cbn"))
+
     def forward(self, x, relative_pos=None):
         shape = x.shape
         nodes = x.reshape(shape[0], shape[1], -1)
-        out = self.gconv.aggregate(nodes, self.dilated_knn_graph.neighbours(nodes))
+        out = from_cbn(self.forward_cbn(to_cbn(nodes)), nodes)
         return out.reshape(shape[0], -1, *shape[2:])
 
 
@@ -83,10 +86,11 @@ class Grapher(nn.Module):
             table = F.interpolate(table[None, None], size=(n, n // (r * r)), mode="bicubic", align_corners=False)
             self.relative_pos = nn.Parameter(-table.squeeze(1), requires_grad=False)
 
+    def forward_cbn(self, x):
+        """x (C,B,N) -> (C,B,N): 3 GEMMs, 3 fused BN kernels, the k-NN build and the max-relative gather."""
+        y = bn_act(self.fc1[1], conv1x1(self.fc1[0], x), pre_bias=self.fc1[0].bias)
+        y = self.graph_conv.forward_cbn(y)
+        return bn_act(self.fc2[1], conv1x1(self.fc2[0], y), pre_bias=self.fc2[0].bias, residual=x)
+
     def forward(self, x):
-        four_d = x.dim() == 4
-        h = x.squeeze(-1) if four_d else x
-        y = batchnorm(self.fc1[1], pointwise(self.fc1[0], h))
-        y = self.graph_conv(y)
-        y = batchnorm(self.fc2[1], pointwise(self.fc2[0], y)) + h
-        return y.unsqueeze(-1) if four_d else y
+        return from_cbn(self.forward_cbn(to_cbn(x)), x)

@@ -9,7 +9,8 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ._dense import batchnorm, pointwise, strided3
+from .. import ops
+from ._dense import bn_act, conv1x1, conv3_stride2, from_cbn, to_cbn
 from .gcn_lib.torch_nn import act_layer
 from .gcn_lib.torch_vertex import Grapher
 
@@ -27,10 +28,11 @@ class Downsample(nn.Module):
         super().__init__()
         self.conv = nn.Sequential(nn.Conv2d(in_dim, out_dim, 3, stride=2, padding=1), nn.BatchNorm2d(out_dim))
 
+    def forward_cbn(self, x):
+        return bn_act(self.conv[1], conv3_stride2(self.conv[0], x), pre_bias=self.conv[0].bias)
+
     def forward(self, x):
-        four_d = x.dim() == 4
-        y = batchnorm(self.conv[1], strided3(self.conv[0], x.squeeze(-1) if four_d else x))
-        return y.unsqueeze(-1) if four_d else y
+        return from_cbn(self.forward_cbn(to_cbn(x)), x)
 
 
 class ChannelConv(nn.Module):
@@ -40,10 +42,11 @@ class ChannelConv(nn.Module):
         super().__init__()
         self.conv = nn.Sequential(nn.Conv2d(in_dim, out_dim, kernel_size=1, bias=False), nn.BatchNorm2d(out_dim))
 
+    def forward_cbn(self, x):
+        return bn_act(self.conv[1], conv1x1(self.conv[0], x))
+
     def forward(self, x):
-        four_d = x.dim() == 4
-        y = batchnorm(self.conv[1], pointwise(self.conv[0], x.squeeze(-1) if four_d else x))
-        return y.unsqueeze(-1) if four_d else y
+        return from_cbn(self.forward_cbn(to_cbn(x)), x)
 
 
 class FFN(nn.Module):
@@ -58,12 +61,16 @@ class FFN(nn.Module):
         self.fc1 = nn.Sequential(nn.Conv2d(in_features, hidden_features, 1, bias=False), nn.BatchNorm2d(hidden_features))
         self.fc2 = nn.Sequential(nn.Conv2d(hidden_features, out_features, 1, bias=False), nn.BatchNorm2d(out_features))
 
+    def forward_cbn(self, x):
+        """x (C,B,N) -> (C,B,N): 2 GEMMs + 2 fused BN kernels (ReLU and the shortcut add are inside them)."""
+        if isinstance(self.act, torch.nn.ReLU):
+            h = bn_act(self.fc1[1], conv1x1(self.fc1[0], x), act=ops.ACT_RELU)
+        else:
+            h = self.act(bn_act(self.fc1[1], conv1x1(self.fc1[0], x)))
+        return bn_act(self.fc2[1], conv1x1(self.fc2[0], h), residual=x)
+
     def forward(self, x):
-        four_d = x.dim() == 4
-        h = x.squeeze(-1) if four_d else x
-        y = self.act(batchnorm(self.fc1[1], pointwise(self.fc1[0], h)))
-        y = batchnorm(self.fc2[1], pointwise(self.fc2[0], y)) + h
-        return y.unsqueeze(-1) if four_d else y
+        return from_cbn(self.forward_cbn(to_cbn(x)), x)
 
 
 class GraphEncoder(nn.Module):
@@ -105,10 +112,17 @@ class GraphEncoder(nn.Module):
                     m.bias.requires_grad = True
 
     def forward(self, x):
-        """x (B, C_in, N) node features -> (B, 1024)."""
-        if x.dim() == 4:
-            x = x.squeeze(-1)
-        x = F.leaky_relu(batchnorm(self.stem[1], pointwise(self.stem[0], x)), self.stem[2].negative_slope)
+        """x (B, C_in, N) node features -> (B, 1024).  Internally every activation is a (C, B, N) matrix."""
+        x = to_cbn(x)
+        x = bn_act(self.stem[1], conv1x1(self.stem[0], x), act=ops.ACT_LEAKY, slope=self.stem[2].negative_slope)
         for mod in self.backbone:
-            x = mod(x)
-        return pointwise(self.proj, x).mean(dim=2)
+            if isinstance(mod, Downsample):
+                x = mod.forward_cbn(x)
+            else:
+                x = mod[1].forward_cbn(mod[0].forward_cbn(x))
+        # readout: mean over nodes commutes with the (linear) 1x1 projection -- project the (C,B) means instead
+        # of the (C,B,N) activations (graph_encoder.py:187-188 projects first: same result, 128x the work)
+        pooled = x.float().mean(dim=2)                                              # (C, B)
+        w = self.proj.weight.reshape(self.proj.out_channels, -1)
+        h = torch.mm(w, pooled.to(w.dtype)) + self.proj.bias.reshape(-1, 1)
+        return h.t().contiguous()

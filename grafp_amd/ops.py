@@ -207,20 +207,36 @@ def peak_extract(spec, weight, bias, stride_h):
 # ------------------------------------------------------------------------------------------------
 # K3-K5  k-NN graph
 # ------------------------------------------------------------------------------------------------
-def knn_graph(x, k, normalize=True):
-    """x (B,C,N) or (B,C,N,1) -> int64 (B,N,k) nearest-neighbour indices (ascending distance, ties to
-    the lowest index).  Non-differentiable, as in the reference (torch_edge.py:78 `no_grad`)."""
+_DT = {torch.float32: 0, torch.bfloat16: 1}
+
+
+def _act_view(x, layout):
+    """Return (tensor, B, C, N, stride_b, stride_c) for an activation in 'bcn' = (B,C,N) or 'cbn' = (C,B,N)
+    layout (N contiguous), f32 or bf16, without copying when it already is contiguous."""
+    if x.dtype not in _DT:
+        x = x.float()
+    x = x.contiguous()
+    if layout == "bcn":
+        B, C, N = x.shape
+        return x, B, C, N, C * N, N
+    C, B, N = x.shape
+    return x, B, C, N, N, B * N
+
+
+def knn_graph(x, k, normalize=True, layout="bcn"):
+    """x (B,C,N) / (B,C,N,1) [layout 'bcn'] or (C,B,N) [layout 'cbn'], f32 or bf16 -> int64 (B,N,k)
+    nearest-neighbour indices (ascending distance, ties to the lowest index).  Non-differentiable, as in the
+    reference (torch_edge.py:78 `no_grad`).  bf16 inputs are widened exactly; all arithmetic is f32."""
     _require_gpu(x)
     if x.dim() == 4:
         x = x.squeeze(-1)
-    x = _f32c(x)
-    B, C, N = x.shape
+    x, B, C, N, sb, sc = _act_view(x.detach(), layout)
     idx = torch.empty((B, N, k), dtype=torch.int64, device=x.device)
-    xn = torch.empty_like(x)
+    xn = torch.empty((B, C, N), dtype=torch.float32, device=x.device)
     sq = torch.empty((B, N), dtype=torch.float32, device=x.device)
     with _timed("knn_normalize", (B, C, N, k)):
-        check(lib.grafp_knn_normalize_f32(_p(x), B, C, N, int(bool(normalize)), _p(xn), _p(sq), _stream()),
-              "knn_normalize")
+        check(lib.grafp_knn_normalize_strided(_p(x), _DT[x.dtype], sb, sc, B, C, N, int(bool(normalize)), _p(xn),
+                                              _p(sq), _stream()), "knn_normalize")
     with _timed("knn_topk", (B, C, N, k)):
         check(lib.grafp_knn_topk_f32(_p(xn), _p(sq), B, C, N, k, _p(idx), _stream()), "knn_topk")
     return idx
@@ -231,37 +247,102 @@ def knn_graph(x, k, normalize=True):
 # ------------------------------------------------------------------------------------------------
 class _MaxRelative(torch.autograd.Function):
     @staticmethod
-    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
-    def forward(ctx, x, idx):
+    def forward(ctx, x, idx, layout):
         _require_gpu(x, idx)
-        x = _f32c(x)
+        x, B, C, N, sb, sc = _act_view(x.detach(), layout)
         idx = idx.to(torch.int64).contiguous()
-        B, C, N = x.shape
         K = idx.shape[-1]
         if tuple(idx.shape) != (B, N, K):
-            raise ValueError(f"idx shape {tuple(idx.shape)} does not match x {(B, C, N)}")
-        out = torch.empty((B, 2 * C, N), dtype=torch.float32, device=x.device)
+            raise ValueError(f"idx shape {tuple(idx.shape)} does not match activations B={B} N={N}")
+        out = torch.empty((B, 2 * C, N) if layout == "bcn" else (2 * C, B, N), dtype=x.dtype, device=x.device)
+        o_sb, o_sc = (2 * C * N, N) if layout == "bcn" else (N, B * N)
         with _timed("mrconv_fwd", (B, C, N, K)):
-            check(lib.grafp_mrconv_fwd_f32(_p(x), _p(idx), B, C, N, K, _p(out), _stream()), "mrconv_fwd")
+            check(lib.grafp_mrconv_fwd_strided(_p(x), _DT[x.dtype], sb, sc, _p(idx), B, C, N, K, _p(out), o_sb, o_sc,
+                                               _stream()), "mrconv_fwd")
         ctx.save_for_backward(x, idx)
+        ctx.layout = layout
         return out
 
     @staticmethod
-    @custom_bwd(device_type="cuda")
     def backward(ctx, grad_out):
         x, idx = ctx.saved_tensors
-        B, C, N = x.shape
+        layout = ctx.layout
+        _, B, C, N, sb, sc = _act_view(x, layout)
         K = idx.shape[-1]
-        g = _f32c(grad_out)
+        g = grad_out.detach().to(x.dtype).contiguous()
+        g_sb, g_sc = (2 * C * N, N) if layout == "bcn" else (N, B * N)
         dx = torch.empty_like(x)
         with _timed("mrconv_bwd", (B, C, N, K)):
-            check(lib.grafp_mrconv_bwd_f32(_p(x), _p(idx), _p(g), B, C, N, K, _p(dx), _stream()), "mrconv_bwd")
-        return dx, None
+            check(lib.grafp_mrconv_bwd_strided(_p(x), _DT[x.dtype], sb, sc, _p(idx), _p(g), g_sb, g_sc, B, C, N, K,
+                                               _p(dx), _stream()), "mrconv_bwd")
+        return dx, None, None
 
 
-def max_relative(x, idx):
-    """x (B,C,N), idx (B,N,K) -> (B,2C,N): channel 2c = x[c], channel 2c+1 = max_k(x[c, idx] - x[c])."""
-    return _MaxRelative.apply(x, idx)
+def max_relative(x, idx, layout="bcn"):
+    """x (B,C,N) ['bcn'] or (C,B,N) ['cbn'], idx (B,N,K) -> (B,2C,N) / (2C,B,N): channel 2c = x[c],
+    channel 2c+1 = max_k(x[c, idx] - x[c]).  f32 or bf16 in = out dtype (arithmetic in f32)."""
+    return _MaxRelative.apply(x, idx, layout)
+
+
+# ------------------------------------------------------------------------------------------------
+# K8/K9 glue  fused [conv bias] + BatchNorm + activation + residual on (C, M) rows
+# ------------------------------------------------------------------------------------------------
+ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+
+
+class _BnAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, pre_bias, residual, running_mean, running_var, training, momentum, eps, act,
+                slope):
+        _require_gpu(x, gamma, beta)
+        if x.dtype not in _DT:
+            x = x.float()
+        x = x.detach().contiguous()
+        C = x.shape[0]
+        M = x.numel() // C
+        res = None if residual is None else residual.detach().to(x.dtype).contiguous()
+        g32, b32 = _f32c(gamma), _f32c(beta)
+        pb = None if pre_bias is None else _f32c(pre_bias)
+        out = torch.empty_like(x)
+        mean = torch.empty((C,), dtype=torch.float32, device=x.device)
+        invstd = torch.empty((C,), dtype=torch.float32, device=x.device)
+        nbytes = lib.grafp_bn_workspace(C, M)
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
+        with _timed("bn_fwd", (C, M, x.element_size())):
+            check(lib.grafp_bn_fwd(_p(x), _DT[x.dtype], C, M, _p(pb), _p(g32), _p(b32), _p(res), act, float(slope),
+                                   float(eps), float(momentum), int(bool(training)), _p(running_mean), _p(running_var),
+                                   _p(out), _p(mean), _p(invstd), _p(ws), nbytes, _stream()), "bn_fwd")
+        ctx.save_for_backward(x, g32, b32, pb if pb is not None else mean.new_empty(0), mean, invstd)
+        ctx.cfg = (C, M, act, float(slope), bool(training), pre_bias is not None, residual is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, g32, b32, pb, mean, invstd = ctx.saved_tensors
+        C, M, act, slope, training, has_pb, has_res = ctx.cfg
+        dz = dz.detach().to(x.dtype).contiguous()
+        dx = torch.empty_like(x)
+        dgamma = torch.empty((C,), dtype=torch.float32, device=x.device)
+        dbeta = torch.empty((C,), dtype=torch.float32, device=x.device)
+        nbytes = lib.grafp_bn_workspace(C, M)
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
+        with _timed("bn_bwd", (C, M, x.element_size())):
+            check(lib.grafp_bn_bwd(_p(x), _p(dz), _DT[x.dtype], C, M, _p(pb) if has_pb else None, _p(g32), _p(b32),
+                                   _p(mean), _p(invstd), act, slope, int(training), _p(dx), _p(dgamma), _p(dbeta),
+                                   _p(ws), nbytes, _stream()), "bn_bwd")
+        dpb = None
+        if has_pb:      # cancels exactly under batch statistics; a plain bias in eval mode
+            dpb = torch.zeros_like(dgamma) if training else dx.reshape(C, -1).float().sum(dim=1)
+        return dx, dgamma, dbeta, dpb, (dz if has_res else None), None, None, None, None, None, None, None
+
+
+def bn_act(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, pre_bias=None, residual=None,
+           act=ACT_NONE, slope=0.0):
+    """z = act(BatchNorm(x + pre_bias)) + residual over ROWS of x (C, ...): one fused HIP forward (2 passes) and
+    backward (2 passes).  x / residual / z share a dtype (f32 or bf16); parameters and statistics are f32.
+    running_mean / running_var are updated in place when training."""
+    return _BnAct.apply(x, gamma, beta, pre_bias, residual, running_mean, running_var, training, momentum, eps, act,
+                        slope)
 
 
 # ------------------------------------------------------------------------------------------------

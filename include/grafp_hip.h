@@ -37,6 +37,10 @@ extern "C" {
 
 typedef void *grafp_stream_t; /* hipStream_t */
 
+/* element types of the *_strided entry points (bf16 = upper 16 bits of an IEEE f32, round-to-nearest-even) */
+#define GRAFP_F32 0
+#define GRAFP_BF16 1
+
 int grafp_abi_version(void);
 const char *grafp_last_error(void);
 
@@ -92,6 +96,10 @@ int grafp_knn_normalize_f32(const float *x, int B, int C, int N, int normalize, 
                             grafp_stream_t stream);
 int grafp_knn_topk_f32(const float *xn, const float *sq, int B, int C, int N, int k, int64_t *idx,
                        grafp_stream_t stream);
+/* normalize pass reading any (b,c)-strided view with N contiguous: element (b,c,n) at x + b*stride_b + c*stride_c + n
+ * (elements of `dtype`), e.g. the GEMM-friendly (C,B,N) layout (stride_b = N, stride_c = B*N). */
+int grafp_knn_normalize_strided(const void *x, int dtype, int64_t stride_b, int64_t stride_c, int B, int C, int N,
+                                int normalize, float *xn, float *sq, grafp_stream_t stream);
 int grafp_knn_graph_f32(const float *x, int B, int C, int N, int k, int normalize, int64_t *idx, void *ws,
                         size_t ws_bytes, grafp_stream_t stream);
 
@@ -106,6 +114,33 @@ int grafp_mrconv_fwd_f32(const float *x, const int64_t *idx, int B, int C, int N
                          grafp_stream_t stream);
 int grafp_mrconv_bwd_f32(const float *x, const int64_t *idx, const float *grad_out, int B, int C, int N, int K,
                          float *dx, grafp_stream_t stream);
+/* Same, any (b,c)-strided views with N contiguous, f32 or bf16 elements (out/grad_out have 2C channels; dx uses
+ * x's strides). */
+int grafp_mrconv_fwd_strided(const void *x, int dtype, int64_t x_sb, int64_t x_sc, const int64_t *idx, int B, int C,
+                             int N, int K, void *out, int64_t o_sb, int64_t o_sc, grafp_stream_t stream);
+int grafp_mrconv_bwd_strided(const void *x, int dtype, int64_t x_sb, int64_t x_sc, const int64_t *idx,
+                             const void *grad_out, int64_t g_sb, int64_t g_sc, int B, int C, int N, int K, void *dx,
+                             grafp_stream_t stream);
+
+/* ---- K8/K9 glue: fused [conv bias] + BatchNorm + activation + residual on the (C, M = B*N) layout ----
+ * Replaces the `+ bias` -> BatchNorm2d -> ReLU/LeakyReLU -> `+ shortcut` chains around every 1x1 convolution
+ * (encoder/gcn_lib/torch_vertex.py:152-162,191-193; torch_nn.py:56-60; encoder/graph_encoder.py:52-55,60-66,131-133).
+ *   z[c][m] = act( ((x[c][m] + pre_bias[c]) - mean[c]) * invstd[c] * gamma[c] + beta[c] ) + residual[c][m]
+ * training != 0: mean/var are the batch statistics of row c (biased variance); running_mean/var (optional) are
+ * updated with `momentum` (unbiased variance), as nn.BatchNorm2d does.  training == 0: running statistics.
+ * x, residual (optional), out, dz, dx: (C, M) rows contiguous, elements of `dtype`; everything else f32.
+ * act: 0 none, 1 ReLU, 2 LeakyReLU(slope).  save_mean / save_invstd (C) feed the backward.
+ * Backward returns dx, dgamma, dbeta; the residual's gradient is dz itself; the gradient of pre_bias is exactly
+ * zero in training mode (it cancels in the normalisation) and sum_m dx in eval mode. */
+size_t grafp_bn_workspace(int C, int64_t M);
+int grafp_bn_fwd(const void *x, int dtype, int C, int64_t M, const float *pre_bias, const float *gamma,
+                 const float *beta, const void *residual, int act, float slope, float eps, float momentum,
+                 int training, float *running_mean, float *running_var, void *out, float *save_mean,
+                 float *save_invstd, void *ws, size_t ws_bytes, grafp_stream_t stream);
+int grafp_bn_bwd(const void *x, const void *dz, int dtype, int C, int64_t M, const float *pre_bias, const float *gamma,
+                 const float *beta, const float *save_mean, const float *save_invstd, int act, float slope,
+                 int training, void *dx, float *dgamma, float *dbeta, void *ws, size_t ws_bytes,
+                 grafp_stream_t stream);
 
 /* ---- K12: NT-Xent loss, fused forward + backward ----------------------------------------------
  * Replaces ntxent_loss (simclr/ntxent.py:4-29; called train.py:71).  Rows of the similarity matrix

@@ -70,8 +70,8 @@ class RecordedGraphs:
         from grafp_amd import ops
         self._ops, self._orig, self.graphs = ops, ops.knn_graph, []
 
-        def rec(x, k, normalize=True):
-            idx = self._orig(x, k, normalize)
+        def rec(x, k, normalize=True, layout="bcn"):
+            idx = self._orig(x, k, normalize, layout)
             self.graphs.append(idx.cpu())
             return idx
         ops.knn_graph = rec
@@ -91,3 +91,79 @@ class RecordedGraphs:
             self.flips += int((own != idx.numpy()).any(-1).sum())
             return idx
         return idx_fn
+
+
+class CpuOps:
+    """TEST-ONLY: swap the HIP ops for torch/oracle equivalents so the module mirror's WIRING (GEMM formulation,
+    layouts, state-dict mapping, BatchNorm bookkeeping) can be checked on a CPU-only machine.  The product never
+    does this: its ops refuse CPU tensors."""
+
+    def __enter__(self):
+        import torch.nn.functional as F
+        from grafp_amd import ops
+        from oracle import model as om
+        self._ops = ops
+        self._saved = (ops.knn_graph, ops.max_relative, ops.peak_extract, ops.bn_act)
+
+        def bcn(x, layout):
+            return x if layout == "bcn" else x.permute(1, 0, 2)
+
+        def knn(x, k, normalize=True, layout="bcn"):
+            if x.dim() == 4:
+                x = x.squeeze(-1)
+            return om.knn_graph_torch(bcn(x, layout).float(), k)
+
+        def maxrel(x, idx, layout="bcn"):
+            out = om.max_relative(bcn(x, layout), idx)
+            return out if layout == "bcn" else out.permute(1, 0, 2).contiguous()
+
+        def peak(spec, w, b, s):
+            return om.peak_extract({"peak_extractor.convs.0.weight": w, "peak_extractor.convs.0.bias": b}, spec, s)
+
+        def bn_act(x, gamma, beta, rm, rv, training, momentum=0.1, eps=1e-5, pre_bias=None, residual=None, act=0,
+                   slope=0.0):
+            C = x.shape[0]
+            y = x.reshape(1, C, -1)
+            if pre_bias is not None:
+                y = y + pre_bias.reshape(1, C, 1)
+            y = F.batch_norm(y, rm, rv, gamma, beta, training, momentum, eps).reshape(x.shape)
+            y = F.relu(y) if act == 1 else (F.leaky_relu(y, slope) if act == 2 else y)
+            return y if residual is None else y + residual
+        ops.knn_graph, ops.max_relative, ops.peak_extract, ops.bn_act = knn, maxrel, peak, bn_act
+        return self
+
+    def __exit__(self, *exc):
+        o = self._ops
+        o.knn_graph, o.max_relative, o.peak_extract, o.bn_act = self._saved
+
+
+def reference_graphs(sd, xi, xj, train):
+    """The k-NN graphs the REFERENCE builds for this input (oracle forward with the torch restatement of
+    dense_knn_matrix, which reproduces the reference's edges exactly on this host -- tests/test_oracle.py),
+    in call order.  `sd` is cloned: running statistics are not disturbed."""
+    from oracle import model as om
+    graphs = []
+
+    def rec(x, k):
+        idx = om.knn_graph_torch(x, k)
+        graphs.append(idx)
+        return idx
+    with torch.no_grad():
+        om.simclr_forward({k: v.detach().clone() for k, v in sd.items()}, xi, xj, train, idx_fn=rec)
+    return graphs
+
+
+class ReplayGraphs:
+    """TEST-ONLY: make grafp_amd.ops.knn_graph return pre-computed graphs (moved to the input's device)."""
+
+    def __init__(self, graphs):
+        self.graphs = graphs
+
+    def __enter__(self):
+        from grafp_amd import ops
+        self._ops, self._orig, it = ops, ops.knn_graph, iter(self.graphs)
+        ops.knn_graph = lambda x, k, normalize=True, layout="bcn": next(it).to(x.device)
+        return self
+
+    def __exit__(self, *exc):
+        self._ops.knn_graph = self._orig

@@ -307,3 +307,113 @@ def test_search_1m_planted_top1(dev):
         wd, wi = native.flat_search_l2(db.numpy(), q[:nq].numpy(), 20)
         assert np.array_equal(ii.cpu().numpy(), wi) and np.array_equal(dd.cpu().numpy(), wd)
         assert torch.equal(ii.cpu(), i[:nq].cpu())                    # batch-size independent
+
+
+# =============================================================== (C,B,N) layout + bf16 variants
+@pytest.mark.parametrize("B,C,N,k", [(3, 64, 1024, 3), (2, 512, 128, 3), (2, 10, 101, 4)])
+def test_knn_graph_cbn_layout_and_bf16(dev, B, C, N, k):
+    """The strided entry reads the GEMM-friendly (C,B,N) layout and bf16 activations; results are the same
+    indices as the (B,C,N) f32 path on the widened values (bit-exact vs the C oracle)."""
+    from grafp_amd import ops
+    from oracle import native
+    x = hash_normalish(f"gpu:knn.cbn.{C}.{N}", (B, C, N))
+    want = native.knn_graph(x, k)
+    xt = t(x).to(dev)
+    got = ops.knn_graph(xt.permute(1, 0, 2).contiguous(), k, layout="cbn").cpu().numpy()
+    assert np.array_equal(got, want)
+    xb = xt.to(torch.bfloat16)
+    want16 = native.knn_graph(xb.float().cpu().numpy(), k)
+    assert np.array_equal(ops.knn_graph(xb, k).cpu().numpy(), want16)
+    assert np.array_equal(ops.knn_graph(xb.permute(1, 0, 2).contiguous(), k, layout="cbn").cpu().numpy(), want16)
+
+
+@pytest.mark.parametrize("B,C,N,K", [(2, 64, 1024, 3), (3, 512, 128, 3), (2, 10, 101, 3)])
+def test_max_relative_cbn_layout_and_bf16(dev, B, C, N, K):
+    from grafp_amd import ops
+    from oracle import model as om
+    x = t(hash_normalish(f"gpu:mr.cbn.x.{C}.{N}", (B, C, N)))
+    idx = hash_ints(f"gpu:mr.cbn.idx.{C}.{N}", (B, N, K), 0, N - 1).astype(np.int64)
+    idx[:, :, 0] = np.arange(N)[None, :]
+    idx = t(idx)
+    g = t(hash_normalish(f"gpu:mr.cbn.g.{C}.{N}", (B, 2 * C, N)))
+    xr = x.clone().requires_grad_(True)
+    want = om.max_relative(xr, idx); want.backward(g)
+    xg = x.to(dev).permute(1, 0, 2).contiguous().requires_grad_(True)
+    got = ops.max_relative(xg, idx.to(dev), layout="cbn")
+    assert got.shape == (2 * C, B, N)
+    got.backward(g.to(dev).permute(1, 0, 2).contiguous())
+    assert torch.equal(got.detach().permute(1, 0, 2).cpu(), want.detach())
+    np.testing.assert_allclose(xg.grad.permute(1, 0, 2).cpu().numpy(), xr.grad.numpy(), rtol=1e-5, atol=1e-6)
+    # bf16 in/out: f32 arithmetic on the widened values, one rounding on store
+    xb = x.to(torch.bfloat16)
+    wantb = om.max_relative(xb.float(), idx).to(torch.bfloat16)
+    gotb = ops.max_relative(xb.to(dev).permute(1, 0, 2).contiguous(), idx.to(dev), layout="cbn")
+    assert gotb.dtype == torch.bfloat16 and torch.equal(gotb.permute(1, 0, 2).cpu(), wantb)
+
+
+def _bn_ref(x, gamma, beta, rm, rv, training, pb, res, act, slope, eps=1e-5, mom=0.1):
+    import torch.nn.functional as F
+    C = x.shape[0]
+    y = x.reshape(1, C, -1).double()
+    if pb is not None:
+        y = y + pb.double().reshape(1, C, 1)
+    y = F.batch_norm(y, rm, rv, gamma.double(), beta.double(), training, mom, eps).reshape(x.shape)
+    y = F.relu(y) if act == 1 else (F.leaky_relu(y, slope) if act == 2 else y)
+    return y if res is None else y + res.double()
+
+
+@pytest.mark.parametrize("C,M,act,use_pb,use_res,training", [
+    (64, 4 * 1024, 1, True, False, True), (256, 3 * 256, 0, True, True, True), (2048, 2 * 128, 1, False, False, True),
+    (8, 5 * 1024, 2, False, False, True), (16, 1001, 1, True, True, True), (64, 2048, 1, True, True, False),
+    (3, 7, 0, False, True, True)])
+def test_bn_act_forward_backward_f32(dev, C, M, act, use_pb, use_res, training):
+    """Fused [bias]+BatchNorm+act+residual vs torch (float64 reference): forward 2e-5, grads 1e-4 of their max,
+    running statistics 1e-5 -- including rows with |mean| >> std (shifted-sum statistics)."""
+    from grafp_amd import ops
+    x = t(hash_normalish(f"gpu:bn.x.{C}.{M}", (C, M))) * 2.0 + 30.0 * t(hash_uniform(f"gpu:bn.mu.{C}", (C, 1)))
+    gamma = 1.0 + 0.2 * t(hash_uniform(f"gpu:bn.g.{C}", (C,))); beta = 0.3 * t(hash_uniform(f"gpu:bn.b.{C}", (C,)))
+    pb = 0.5 * t(hash_uniform(f"gpu:bn.pb.{C}", (C,))) if use_pb else None
+    res = t(hash_normalish(f"gpu:bn.r.{C}.{M}", (C, M))) if use_res else None
+    rm0 = 0.1 * t(hash_uniform(f"gpu:bn.rm.{C}", (C,))); rv0 = 1.0 + 0.5 * t(hash_uniform(f"gpu:bn.rv.{C}", (C,))).abs()
+    gz = t(hash_normalish(f"gpu:bn.gz.{C}.{M}", (C, M)))
+    # reference (float64 autograd)
+    xr = x.double().requires_grad_(True); gr = gamma.double().requires_grad_(True); br = beta.double().requires_grad_(True)
+    rr = res.double().requires_grad_(True) if use_res else None
+    pr = pb.double().requires_grad_(True) if use_pb else None
+    rm_ref, rv_ref = rm0.double().clone(), rv0.double().clone()
+    want = _bn_ref(xr, gr, br, rm_ref, rv_ref, training, pr, rr, act, 0.2)
+    want.backward(gz.double())
+    # HIP
+    xg = x.to(dev).requires_grad_(True); gg = gamma.to(dev).requires_grad_(True); bg = beta.to(dev).requires_grad_(True)
+    rg = res.to(dev).requires_grad_(True) if use_res else None
+    pg = pb.to(dev).requires_grad_(True) if use_pb else None
+    rm, rv = rm0.to(dev).clone(), rv0.to(dev).clone()
+    got = ops.bn_act(xg, gg, bg, rm, rv, training, 0.1, 1e-5, pg, rg, act, 0.2)
+    got.backward(gz.to(dev))
+    np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().numpy(), rtol=2e-5, atol=2e-5)
+    for a, b in ((xg.grad, xr.grad), (gg.grad, gr.grad), (bg.grad, br.grad)):
+        np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), rtol=1e-4, atol=1e-4 * float(b.abs().max()) + 1e-7)
+    if use_res:
+        assert torch.equal(rg.grad.cpu(), gz)
+    if use_pb:
+        np.testing.assert_allclose(pg.grad.cpu().numpy(), pr.grad.numpy(), rtol=1e-4,
+                                   atol=2e-4 * float(gz.abs().sum(1).max()) if training else 1e-4 * float(pr.grad.abs().max()))
+    np.testing.assert_allclose(rm.cpu().numpy(), rm_ref.numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(rv.cpu().numpy(), rv_ref.numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_bn_act_bf16(dev):
+    """bf16 activations in/out, f32 statistics: equals the f32 computation on the widened inputs up to the final
+    bf16 rounding (1 ulp = 2^-8 relative)."""
+    from grafp_amd import ops
+    C, M = 128, 4096
+    x = t(hash_normalish("gpu:bn16.x", (C, M))).to(torch.bfloat16)
+    res = t(hash_normalish("gpu:bn16.r", (C, M))).to(torch.bfloat16)
+    gamma = 1.0 + 0.2 * t(hash_uniform("gpu:bn16.g", (C,))); beta = 0.3 * t(hash_uniform("gpu:bn16.b", (C,)))
+    want = _bn_ref(x.float(), gamma, beta, None, None, True, None, res.float(), 1, 0.0).float()
+    xg = x.to(dev).requires_grad_(True)
+    got = ops.bn_act(xg, gamma.to(dev), beta.to(dev), None, None, True, residual=res.to(dev), act=1)
+    assert got.dtype == torch.bfloat16
+    np.testing.assert_allclose(got.detach().float().cpu().numpy(), want.numpy(), rtol=2 ** -7, atol=2 ** -7)
+    got.float().sum().backward()
+    assert xg.grad.dtype == torch.bfloat16 and torch.isfinite(xg.grad.float()).all()

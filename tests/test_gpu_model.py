@@ -6,7 +6,8 @@ import numpy as np
 import pytest
 import torch
 
-from _common import RecordedGraphs, filled_state_dict, golden, hash_normalish, simclr_inputs
+from _common import (RecordedGraphs, ReplayGraphs, filled_state_dict, golden, hash_normalish, reference_graphs,
+                     simclr_inputs)
 
 pytestmark = pytest.mark.gpu
 
@@ -58,24 +59,33 @@ def test_simclr_forward_vs_oracle_with_equal_edges(dev):
 
 
 def test_simclr_forward_matches_reference_golden(dev):
-    """The reference's own SimCLR.forward output (tests/golden/simclr_forward.npz, produced on CPU).  A
-    near-tie neighbour flipping between CPU and GPU moves an embedding by ~1e-3, so the bar against the golden
-    is 5e-3 relative L2 per vector (observed: 1e-6 without a flip, 0.7-1.4e-3 with one); the tight bar is the
-    equal-edges test above."""
+    """The reference's own SimCLR.forward output (tests/golden/simclr_forward.npz, produced on CPU) with the
+    reference's edges replayed into the HIP model: 1e-4 relative L2 per vector, train and eval mode.
+    (With its own graphs the random-weight network is chaotic: one near-tie neighbour flipping in block 8 of 12
+    grows to 0.1 at the output -- measured -- so own-graph outputs are only sanity-checked for direction; the
+    k-NN decision itself is verified bit-exactly on identical inputs in test_gpu_kernels.py / smoke().)"""
     g = golden("simclr_forward.npz")
     cfg, model = _filled_model(dev)
     xi, xj = simclr_inputs()
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     model.train()
-    with torch.no_grad():
+    with ReplayGraphs(reference_graphs(sd, xi, xj, True)), torch.no_grad():
         h_i, h_j, z_i, z_j = model(xi.to(dev), xj.to(dev))
     for got, want in ((z_i, g["z_i"]), (z_j, g["z_j"]), (h_i, g["h_i"]), (h_j, g["h_j"])):
-        assert _rel_l2(got, want) <= 5e-3
+        assert _rel_l2(got, want) <= 1e-4
     np.testing.assert_allclose(model.encoder.stem[1].running_mean.cpu().numpy(), g["stem_running_mean"], rtol=1e-5, atol=1e-6)
     model.eval()
-    with torch.no_grad():
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    with ReplayGraphs(reference_graphs(sd, xi, xj, False)), torch.no_grad():
         eh_i, _, ez_i, ez_j = model(xi.to(dev), xj.to(dev))
+    # eval mode runs on the running statistics this model accumulated on the GPU (equal to the reference's only to
+    # rounding), so the replayed graphs can differ from the golden run's by a near-tie: 5e-3 instead of 1e-4
     for got, want in ((ez_i, g["eval_z_i"]), (ez_j, g["eval_z_j"]), (eh_i, g["eval_h_i"])):
         assert _rel_l2(got, want) <= 5e-3
+    with torch.no_grad():                                   # own graphs: direction only
+        _, _, oz_i, oz_j = model(xi.to(dev), xj.to(dev))
+    cos = torch.nn.functional.cosine_similarity(torch.cat([oz_i, oz_j]).cpu(), torch.from_numpy(np.concatenate([g["eval_z_i"], g["eval_z_j"]])))
+    assert float(cos.min()) > 0.97, cos
 
 
 def test_train_step_vs_oracle_with_equal_edges(dev):
@@ -115,29 +125,31 @@ def test_train_step_vs_oracle_with_equal_edges(dev):
 
 
 def test_train_step_matches_reference_golden(dev):
-    """The reference's own train step (golden produced on CPU): loss, gradient norms and post-Adam parameter
-    sums; element-wise gradients to 5% of their max-norm (near-tie flips re-route a few gradient paths)."""
+    """The reference's own train step (golden produced on CPU), reference edges replayed: loss 1e-4, gradient
+    norms 1e-2, two full gradient tensors 2e-2 relative L2, post-Adam parameter sums."""
     from grafp_amd.simclr.ntxent import ntxent_loss
     g = golden("train_step.npz")
     cfg, model = _filled_model(dev)
     model.train()
     opt = torch.optim.Adam(model.parameters(), lr=8e-5)
     xi, xj = simclr_inputs()
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     opt.zero_grad()
-    _, _, z_i, z_j = model(xi.to(dev), xj.to(dev))
+    with ReplayGraphs(reference_graphs(sd, xi, xj, True)):
+        _, _, z_i, z_j = model(xi.to(dev), xj.to(dev))
     loss = ntxent_loss(z_i, z_j, cfg)
     loss.backward()
-    np.testing.assert_allclose(loss.item(), g["loss"], rtol=1e-3)
+    np.testing.assert_allclose(loss.item(), g["loss"], rtol=1e-4)
     probe = [str(p) for p in g["probe"]]
     params = dict(model.named_parameters())
     gn = np.array([params[k].grad.double().norm().item() for k in probe])
-    np.testing.assert_allclose(gn, g["grad_norm"], rtol=2e-2)
+    np.testing.assert_allclose(gn, g["grad_norm"], rtol=1e-2)
     for k in probe[:2]:
         want = g["grad:" + k]
-        assert np.abs(params[k].grad.cpu().numpy() - want).max() <= 0.05 * np.abs(want).max()
+        assert np.linalg.norm(params[k].grad.cpu().numpy() - want) <= 2e-2 * np.linalg.norm(want)
     opt.step()
     # Adam's first step moves every weight by ~lr * sign(grad): entries whose gradient is ~0 can take the other
-    # sign after a near-tie flip, so the sums agree to a few 1e-3 absolute rather than to rounding
+    # sign after a single mask flip, so the sums agree to a few 1e-3 absolute rather than to rounding
     ps = np.array([params[k].detach().double().sum().item() for k in probe])
     np.testing.assert_allclose(ps, g["param_sum_after"], rtol=1e-4, atol=2e-2)
 
@@ -178,13 +190,8 @@ def test_bf16_autocast_mode(dev):
     with RecordedGraphs() as rg, torch.no_grad():
         _, _, z32, _ = model(xi.to(dev), xj.to(dev))
     from grafp_amd import ops
-    it, orig = iter(rg.graphs), ops.knn_graph
-    ops.knn_graph = lambda x, k, normalize=True: next(it).to(x.device)
-    try:
-        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
-            _, _, z16r, _ = model(xi.to(dev), xj.to(dev))
-    finally:
-        ops.knn_graph = orig
+    with ReplayGraphs(rg.graphs), torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        _, _, z16r, _ = model(xi.to(dev), xj.to(dev))
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
         _, _, z16, _ = model(xi.to(dev), xj.to(dev))
     cos_r = torch.nn.functional.cosine_similarity(z32.float(), z16r.float(), dim=1)
@@ -200,10 +207,10 @@ def test_trainer_reduces_loss(dev):
     cfg = load_config(); cfg["bsz_train"] = 16
     torch.manual_seed(0)
     model = build_model(cfg, device=dev)
-    tr = Trainer(cfg, model, dev, lr=1e-3)
+    tr = Trainer(cfg, model, dev, lr=2e-4)
     x_i, x_j = synthetic_batch(16, 5, dev)
-    losses = [float(tr.step(x_i, x_j)) for _ in range(6)]
-    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    losses = [float(tr.step(x_i, x_j)) for _ in range(16)]
+    assert all(np.isfinite(losses)) and np.mean(losses[-4:]) < np.mean(losses[:4]), losses
     ck = tr.checkpoint(1, losses, [])
     assert set(ck) == {"epoch", "loss", "valid_acc", "hit_rate", "state_dict", "optimizer", "scheduler"}
     assert len(ck["state_dict"]) == 443

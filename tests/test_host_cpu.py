@@ -78,55 +78,61 @@ def test_dropin_aliases():
 
 
 def test_dense_helpers_match_conv_library_semantics():
-    """pointwise / strided3 / batchnorm (GEMM formulation) == F.conv2d / BatchNorm2d on (B,C,N,1)."""
-    import torch.nn.functional as F
+    """conv1x1 / conv3_stride2 (single-GEMM formulation on (C,B,N)) == F.conv2d on (B,C,N,1)."""
     from torch import nn
-    from grafp_amd.encoder._dense import batchnorm, pointwise, strided3
+    from grafp_amd.encoder._dense import conv1x1, conv3_stride2, from_cbn, to_cbn
     torch.manual_seed(0)
     x = torch.randn(3, 16, 40)
-    for groups, bias in ((1, True), (4, True), (1, False)):
-        conv = nn.Conv2d(16, 24, 1, groups=groups, bias=bias)
-        np.testing.assert_allclose(pointwise(conv, x).detach().numpy(), conv(x.unsqueeze(-1)).squeeze(-1).detach().numpy(),
+    assert to_cbn(x).shape == (16, 3, 40) and torch.equal(from_cbn(to_cbn(x), x), x)
+    assert from_cbn(to_cbn(x.unsqueeze(-1)), x.unsqueeze(-1)).shape == (3, 16, 40, 1)
+    for groups in (1, 4):
+        conv = nn.Conv2d(16, 24, 1, groups=groups, bias=False)
+        got = from_cbn(conv1x1(conv, to_cbn(x)), x)
+        np.testing.assert_allclose(got.detach().numpy(), conv(x.unsqueeze(-1)).squeeze(-1).detach().numpy(),
                                    rtol=1e-5, atol=1e-5)
     for n in (40, 41):
         xs = torch.randn(2, 16, n)
-        down = nn.Conv2d(16, 32, 3, stride=2, padding=1)
-        np.testing.assert_allclose(strided3(down, xs).detach().numpy(), down(xs.unsqueeze(-1)).squeeze(-1).detach().numpy(),
+        down = nn.Conv2d(16, 32, 3, stride=2, padding=1, bias=False)
+        got = from_cbn(conv3_stride2(down, to_cbn(xs)), xs)
+        np.testing.assert_allclose(got.detach().numpy(), down(xs.unsqueeze(-1)).squeeze(-1).detach().numpy(),
                                    rtol=1e-5, atol=1e-5)
-    bn_a, bn_b = nn.BatchNorm2d(16), nn.BatchNorm2d(16)
-    for train in (True, False):
-        bn_a.train(train); bn_b.train(train)
-        np.testing.assert_allclose(batchnorm(bn_a, x).detach().numpy(), bn_b(x.unsqueeze(-1)).squeeze(-1).detach().numpy(),
-                                   rtol=1e-5, atol=1e-6)
-    np.testing.assert_allclose(bn_a.running_var.numpy(), bn_b.running_var.numpy(), rtol=1e-6)
-    assert int(bn_a.num_batches_tracked) == 1
 
 
 def test_dense_part_of_the_model_matches_the_oracle_on_cpu():
-    """With the HIP ops swapped for the oracle's (TEST-ONLY monkeypatch) the module mirror reproduces the
-    oracle's forward: pins the GEMM/BN/residual wiring and the state-dict mapping without a GPU."""
-    from grafp_amd import ops
+    """With the HIP ops swapped for torch/oracle equivalents (TEST-ONLY, _common.CpuOps) the module mirror
+    reproduces the oracle's forward AND backward: pins the GEMM / fused-BN / residual wiring, the (C,B,N) layout
+    handling and the state-dict mapping without a GPU."""
+    from _common import CpuOps, simclr_inputs
     from oracle import model as om
     cfg, model = _model()
     filled = filled_state_dict()
     sd = model.state_dict(); sd.update(filled); model.load_state_dict(sd)
-    saved = (ops.knn_graph, ops.max_relative, ops.peak_extract)
-    ops.knn_graph = lambda x, k, normalize=True: om.knn_graph_torch(x.squeeze(-1) if x.dim() == 4 else x, k)
-    ops.max_relative = om.max_relative
-    ops.peak_extract = lambda spec, w, b, s: om.peak_extract(
-        {"peak_extractor.convs.0.weight": w, "peak_extractor.convs.0.bias": b}, spec, s)
-    try:
-        from _common import simclr_inputs
-        xi, xj = simclr_inputs()
+    xi, xj = simclr_inputs()
+    with CpuOps():
         model.train()
-        with torch.no_grad():
-            h_i, h_j, z_i, z_j = model(xi, xj)
-            o = om.simclr_forward({k: v.clone() for k, v in filled.items()}, xi, xj, True)
-        np.testing.assert_allclose(z_i.numpy(), o[2].numpy(), rtol=1e-3, atol=1e-5)
-        np.testing.assert_allclose(z_j.numpy(), o[3].numpy(), rtol=1e-3, atol=1e-5)
-        np.testing.assert_allclose(h_i.numpy(), o[0].numpy(), rtol=1e-3, atol=1e-4)
-    finally:
-        ops.knn_graph, ops.max_relative, ops.peak_extract = saved
+        h_i, h_j, z_i, z_j = model(xi, xj)
+        loss = om.ntxent(z_i, z_j, 0.05)
+        loss.backward()
+    osd = {k: v.clone() for k, v in filled.items()}
+    for k, v in osd.items():
+        if v.is_floating_point() and k.rsplit(".", 1)[-1] not in ("running_mean", "running_var"):
+            v.requires_grad_(True)
+    o = om.simclr_forward(osd, xi, xj, True)
+    oloss = om.ntxent(o[2], o[3], 0.05)
+    oloss.backward()
+    np.testing.assert_allclose(z_i.detach().numpy(), o[2].detach().numpy(), rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(z_j.detach().numpy(), o[3].detach().numpy(), rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(h_i.detach().numpy(), o[0].detach().numpy(), rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(loss.item(), oloss.item(), rtol=1e-5)
+    sdm = model.state_dict()
+    for k in ("encoder.stem.1.running_mean", "encoder.backbone.7.1.fc1.1.running_var", "encoder.backbone.3.0.fc2.1.running_mean"):
+        np.testing.assert_allclose(sdm[k].numpy(), osd[k].detach().numpy(), rtol=1e-4, atol=1e-6)
+    assert int(sdm["encoder.stem.1.num_batches_tracked"]) == 2
+    P = dict(model.named_parameters())
+    gn = max(float(osd[k].grad.norm()) for k in P if P[k].requires_grad)
+    rel = [float((P[k].grad - osd[k].grad).norm()) / max(float(osd[k].grad.norm()), 1e-4 * gn)
+           for k in P if P[k].requires_grad]
+    assert max(rel) < 5e-2 and np.median(rel) < 5e-3, (max(rel), np.median(rel))
 
 
 def test_sequence_rerank_matches_oracle():
