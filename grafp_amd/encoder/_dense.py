@@ -39,12 +39,7 @@ def conv1x1(conv, x):
     for the grouped conv of the max-relative block)."""
     cin, B, N = x.shape
     cout, g = conv.out_channels, conv.groups
-    w = conv.weight.reshape(cout, cin // g)
-    if g == 1:
-        y = torch.mm(w, x.reshape(cin, B * N))
-    else:
-        y = torch.bmm(w.reshape(g, cout // g, cin // g), x.reshape(g, cin // g, B * N))
-    return y.reshape(cout, B, N)
+    return ops.conv1x1_rows(x.reshape(cin, B * N), conv.weight.reshape(cout, cin // g), g).reshape(cout, B, N)
 
 
 def conv3_stride2(conv, x):
@@ -58,7 +53,7 @@ def conv3_stride2(conv, x):
     xp = F.pad(x, (1, 1))
     taps = torch.cat([xp[:, :, t:t + 2 * n_out - 1:2] for t in range(3)], dim=0)       # (3Cin, B, n_out)
     w = conv.weight[:, :, :, 1].permute(0, 2, 1).reshape(cout, 3 * cin)                 # [o][t*Cin + c]
-    return torch.mm(w, taps.reshape(3 * cin, B * n_out)).reshape(cout, B, n_out)
+    return ops.conv1x1_rows(taps.reshape(3 * cin, B * n_out), w).reshape(cout, B, n_out)
 
 
 def bn_act(bn, y, pre_bias=None, residual=None, act=ops.ACT_NONE, slope=0.0):

@@ -346,6 +346,62 @@ def bn_act(x, gamma, beta, running_mean, running_var, training, momentum=0.1, ep
 
 
 # ------------------------------------------------------------------------------------------------
+# K9  1x1 convolution on (C, M) rows: library GEMMs forward / input-gradient, hand-written weight gradient
+# ------------------------------------------------------------------------------------------------
+def _block_diag_weight(w, groups):
+    """(Cout, Cin/g) grouped weight -> dense block-diagonal (Cout, Cin): for the small groups of the max-relative
+    conv one dense GEMM (memory-bound either way) beats a 4-batch GEMM of 32x32 problems."""
+    cout, cin_g = w.shape
+    return torch.block_diag(*w.reshape(groups, cout // groups, cin_g).unbind(0))
+
+
+class _Conv1x1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, groups):
+        """x (Cin, M) f32/bf16 rows, w (Cout, Cin/groups) parameter view -> (Cout, M) in x's dtype."""
+        x = x.detach()
+        wl = w.detach().to(x.dtype)
+        dense = _block_diag_weight(wl, groups) if groups > 1 else wl
+        y = torch.mm(dense, x)
+        ctx.save_for_backward(x, dense)
+        ctx.groups, ctx.wshape = groups, tuple(w.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, dense = ctx.saved_tensors
+        groups = ctx.groups
+        cout, cin_g = ctx.wshape
+        g = g.detach().to(x.dtype).contiguous()
+        dx = torch.mm(dense.t(), g) if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            cin, M = x.shape
+            if x.dtype == torch.bfloat16 and x.is_cuda:
+                dw = torch.empty((cout, cin_g), dtype=torch.float32, device=x.device)
+                nbytes = lib.grafp_conv1x1_wgrad_workspace(cout, cin, groups, M)
+                ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
+                with _timed("conv1x1_wgrad", (cout, cin, groups, M)):
+                    check(lib.grafp_conv1x1_wgrad_bf16(_p(g), _p(x), cout, cin, groups, M, _p(dw), _p(ws), nbytes,
+                                                       _stream()), "conv1x1_wgrad")
+            elif groups == 1:
+                dw = torch.mm(g, x.t()).float()
+            else:
+                dw = torch.bmm(g.reshape(groups, cout // groups, M), x.reshape(groups, cin_g, M).transpose(1, 2))
+                dw = dw.reshape(cout, cin_g).float()
+        return dx, dw, None
+
+
+def conv1x1_rows(x, w, groups=1):
+    """y = W x over (C, M) rows (x contiguous 2-D).  Under autocast f32 inputs are lowered to the autocast dtype
+    (the rest of a block already flows in it); the weight gradient of bf16 operands is the hand-written split-K
+    kernel (grafp_conv1x1_wgrad_bf16), everything else a plain library GEMM."""
+    if torch.is_autocast_enabled() and x.is_cuda and x.dtype == torch.float32:
+        x = x.to(torch.get_autocast_gpu_dtype())
+    return _Conv1x1.apply(x.contiguous(), w, groups)
+
+
+# ------------------------------------------------------------------------------------------------
 # K12  NT-Xent
 # ------------------------------------------------------------------------------------------------
 class _NTXent(torch.autograd.Function):

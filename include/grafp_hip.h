@@ -142,6 +142,17 @@ int grafp_bn_bwd(const void *x, const void *dz, int dtype, int C, int64_t M, con
                  int training, void *dx, float *dgamma, float *dbeta, void *ws, size_t ws_bytes,
                  grafp_stream_t stream);
 
+/* ---- K9 backward: weight gradient of a 1x1 convolution on the (C, M) layout ------------------------------
+ * dW[o][c] = sum_m grad_out[o][m] * x[c][m] for every 1x1 Conv2d of the encoder (torch_vertex.py:152-162,
+ * torch_nn.py:56, graph_encoder.py:52-55,131): tiny output, contraction over M = B*N with both operands contiguous
+ * along it -- a split-K streaming reduction on bf16 MFMA instead of a library GEMM.
+ *   grad_out (Cout, M) bf16, x (Cin, M) bf16, rows contiguous, 16-byte aligned; dweight (Cout, Cin/groups) f32
+ *   (the Conv2d weight layout; group g owns output rows [g*Cout/groups, (g+1)*Cout/groups) and the matching
+ *   input rows). */
+size_t grafp_conv1x1_wgrad_workspace(int Cout, int Cin, int groups, int64_t M);
+int grafp_conv1x1_wgrad_bf16(const void *grad_out, const void *x, int Cout, int Cin, int groups, int64_t M,
+                             float *dweight, void *ws, size_t ws_bytes, grafp_stream_t stream);
+
 /* ---- K12: NT-Xent loss, fused forward + backward ----------------------------------------------
  * Replaces ntxent_loss (simclr/ntxent.py:4-29; called train.py:71).  Rows of the similarity matrix
  * are the 2*B_all embeddings (view i then view j; the loss is invariant to the reference's

@@ -417,3 +417,25 @@ def test_bn_act_bf16(dev):
     np.testing.assert_allclose(got.detach().float().cpu().numpy(), want.numpy(), rtol=2 ** -7, atol=2 ** -7)
     got.float().sum().backward()
     assert xg.grad.dtype == torch.bfloat16 and torch.isfinite(xg.grad.float()).all()
+
+
+@pytest.mark.parametrize("cout,cin,groups,M", [(64, 64, 1, 8192), (256, 64, 1, 4096), (64, 128, 1, 3000), (128, 128, 4, 8192),
+                                                (512, 128, 1, 2048), (40, 24, 1, 777), (96, 192, 4, 1000)])
+def test_conv1x1_wgrad_bf16(dev, cout, cin, groups, M):
+    """Split-K weight gradient vs a float64 product of the same bf16 operands: 2e-3 of the largest entry (f32
+    accumulation of bf16 products in a different order)."""
+    from grafp_amd import ops
+    x = t(hash_normalish(f"gpu:wg.x.{cin}.{M}", (cin, M))).to(torch.bfloat16)
+    w = t(0.1 * hash_normalish(f"gpu:wg.w.{cout}.{cin}", (cout, cin // groups)))
+    g = t(hash_normalish(f"gpu:wg.g.{cout}.{M}", (cout, M))).to(torch.bfloat16)
+    xg = x.to(dev).requires_grad_(True); wg = w.to(dev).requires_grad_(True)
+    y = ops.conv1x1_rows(xg, wg, groups)
+    y.backward(g.to(dev))
+    xd, gd = x.double(), g.double()
+    want = torch.cat([gd.reshape(groups, cout // groups, M)[i] @ xd.reshape(groups, cin // groups, M)[i].t()
+                      for i in range(groups)], dim=0)
+    assert wg.grad.shape == (cout, cin // groups) and wg.grad.dtype == torch.float32
+    np.testing.assert_allclose(wg.grad.cpu().numpy(), want.numpy(), rtol=1e-3, atol=2e-3 * float(want.abs().max()))
+    dense = torch.block_diag(*w.to(torch.bfloat16).double().reshape(groups, cout // groups, cin // groups).unbind(0))
+    np.testing.assert_allclose(y.detach().float().cpu().numpy(), (dense @ xd).numpy(), rtol=2e-2, atol=2e-2)
+    np.testing.assert_allclose(xg.grad.float().cpu().numpy(), (dense.t() @ gd).numpy(), rtol=2e-2, atol=3e-2)
