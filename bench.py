@@ -46,12 +46,12 @@ def knn_flops(meta):
     return 2.0 * N * N * C * B
 
 
-def mrconv_bytes(meta, backward=False):
+def mrconv_bytes(meta, esize):
     B, C, N, K = meta
-    return (4.0 * C * N + 8.0 * K * N + 8.0 * C * N) * B      # x + idx + interleaved (B,2C,N); bwd same order
+    return (esize * C * N + 8.0 * K * N + 2.0 * esize * C * N) * B   # x + idx + interleaved (2C rows); bwd same order
 
 
-def summarise_kernels(timed):
+def summarise_kernels(timed, esize=4):
     """name -> dict(calls, total_ms, avg_us, achieved, unit, peak, frac, bound) from HIP-event records."""
     from grafp_amd import ops
     out = {}
@@ -66,7 +66,15 @@ def summarise_kernels(timed):
             row.update(bound="mfma", achieved=round(fl / (tot * 1e-3) / 1e12, 3), unit="TFLOP/s",
                        peak=PEAK_F32_MATRIX_TFLOPS)
         elif name in ("mrconv_fwd", "mrconv_bwd"):
-            by = sum(mrconv_bytes(m) for _, _, m in ev)
+            by = sum(mrconv_bytes(m, esize) for _, _, m in ev)
+            row.update(bound="hbm", achieved=round(by / (tot * 1e-3) / 1e9, 1), unit="GB/s", peak=PEAK_HBM_GBS)
+        elif name in ("bn_fwd", "bn_bwd"):
+            # fwd: stats read + apply read + write (+ residual read, not counted); bwd: 2 x (x, dz) reads + dx write
+            per = 3.0 if name == "bn_fwd" else 5.0
+            by = sum(per * C * M * e for _, _, (C, M, e) in ev)
+            row.update(bound="hbm", achieved=round(by / (tot * 1e-3) / 1e9, 1), unit="GB/s", peak=PEAK_HBM_GBS)
+        elif name == "conv1x1_wgrad":
+            by = sum((co + ci) * M * 2.0 for _, _, (co, ci, g, M) in ev)
             row.update(bound="hbm", achieved=round(by / (tot * 1e-3) / 1e9, 1), unit="GB/s", peak=PEAK_HBM_GBS)
         elif name == "logmel":
             by = sum(B * (4.0 * T + 4.0 * 64 * (1 + T // 512)) for _, _, (B, T) in ev)
@@ -173,15 +181,15 @@ def main():
     for _ in range(args.warmup):
         trainer.step(x_i, x_j)
     barrier()
-    names = ("knn_topk", "knn_normalize", "mrconv_fwd", "mrconv_bwd", "ntxent", "logmel", "peak_extract_fwd",
-             "peak_extract_bwd")
+    names = ("knn_topk", "knn_normalize", "mrconv_fwd", "mrconv_bwd", "bn_fwd", "bn_bwd", "conv1x1_wgrad", "ntxent",
+             "logmel", "peak_extract_fwd", "peak_extract_bwd")
     with ops.time_kernels(*names) as timed:
         t0 = time.perf_counter()
         for _ in range(args.steps):
             loss = trainer.step(x_i, x_j)
         barrier()
         elapsed = time.perf_counter() - t0
-        kernels = summarise_kernels(timed)
+        kernels = summarise_kernels(timed, 2 if args.dtype == "bf16" else 4)
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -33,40 +33,47 @@ __device__ __forceinline__ void mr_st(unsigned short *p, float v) {
     *p = (unsigned short)(u >> 16);
 }
 
+// 4-wide access (16 B of f32 / 8 B of bf16); callers guarantee 4-element alignment of the address
+__device__ __forceinline__ void mr_ld4(const float *p, float (&v)[4]) {
+    const float4 t = *reinterpret_cast<const float4 *>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+__device__ __forceinline__ void mr_ld4(const unsigned short *p, float (&v)[4]) {
+    const uint2 t = *reinterpret_cast<const uint2 *>(p);
+    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+}
+__device__ __forceinline__ unsigned mr_pack(float lo, float hi) {
+    unsigned short a, b;
+    mr_st(&a, lo); mr_st(&b, hi);
+    return (unsigned)a | ((unsigned)b << 16);
+}
+__device__ __forceinline__ void mr_st4(float *p, const float (&v)[4]) {
+    *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void mr_st4(unsigned short *p, const float (&v)[4]) {
+    *reinterpret_cast<uint2 *>(p) = make_uint2(mr_pack(v[0], v[1]), mr_pack(v[2], v[3]));
+}
+
 // Activations are addressed as base + b*sb + c*sc + n (N contiguous): (B,C,N) has sb = C*N, sc = N; the
-// GEMM-friendly (C,B,N) has sb = N, sc = B*N.  dynamic LDS: rows[CC*N] f32 | (bwd: acc[CC*N] f32) | sidx[K*N] i32
-template <typename T>
-__device__ __forceinline__ void stage_rows(float *dst, const T *__restrict__ src, int64_t sc, int cc, int N, int tid) {
-    for (int i = tid; i < cc * N; i += MR_THREADS) {
-        const int c = i / N, n = i - c * N;
-        dst[i] = mr_ld(src + (size_t)c * sc + n);
-    }
-}
-template <>
-__device__ __forceinline__ void stage_rows<float>(float *dst, const float *__restrict__ src, int64_t sc, int cc, int N,
-                                                  int tid) {
-    if ((N & 3) == 0 && (sc & 3) == 0 && (((uintptr_t)src) & 15) == 0) {
-        const int n4 = N >> 2;
-        for (int i = tid; i < cc * n4; i += MR_THREADS) {
-            const int c = i / n4, j = i - c * n4;
-            reinterpret_cast<float4 *>(dst)[i] = reinterpret_cast<const float4 *>(src + (size_t)c * sc)[j];
-        }
-    } else {
-        for (int i = tid; i < cc * N; i += MR_THREADS) {
-            const int c = i / N, n = i - c * N;
-            dst[i] = src[(size_t)c * sc + n];
-        }
-    }
-}
+// GEMM-friendly (C,B,N) has sb = N, sc = B*N.  dynamic LDS: rows[CC*N] f32 | (bwd: acc[CC*N] f32) | sidx[K*N] i32.
+// A workgroup owns CC channel rows of one clip; thread t walks the slab's elements t*V, t*V + 256*V, ... as a
+// running (channel, node) pair -- no integer division in any loop.  V = 4 when N % 4 == 0 and the strides and
+// base pointers are 4-element aligned (always true for the encoder's shapes), else 1.
+#define MR_WALK(V, tid, N, c, n)                    \
+    int c = ((tid) * (V)) / (N), n = ((tid) * (V)) - c * (N)
+#define MR_NEXT(V, N, c, n)                         \
+    do {                                            \
+        n += MR_THREADS * (V);                      \
+        while (n >= (N)) { n -= (N); ++c; }         \
+    } while (0)
 
 __device__ __forceinline__ void stage_idx(int *sidx, const int64_t *__restrict__ idxb, int N, int K, int tid) {
-    for (int i = tid; i < N * K; i += MR_THREADS) {
-        const int n = i / K, k = i - n * K;
-        sidx[k * N + n] = clampi(idxb[i], N);
-    }
+    for (int n = tid; n < N; n += MR_THREADS)
+        for (int k = 0; k < K; ++k) sidx[k * N + n] = clampi(idxb[(size_t)n * K + k], N);
 }
 
-template <typename T>
+template <typename T, int V>
 __global__ __launch_bounds__(MR_THREADS) void mrconv_fwd_kernel(const T *__restrict__ x, int64_t x_sb, int64_t x_sc,
                                                                 const int64_t *__restrict__ idx, T *__restrict__ out,
                                                                 int64_t o_sb, int64_t o_sc, int C, int N, int K,
@@ -76,26 +83,49 @@ __global__ __launch_bounds__(MR_THREADS) void mrconv_fwd_kernel(const T *__restr
     const int cc = min(CC, C - c0);
     float *rows = reinterpret_cast<float *>(smem);
     int *sidx = reinterpret_cast<int *>(rows + (size_t)CC * N);
-    stage_rows<T>(rows, x + (size_t)b * x_sb + (size_t)c0 * x_sc, x_sc, cc, N, tid);
+    const T *xb = x + (size_t)b * x_sb + (size_t)c0 * x_sc;
+    {
+        MR_WALK(V, tid, N, c, n);
+        while (c < cc) {
+            float v[4];
+            if (V == 4) mr_ld4(xb + (size_t)c * x_sc + n, v); else v[0] = mr_ld(xb + (size_t)c * x_sc + n);
+#pragma unroll
+            for (int e = 0; e < V; ++e) rows[c * N + n + e] = v[e];
+            MR_NEXT(V, N, c, n);
+        }
+    }
     stage_idx(sidx, idx + (size_t)b * N * K, N, K, tid);
     __syncthreads();
 
     T *ob = out + (size_t)b * o_sb + (size_t)(2 * c0) * o_sc;
-    int c = 0, n = tid;
-    while (n >= N) { n -= N; ++c; }
+    MR_WALK(V, tid, N, c, n);
     while (c < cc) {
         const float *row = rows + c * N;
-        const float xi = row[n];
-        float m = -INFINITY;
-        for (int k = 0; k < K; ++k) m = fmaxf(m, row[sidx[k * N + n]] - xi);
-        mr_st(ob + (size_t)(2 * c) * o_sc + n, xi);
-        mr_st(ob + (size_t)(2 * c + 1) * o_sc + n, m);
-        n += MR_THREADS;
-        while (n >= N) { n -= N; ++c; }
+        float xi[4], m[4];
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            xi[e] = row[n + e];
+            m[e] = -INFINITY;
+        }
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int e = 0; e < V; ++e) m[e] = fmaxf(m[e], row[sidx[k * N + n + e]] - xi[e]);
+        if (V == 4) {
+            mr_st4(ob + (size_t)(2 * c) * o_sc + n, xi);
+            mr_st4(ob + (size_t)(2 * c + 1) * o_sc + n, m);
+        } else {
+            mr_st(ob + (size_t)(2 * c) * o_sc + n, xi[0]);
+            mr_st(ob + (size_t)(2 * c + 1) * o_sc + n, m[0]);
+        }
+        MR_NEXT(V, N, c, n);
     }
 }
 
-template <typename T>
+// BWD_ITEMS * 256 * V elements per workgroup: the odd-channel gradients stay in registers between the
+// accumulator initialisation and the scatter phase.
+constexpr int BWD_ITEMS = 4;
+
+template <typename T, int V>
 __global__ __launch_bounds__(MR_THREADS) void mrconv_bwd_kernel(const T *__restrict__ x, int64_t x_sb, int64_t x_sc,
                                                                 const int64_t *__restrict__ idx,
                                                                 const T *__restrict__ gout, int64_t g_sb, int64_t g_sc,
@@ -106,42 +136,70 @@ __global__ __launch_bounds__(MR_THREADS) void mrconv_bwd_kernel(const T *__restr
     float *rows = reinterpret_cast<float *>(smem);
     float *acc = rows + (size_t)CC * N;
     int *sidx = reinterpret_cast<int *>(acc + (size_t)CC * N);
-    stage_rows<T>(rows, x + (size_t)b * x_sb + (size_t)c0 * x_sc, x_sc, cc, N, tid);
-    stage_idx(sidx, idx + (size_t)b * N * K, N, K, tid);
+    const T *xb = x + (size_t)b * x_sb + (size_t)c0 * x_sc;
     const T *gb = gout + (size_t)b * g_sb + (size_t)(2 * c0) * g_sc;
-    {   // acc <- g_even - g_odd  (identity branch, minus the centre term of every relative difference)
-        int c = 0, n = tid;
-        while (n >= N) { n -= N; ++c; }
-        while (c < cc) {
-            acc[c * N + n] = mr_ld(gb + (size_t)(2 * c) * g_sc + n) - mr_ld(gb + (size_t)(2 * c + 1) * g_sc + n);
-            n += MR_THREADS;
-            while (n >= N) { n -= N; ++c; }
+    float godd[BWD_ITEMS][4];
+    {   // stage x; acc <- g_even - g_odd (identity branch minus the centre term of every relative difference)
+        MR_WALK(V, tid, N, c, n);
+#pragma unroll
+        for (int it = 0; it < BWD_ITEMS; ++it) {
+            if (c < cc) {
+                float v[4], ge[4];
+                if (V == 4) {
+                    mr_ld4(xb + (size_t)c * x_sc + n, v);
+                    mr_ld4(gb + (size_t)(2 * c) * g_sc + n, ge);
+                    mr_ld4(gb + (size_t)(2 * c + 1) * g_sc + n, godd[it]);
+                } else {
+                    v[0] = mr_ld(xb + (size_t)c * x_sc + n);
+                    ge[0] = mr_ld(gb + (size_t)(2 * c) * g_sc + n);
+                    godd[it][0] = mr_ld(gb + (size_t)(2 * c + 1) * g_sc + n);
+                }
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    rows[c * N + n + e] = v[e];
+                    acc[c * N + n + e] = ge[e] - godd[it][e];
+                }
+            }
+            MR_NEXT(V, N, c, n);
         }
     }
+    stage_idx(sidx, idx + (size_t)b * N * K, N, K, tid);
     __syncthreads();
     {   // route g_odd[c][m] to the arg-max neighbour of m (first maximum)
-        int c = 0, n = tid;
-        while (n >= N) { n -= N; ++c; }
-        while (c < cc) {
-            const float *row = rows + c * N;
-            const float xi = row[n];
-            float best = -INFINITY;
-            int bj = sidx[n];
-            for (int k = 0; k < K; ++k) {
-                const int j = sidx[k * N + n];
-                const float v = row[j] - xi;
-                if (v > best) { best = v; bj = j; }
+        MR_WALK(V, tid, N, c, n);
+#pragma unroll
+        for (int it = 0; it < BWD_ITEMS; ++it) {
+            if (c < cc) {
+                const float *row = rows + c * N;
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    const float xi = row[n + e];
+                    float best = -INFINITY;
+                    int bj = sidx[n + e];
+                    for (int k = 0; k < K; ++k) {
+                        const int j = sidx[k * N + n + e];
+                        const float v = row[j] - xi;
+                        if (v > best) { best = v; bj = j; }
+                    }
+                    atomicAdd(&acc[c * N + bj], godd[it][e]);
+                }
             }
-            atomicAdd(&acc[c * N + bj], mr_ld(gb + (size_t)(2 * c + 1) * g_sc + n));
-            n += MR_THREADS;
-            while (n >= N) { n -= N; ++c; }
+            MR_NEXT(V, N, c, n);
         }
     }
     __syncthreads();
     T *db = dx + (size_t)b * x_sb + (size_t)c0 * x_sc;
-    for (int i = tid; i < cc * N; i += MR_THREADS) {
-        const int c = i / N, n = i - c * N;
-        mr_st(db + (size_t)c * x_sc + n, acc[i]);
+    MR_WALK(V, tid, N, c, n);
+    while (c < cc) {
+        if (V == 4) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[c * N + n + e];
+            mr_st4(db + (size_t)c * x_sc + n, v);
+        } else {
+            mr_st(db + (size_t)c * x_sc + n, acc[c * N + n]);
+        }
+        MR_NEXT(V, N, c, n);
     }
 }
 
@@ -161,19 +219,21 @@ extern "C" int grafp_mrconv_fwd_strided(const void *x, int dtype, int64_t x_sb, 
     GRAFP_REQUIRE(x && idx && out, "mrconv_fwd: null pointer");
     GRAFP_REQUIRE(B > 0 && C > 0 && N > 0 && K > 0, "mrconv_fwd: bad shape B=%d C=%d N=%d K=%d", B, C, N, K);
     GRAFP_REQUIRE(dtype == GRAFP_F32 || dtype == GRAFP_BF16, "mrconv_fwd: dtype %d not in {f32, bf16}", dtype);
-    const int CC = pick_cc(C, N, 8192);
+    const int CC = pick_cc(C, N, 16384);
     const size_t lds = ((size_t)CC * N + (size_t)K * N) * 4;
     GRAFP_REQUIRE(lds <= 160 * 1024, "mrconv_fwd: N=%d K=%d needs %zu B of LDS (> 160 KiB)", N, K, lds);
     const dim3 grid((C + CC - 1) / CC, B);
-    if (dtype == GRAFP_F32) {
-        (void)hipFuncSetAttribute((const void *)mrconv_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(mrconv_fwd_kernel<float>, grid, dim3(MR_THREADS), lds, (hipStream_t)stream, (const float *)x,
-                           x_sb, x_sc, idx, (float *)out, o_sb, o_sc, C, N, K, CC);
-    } else {
-        (void)hipFuncSetAttribute((const void *)mrconv_fwd_kernel<unsigned short>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(mrconv_fwd_kernel<unsigned short>, grid, dim3(MR_THREADS), lds, (hipStream_t)stream,
-                           (const unsigned short *)x, x_sb, x_sc, idx, (unsigned short *)out, o_sb, o_sc, C, N, K, CC);
-    }
+    const size_t es = dtype == GRAFP_F32 ? 4 : 2;
+    const bool v4 = (N % 4 == 0) && (x_sb % 4 == 0) && (x_sc % 4 == 0) && (o_sb % 4 == 0) && (o_sc % 4 == 0) &&
+                    ((uintptr_t)x % (4 * es) == 0) && ((uintptr_t)out % (4 * es) == 0);
+#define MR_FWD(T, V)                                                                                                   \
+    (void)hipFuncSetAttribute((const void *)mrconv_fwd_kernel<T, V>, hipFuncAttributeMaxDynamicSharedMemorySize,       \
+                              (int)lds);                                                                               \
+    hipLaunchKernelGGL((mrconv_fwd_kernel<T, V>), grid, dim3(MR_THREADS), lds, (hipStream_t)stream, (const T *)x, x_sb,  \
+                       x_sc, idx, (T *)out, o_sb, o_sc, C, N, K, CC)
+    if (dtype == GRAFP_F32) { if (v4) { MR_FWD(float, 4); } else { MR_FWD(float, 1); } }
+    else { if (v4) { MR_FWD(unsigned short, 4); } else { MR_FWD(unsigned short, 1); } }
+#undef MR_FWD
     GRAFP_CHECK_LAUNCH("mrconv_fwd_kernel");
     return GRAFP_OK;
 }
@@ -185,20 +245,26 @@ extern "C" int grafp_mrconv_bwd_strided(const void *x, int dtype, int64_t x_sb, 
     GRAFP_REQUIRE(x && idx && grad_out && dx, "mrconv_bwd: null pointer");
     GRAFP_REQUIRE(B > 0 && C > 0 && N > 0 && K > 0, "mrconv_bwd: bad shape B=%d C=%d N=%d K=%d", B, C, N, K);
     GRAFP_REQUIRE(dtype == GRAFP_F32 || dtype == GRAFP_BF16, "mrconv_bwd: dtype %d not in {f32, bf16}", dtype);
-    const int CC = pick_cc(C, N, 4096);
+    const size_t es = dtype == GRAFP_F32 ? 4 : 2;
+    const bool v4 = (N % 4 == 0) && (x_sb % 4 == 0) && (x_sc % 4 == 0) && (g_sb % 4 == 0) && (g_sc % 4 == 0) &&
+                    ((uintptr_t)x % (4 * es) == 0) && ((uintptr_t)grad_out % (4 * es) == 0) && ((uintptr_t)dx % (4 * es) == 0);
+    // a workgroup covers exactly BWD_ITEMS * 256 * V elements (whole channel rows)
+    int CC = (BWD_ITEMS * MR_THREADS * (v4 ? 4 : 1)) / N;
+    if (CC < 1) CC = 1;
+    if (CC > C) CC = C;
+    GRAFP_REQUIRE((size_t)CC * N <= (size_t)BWD_ITEMS * MR_THREADS * (v4 ? 4 : 1),
+                  "mrconv_bwd: N=%d exceeds the %d nodes a workgroup covers", N, BWD_ITEMS * MR_THREADS * (v4 ? 4 : 1));
     const size_t lds = ((size_t)2 * CC * N + (size_t)K * N) * 4;
     GRAFP_REQUIRE(lds <= 160 * 1024, "mrconv_bwd: N=%d K=%d needs %zu B of LDS (> 160 KiB)", N, K, lds);
     const dim3 grid((C + CC - 1) / CC, B);
-    if (dtype == GRAFP_F32) {
-        (void)hipFuncSetAttribute((const void *)mrconv_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(mrconv_bwd_kernel<float>, grid, dim3(MR_THREADS), lds, (hipStream_t)stream, (const float *)x,
-                           x_sb, x_sc, idx, (const float *)grad_out, g_sb, g_sc, (float *)dx, C, N, K, CC);
-    } else {
-        (void)hipFuncSetAttribute((const void *)mrconv_bwd_kernel<unsigned short>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(mrconv_bwd_kernel<unsigned short>, grid, dim3(MR_THREADS), lds, (hipStream_t)stream,
-                           (const unsigned short *)x, x_sb, x_sc, idx, (const unsigned short *)grad_out, g_sb, g_sc,
-                           (unsigned short *)dx, C, N, K, CC);
-    }
+#define MR_BWD(T, V)                                                                                                   \
+    (void)hipFuncSetAttribute((const void *)mrconv_bwd_kernel<T, V>, hipFuncAttributeMaxDynamicSharedMemorySize,       \
+                              (int)lds);                                                                               \
+    hipLaunchKernelGGL((mrconv_bwd_kernel<T, V>), grid, dim3(MR_THREADS), lds, (hipStream_t)stream, (const T *)x, x_sb,  \
+                       x_sc, idx, (const T *)grad_out, g_sb, g_sc, (T *)dx, C, N, K, CC)
+    if (dtype == GRAFP_F32) { if (v4) { MR_BWD(float, 4); } else { MR_BWD(float, 1); } }
+    else { if (v4) { MR_BWD(unsigned short, 4); } else { MR_BWD(unsigned short, 1); } }
+#undef MR_BWD
     GRAFP_CHECK_LAUNCH("mrconv_bwd_kernel");
     return GRAFP_OK;
 }

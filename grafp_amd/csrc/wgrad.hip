@@ -18,35 +18,43 @@ namespace grafp {
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int WG_T = 64;                 // output tile edge
 constexpr int WG_KC = 128;               // contraction columns per LDS chunk
 constexpr int WG_LS = WG_KC * 2 + 16;    // LDS row stride in bytes (272: ds_read_b128 rows land on distinct bank quads)
 
+// TW = output tile edge per workgroup (64: one 32x32 MFMA tile per wave; 128: 2x2 tiles per wave, which halves
+// the re-reads of the smaller operand for the large outputs).
+template <int TW>
 __global__ __launch_bounds__(256) void wgrad_partial_kernel(const unsigned short *__restrict__ G,
                                                             const unsigned short *__restrict__ X, int64_t M,
                                                             int cout_g, int cin_g, int tiles_c, int64_t cols_per_split,
                                                             float *__restrict__ part) {
-    __shared__ __attribute__((aligned(16))) unsigned char sG[WG_T * WG_LS];
-    __shared__ __attribute__((aligned(16))) unsigned char sX[WG_T * WG_LS];
+    constexpr int Q = TW / 2;        // quadrant edge per wave
+    constexpr int NT = Q / 32;       // MFMA tiles per quadrant edge
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *sG = smem, *sX = smem + TW * WG_LS;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int split = blockIdx.x, tile = blockIdx.y, grp = blockIdx.z;
-    const int o0 = (tile / tiles_c) * WG_T, c0 = (tile % tiles_c) * WG_T;
+    const int o0 = (tile / tiles_c) * TW, c0 = (tile % tiles_c) * TW;
     const unsigned short *Gg = G + (size_t)grp * cout_g * M;
     const unsigned short *Xg = X + (size_t)grp * cin_g * M;
     const int64_t m_begin = (int64_t)split * cols_per_split;
     const int64_t m_end = (m_begin + cols_per_split < M) ? m_begin + cols_per_split : M;
     const int wo = wave >> 1, wc = wave & 1;
 
-    f32x16 acc;
+    f32x16 acc[NT][NT];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
     const bool vec_ok = (M & 7) == 0;
     for (int64_t m0 = m_begin; m0 < m_end; m0 += WG_KC) {
         __syncthreads();
-        // stage 64 rows x 128 columns of G and X: thread -> (row = i*16 + tid/16, 16-byte column tid%16)
+        // stage TW rows x 128 columns of G and X: thread -> (row = i*16 + tid/16, 16-byte column tid%16)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < TW / 16; ++i) {
             const int row = i * 16 + (tid >> 4), cb = tid & 15;
             const int64_t m = m0 + cb * 8;
             uint4 vg = make_uint4(0, 0, 0, 0), vx = make_uint4(0, 0, 0, 0);
@@ -66,46 +74,74 @@ __global__ __launch_bounds__(256) void wgrad_partial_kernel(const unsigned short
             *reinterpret_cast<uint4 *>(sX + row * WG_LS + cb * 16) = vx;
         }
         __syncthreads();
-        const unsigned char *ga = sG + (wo * 32 + l31) * WG_LS + half * 16;
-        const unsigned char *xa = sX + (wc * 32 + l31) * WG_LS + half * 16;
+        const unsigned char *ga = sG + (wo * Q + l31) * WG_LS + half * 16;
+        const unsigned char *xa = sX + (wc * Q + l31) * WG_LS + half * 16;
 #pragma unroll
         for (int kk = 0; kk < WG_KC / 16; ++kk) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8 *>(ga + kk * 32);
-            const bf16x8 b = *reinterpret_cast<const bf16x8 *>(xa + kk * 32);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+            bf16x8 av[NT], bv[NT];
+#pragma unroll
+            for (int a = 0; a < NT; ++a) av[a] = *reinterpret_cast<const bf16x8 *>(ga + a * 32 * WG_LS + kk * 32);
+#pragma unroll
+            for (int b = 0; b < NT; ++b) bv[b] = *reinterpret_cast<const bf16x8 *>(xa + b * 32 * WG_LS + kk * 32);
+#pragma unroll
+            for (int a = 0; a < NT; ++a)
+#pragma unroll
+                for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[a], bv[b], acc[a][b], 0, 0, 0);
         }
     }
     // partial tile -> part[split][grp][o][c]
     float *pp = part + ((size_t)split * gridDim.z + grp) * cout_g * cin_g;
-    const int c = c0 + wc * 32 + l31;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int o = o0 + wo * 32 + mfma_row(r, half);
-        if (o < cout_g && c < cin_g) pp[(size_t)o * cin_g + c] = acc[r];
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+            const int c = c0 + wc * Q + b * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = o0 + wo * Q + a * 32 + mfma_row(r, half);
+                if (o < cout_g && c < cin_g) pp[(size_t)o * cin_g + c] = acc[a][b][r];
+            }
+        }
+}
+
+// out[i] = sum_k part[k][i]: 16 outputs x 16 split-lanes per workgroup, fixed summation order (deterministic)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ part, int S, int64_t n,
+                                                           float *__restrict__ out) {
+    __shared__ float red[16][17];
+    const int tid = threadIdx.x, j = tid & 15, q = tid >> 4;
+    const int64_t i = (int64_t)blockIdx.x * 16 + j;
+    float s = 0.0f;
+    if (i < n) {
+#pragma unroll 4
+        for (int k = q; k < S; k += 16) s += part[(size_t)k * n + i];
+    }
+    red[q][j] = s;
+    __syncthreads();
+    if (tid < 16 && i < n) {
+        float t = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][tid];
+        out[i] = t;
     }
 }
 
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ part, int S, int64_t n,
-                                                           float *__restrict__ out) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float s = 0.0f;
-    for (int k = 0; k < S; ++k) s += part[(size_t)k * n + i];
-    out[i] = s;
-}
-
 struct WgradPlan {
-    int tiles_o, tiles_c, S;
+    int tw, tiles_o, tiles_c, S;
     int64_t cols;
 };
 static WgradPlan wgrad_plan(int cout_g, int cin_g, int groups, int64_t M) {
     WgradPlan p;
-    p.tiles_o = (cout_g + WG_T - 1) / WG_T;
-    p.tiles_c = (cin_g + WG_T - 1) / WG_T;
+    p.tw = (cout_g >= 256 && cin_g >= 256) ? 128 : 64;
+    p.tiles_o = (cout_g + p.tw - 1) / p.tw;
+    p.tiles_c = (cin_g + p.tw - 1) / p.tw;
     const int64_t tiles = (int64_t)p.tiles_o * p.tiles_c * groups;
-    int64_t S = (2048 + tiles - 1) / tiles;                 // ~2048 workgroups: 8 per CU keeps loads in flight
+    // measured on MI355X: ~1024 workgroups for the 64-tiles (small outputs: parallelism must come from split-K),
+    // ~512 for the 128-tiles (large outputs: more splits only add partial-sum traffic)
+    const int64_t target = p.tw == 64 ? 1024 : 512;
+    int64_t S = (target + tiles - 1) / tiles;
     const int64_t max_s = (M + 4 * WG_KC - 1) / (4 * WG_KC);  // >= 4 chunks per slice
     if (S > max_s) S = max_s;
+    if (S > 256) S = 256;
     if (S < 1) S = 1;
     int64_t cols = (M + S - 1) / S;
     cols = (cols + WG_KC - 1) / WG_KC * WG_KC;
@@ -139,12 +175,19 @@ extern "C" int grafp_conv1x1_wgrad_bf16(const void *grad_out, const void *x, int
     const WgradPlan p = wgrad_plan(cout_g, cin_g, groups, M);
     GRAFP_REQUIRE(p.tiles_o * p.tiles_c <= 65535, "conv1x1_wgrad: output too large");
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(wgrad_partial_kernel, dim3(p.S, p.tiles_o * p.tiles_c, groups), dim3(256), 0, s,
-                       (const unsigned short *)grad_out, (const unsigned short *)x, M, cout_g, cin_g, p.tiles_c, p.cols,
-                       (float *)ws);
+    const dim3 grid(p.S, p.tiles_o * p.tiles_c, groups);
+    const size_t lds = (size_t)2 * p.tw * WG_LS;
+    if (p.tw == 64) {
+        hipLaunchKernelGGL(wgrad_partial_kernel<64>, grid, dim3(256), lds, s, (const unsigned short *)grad_out,
+                           (const unsigned short *)x, M, cout_g, cin_g, p.tiles_c, p.cols, (float *)ws);
+    } else {
+        (void)hipFuncSetAttribute((const void *)wgrad_partial_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(wgrad_partial_kernel<128>, grid, dim3(256), lds, s, (const unsigned short *)grad_out,
+                           (const unsigned short *)x, M, cout_g, cin_g, p.tiles_c, p.cols, (float *)ws);
+    }
     GRAFP_CHECK_LAUNCH("wgrad_partial_kernel");
     const int64_t n = (int64_t)Cout * cin_g;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float *)ws, p.S, n,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, s, (const float *)ws, p.S, n,
                        dweight);
     GRAFP_CHECK_LAUNCH("wgrad_reduce_kernel");
     return GRAFP_OK;
