@@ -85,15 +85,18 @@ __device__ __forceinline__ float act_grad(float u, int act, float slope) {
 
 // ---- forward pass 1: partial shifted sums --------------------------------------------------------
 template <typename T, bool VEC>
-__global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(const T *__restrict__ x, int64_t M, int64_t chunk, int S,
+__global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(const T *__restrict__ x, int64_t M, int64_t Mg,
+                                                              int64_t chunk, int Sg,
                                                               const float *__restrict__ pre_bias,
                                                               float *__restrict__ part) {
     __shared__ float2 scratch[BN_THREADS / 64];
     const int c = blockIdx.y, s = blockIdx.x, tid = threadIdx.x;
+    const int S = gridDim.x, g = s / Sg, sl = s - g * Sg;
     const T *row = x + (size_t)c * M;
     const float pb = pre_bias ? pre_bias[c] : 0.0f;
-    const float shift = BnIO<T>::ld1(row) + pb;
-    const int64_t lo = (int64_t)s * chunk, hi = (lo + chunk < M) ? lo + chunk : M;
+    const float shift = BnIO<T>::ld1(row + (int64_t)g * Mg) + pb;
+    const int64_t gend = (int64_t)(g + 1) * Mg;
+    const int64_t lo = (int64_t)g * Mg + (int64_t)sl * chunk, hi = (lo + chunk < gend) ? lo + chunk : gend;
     float a = 0.0f, q = 0.0f;
     constexpr int W = VEC ? BnIO<T>::W : 1;
     for (int64_t m = lo + (int64_t)tid * W; m < hi; m += (int64_t)BN_THREADS * W) {
@@ -123,7 +126,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(const T *__restric
 
 // ---- forward pass 2: finalise statistics (train) or take running ones (eval), then apply -----------
 template <typename T, bool VEC>
-__global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const T *__restrict__ x, int64_t M, int64_t chunk, int S,
+__global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const T *__restrict__ x, int64_t M, int64_t Mg,
+                                                              int64_t chunk, int Sg, int G,
                                                               const float *__restrict__ pre_bias,
                                                               const float *__restrict__ gamma,
                                                               const float *__restrict__ beta,
@@ -135,42 +139,59 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const T *__restric
                                                               float *__restrict__ save_mean,
                                                               float *__restrict__ save_invstd) {
     const int c = blockIdx.y, s = blockIdx.x, tid = threadIdx.x;
+    const int S = gridDim.x, grp = s / Sg, sl = s - grp * Sg;
     const T *row = x + (size_t)c * M;
     const float pb = pre_bias ? pre_bias[c] : 0.0f;
     float mean, invstd;
     if (training) {
+        // statistics of group `grp` (a view's columns); same summation order in every block of the group
         float a = 0.0f, q = 0.0f;
-        for (int i = 0; i < S; ++i) {               // same order in every block of the row: identical statistics
+        for (int i = grp * Sg; i < (grp + 1) * Sg; ++i) {
             a += part[((size_t)c * S + i) * 2 + 0];
             q += part[((size_t)c * S + i) * 2 + 1];
         }
-        const float shift = BnIO<T>::ld1(row) + pb;
-        const float dm = a / (float)M;
-        const float var = fmaxf(q / (float)M - dm * dm, 0.0f);
+        const float shift = BnIO<T>::ld1(row + (int64_t)grp * Mg) + pb;
+        const float dm = a / (float)Mg;
+        const float var = fmaxf(q / (float)Mg - dm * dm, 0.0f);
         mean = shift + dm;
         invstd = 1.0f / sqrtf(var + eps);
-        if (s == 0 && tid == 0) {
-            save_mean[c] = mean;
-            save_invstd[c] = invstd;
-            if (running_mean) {
-                const float unbiased = M > 1 ? var * ((float)M / (float)(M - 1)) : var;
-                running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * mean;
-                running_var[c] = (1.0f - momentum) * running_var[c] + momentum * unbiased;
+        if (sl == 0 && tid == 0) {
+            save_mean[c * G + grp] = mean;
+            save_invstd[c * G + grp] = invstd;
+        }
+        if (s == 0 && tid == 0 && running_mean) {
+            // running statistics advance once per group, in order -- exactly what G sequential forward calls do
+            float rm = running_mean[c], rv = running_var[c];
+            for (int g2 = 0; g2 < G; ++g2) {
+                float a2 = 0.0f, q2 = 0.0f;
+                for (int i = g2 * Sg; i < (g2 + 1) * Sg; ++i) {
+                    a2 += part[((size_t)c * S + i) * 2 + 0];
+                    q2 += part[((size_t)c * S + i) * 2 + 1];
+                }
+                const float sh2 = BnIO<T>::ld1(row + (int64_t)g2 * Mg) + pb;
+                const float dm2 = a2 / (float)Mg;
+                const float var2 = fmaxf(q2 / (float)Mg - dm2 * dm2, 0.0f);
+                const float unbiased = Mg > 1 ? var2 * ((float)Mg / (float)(Mg - 1)) : var2;
+                rm = (1.0f - momentum) * rm + momentum * (sh2 + dm2);
+                rv = (1.0f - momentum) * rv + momentum * unbiased;
             }
+            running_mean[c] = rm;
+            running_var[c] = rv;
         }
     } else {
         mean = running_mean[c];
         invstd = 1.0f / sqrtf(running_var[c] + eps);
-        if (s == 0 && tid == 0) {
-            save_mean[c] = mean;
-            save_invstd[c] = invstd;
+        if (sl == 0 && tid == 0) {
+            save_mean[c * G + grp] = mean;
+            save_invstd[c * G + grp] = invstd;
         }
     }
     const float g = gamma[c] * invstd;
     const float off = beta[c] + (pb - mean) * g;      // z = act(x*g + off) + r
     const T *rrow = residual ? residual + (size_t)c * M : nullptr;
     T *orow = out + (size_t)c * M;
-    const int64_t lo = (int64_t)s * chunk, hi = (lo + chunk < M) ? lo + chunk : M;
+    const int64_t gend = (int64_t)(grp + 1) * Mg;
+    const int64_t lo = (int64_t)grp * Mg + (int64_t)sl * chunk, hi = (lo + chunk < gend) ? lo + chunk : gend;
     constexpr int W = VEC ? BnIO<T>::W : 1;
     for (int64_t m = lo + (int64_t)tid * W; m < hi; m += (int64_t)BN_THREADS * W) {
         if (VEC && m + W <= hi) {
@@ -196,8 +217,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const T *__restric
 // ---- backward pass 1: partial sums of dy and dy * xhat ----------------------------------------------
 template <typename T, bool VEC>
 __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(const T *__restrict__ x, const T *__restrict__ dz,
-                                                                   int64_t M, int64_t chunk, int S,
-                                                                   const float *__restrict__ pre_bias,
+                                                                   int64_t M, int64_t Mg, int64_t chunk, int Sg,
+                                                                   int G, const float *__restrict__ pre_bias,
                                                                    const float *__restrict__ gamma,
                                                                    const float *__restrict__ beta,
                                                                    const float *__restrict__ save_mean,
@@ -205,10 +226,12 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(const T *__re
                                                                    float slope, float *__restrict__ part) {
     __shared__ float2 scratch[BN_THREADS / 64];
     const int c = blockIdx.y, s = blockIdx.x, tid = threadIdx.x;
+    const int S = gridDim.x, grp = s / Sg, sl = s - grp * Sg;
     const T *row = x + (size_t)c * M, *grow = dz + (size_t)c * M;
     const float pb = pre_bias ? pre_bias[c] : 0.0f;
-    const float mean = save_mean[c], invstd = save_invstd[c], ga = gamma[c], be = beta[c];
-    const int64_t lo = (int64_t)s * chunk, hi = (lo + chunk < M) ? lo + chunk : M;
+    const float mean = save_mean[c * G + grp], invstd = save_invstd[c * G + grp], ga = gamma[c], be = beta[c];
+    const int64_t gend = (int64_t)(grp + 1) * Mg;
+    const int64_t lo = (int64_t)grp * Mg + (int64_t)sl * chunk, hi = (lo + chunk < gend) ? lo + chunk : gend;
     float sd = 0.0f, sdx = 0.0f;
     constexpr int W = VEC ? BnIO<T>::W : 1;
     for (int64_t m = lo + (int64_t)tid * W; m < hi; m += (int64_t)BN_THREADS * W) {
@@ -242,7 +265,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(const T *__re
 // ---- backward pass 2: dgamma, dbeta, dx ---------------------------------------------------------------
 template <typename T, bool VEC>
 __global__ __launch_bounds__(BN_THREADS) void bn_bwd_dx_kernel(const T *__restrict__ x, const T *__restrict__ dz,
-                                                               int64_t M, int64_t chunk, int S,
+                                                               int64_t M, int64_t Mg, int64_t chunk, int Sg, int G,
                                                                const float *__restrict__ pre_bias,
                                                                const float *__restrict__ gamma,
                                                                const float *__restrict__ beta,
@@ -252,23 +275,30 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_dx_kernel(const T *__restri
                                                                const float *__restrict__ part, T *__restrict__ dx,
                                                                float *__restrict__ dgamma, float *__restrict__ dbeta) {
     const int c = blockIdx.y, s = blockIdx.x, tid = threadIdx.x;
+    const int S = gridDim.x, grp = s / Sg, sl = s - grp * Sg;
     const T *row = x + (size_t)c * M, *grow = dz + (size_t)c * M;
     T *orow = dx + (size_t)c * M;
     const float pb = pre_bias ? pre_bias[c] : 0.0f;
-    const float mean = save_mean[c], invstd = save_invstd[c], ga = gamma[c], be = beta[c];
+    const float mean = save_mean[c * G + grp], invstd = save_invstd[c * G + grp], ga = gamma[c], be = beta[c];
     float sd = 0.0f, sdx = 0.0f;
-    for (int i = 0; i < S; ++i) {
+    for (int i = grp * Sg; i < (grp + 1) * Sg; ++i) {
         sd += part[((size_t)c * S + i) * 2 + 0];
         sdx += part[((size_t)c * S + i) * 2 + 1];
     }
-    if (s == 0 && tid == 0) {
-        dgamma[c] = sdx;
-        dbeta[c] = sd;
+    if (s == 0 && tid == 0) {          // parameter gradients sum over all groups (fixed order)
+        float td = 0.0f, tdx = 0.0f;
+        for (int i = 0; i < S; ++i) {
+            td += part[((size_t)c * S + i) * 2 + 0];
+            tdx += part[((size_t)c * S + i) * 2 + 1];
+        }
+        dgamma[c] = tdx;
+        dbeta[c] = td;
     }
-    // train: dx = ga*invstd * (dy - mean(dy) - xhat * mean(dy*xhat)); eval: dx = ga*invstd*dy
+    // train: dx = ga*invstd * (dy - mean_g(dy) - xhat * mean_g(dy*xhat)) within the group; eval: dx = ga*invstd*dy
     const float k = ga * invstd;
-    const float m1 = training ? sd / (float)M : 0.0f, m2 = training ? sdx / (float)M : 0.0f;
-    const int64_t lo = (int64_t)s * chunk, hi = (lo + chunk < M) ? lo + chunk : M;
+    const float m1 = training ? sd / (float)Mg : 0.0f, m2 = training ? sdx / (float)Mg : 0.0f;
+    const int64_t gend = (int64_t)(grp + 1) * Mg;
+    const int64_t lo = (int64_t)grp * Mg + (int64_t)sl * chunk, hi = (lo + chunk < gend) ? lo + chunk : gend;
     constexpr int W = VEC ? BnIO<T>::W : 1;
     for (int64_t m = lo + (int64_t)tid * W; m < hi; m += (int64_t)BN_THREADS * W) {
         if (VEC && m + W <= hi) {
@@ -293,43 +323,46 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_dx_kernel(const T *__restri
 }
 
 struct BnPlan {
-    int S;
+    int Sg;
     int64_t chunk;
 };
-static BnPlan bn_plan(int C, int64_t M, int W) {
+static BnPlan bn_plan(int C, int64_t Mg, int G, int W) {
     const int64_t per_block = (int64_t)BN_THREADS * W * 4;      // >= 4 vector iterations per thread
-    int64_t S = (M + per_block - 1) / per_block;
-    const int64_t cap = 4096 / C > 1 ? 4096 / C : 1;            // ~4096 workgroups in flight overall
+    int64_t S = (Mg + per_block - 1) / per_block;
+    const int64_t cap = 4096 / ((int64_t)C * G) > 1 ? 4096 / ((int64_t)C * G) : 1;   // ~4096 workgroups overall
     if (S > cap) S = cap;
     if (S < 1) S = 1;
-    int64_t chunk = (M + S - 1) / S;
+    int64_t chunk = (Mg + S - 1) / S;
     chunk = (chunk + W - 1) / W * W;                             // chunk boundaries stay vector-aligned
     BnPlan p;
     p.chunk = chunk;
-    p.S = (int)((M + chunk - 1) / chunk);
+    p.Sg = (int)((Mg + chunk - 1) / chunk);
     return p;
 }
 
 template <typename T>
-static bool bn_vec_ok(const void *a, const void *b, const void *c, const void *d, int64_t M) {
+static bool bn_vec_ok(const void *a, const void *b, const void *c, const void *d, int64_t Mg) {
     const uintptr_t m = (uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d;
-    return (M % BnIO<T>::W) == 0 && (m & 15) == 0;
+    return (Mg % BnIO<T>::W) == 0 && (m & 15) == 0;
 }
 
 }  // namespace grafp
 
 extern "C" size_t grafp_bn_workspace(int C, int64_t M) {
     if (C <= 0 || M <= 0) return 0;
-    return (size_t)C * (size_t)(4096 / C > 1 ? 4096 / C : 1) * 2 * sizeof(float);
+    return ((size_t)4096 + (size_t)C * 8) * 2 * sizeof(float);      // >= C * G * Sg partial pairs for any G <= 8
 }
 
-extern "C" int grafp_bn_fwd(const void *x, int dtype, int C, int64_t M, const float *pre_bias, const float *gamma,
+extern "C" int grafp_bn_fwd(const void *x, int dtype, int C, int64_t M, int groups, const float *pre_bias, const float *gamma,
                             const float *beta, const void *residual, int act, float slope, float eps, float momentum,
                             int training, float *running_mean, float *running_var, void *out, float *save_mean,
                             float *save_invstd, void *ws, size_t ws_bytes, grafp_stream_t stream) {
     using namespace grafp;
     GRAFP_REQUIRE(x && gamma && beta && out && save_mean && save_invstd, "bn_fwd: null pointer");
     GRAFP_REQUIRE(C > 0 && M > 0 && C <= 65535, "bn_fwd: bad shape C=%d M=%lld", C, (long long)M);
+    GRAFP_REQUIRE(groups >= 1 && groups <= 8 && M % groups == 0, "bn_fwd: groups=%d must be in [1,8] and divide M=%lld", groups, (long long)M);
+    const int G = groups;
+    const int64_t Mg = M / G;
     GRAFP_REQUIRE(dtype == GRAFP_F32 || dtype == GRAFP_BF16, "bn_fwd: dtype %d not in {f32, bf16}", dtype);
     GRAFP_REQUIRE(act >= 0 && act <= 2, "bn_fwd: act %d not in {0 none, 1 relu, 2 leaky}", act);
     GRAFP_REQUIRE(training || (running_mean && running_var), "bn_fwd: eval mode needs running statistics");
@@ -341,32 +374,35 @@ extern "C" int grafp_bn_fwd(const void *x, int dtype, int C, int64_t M, const fl
     float *part = (float *)ws;
 #define BN_FWD(T, VEC)                                                                                                 \
     do {                                                                                                               \
-        const BnPlan p = bn_plan(C, M, BnIO<T>::W);                                                                    \
-        const dim3 grid(p.S, C);                                                                                       \
+        const BnPlan p = bn_plan(C, Mg, G, VEC ? BnIO<T>::W : 1);                                                      \
+        const dim3 grid(p.Sg * G, C);                                                                                  \
         if (training)                                                                                                  \
-            hipLaunchKernelGGL((bn_stats_kernel<T, VEC>), grid, dim3(BN_THREADS), 0, s, (const T *)x, M, p.chunk, p.S,  \
-                               pre_bias, part);                                                                        \
-        hipLaunchKernelGGL((bn_apply_kernel<T, VEC>), grid, dim3(BN_THREADS), 0, s, (const T *)x, M, p.chunk, p.S,     \
-                           pre_bias, gamma, beta, (const T *)residual, act, slope, eps, momentum, training,            \
+            hipLaunchKernelGGL((bn_stats_kernel<T, VEC>), grid, dim3(BN_THREADS), 0, s, (const T *)x, M, Mg, p.chunk,   \
+                               p.Sg, pre_bias, part);                                                                  \
+        hipLaunchKernelGGL((bn_apply_kernel<T, VEC>), grid, dim3(BN_THREADS), 0, s, (const T *)x, M, Mg, p.chunk,      \
+                           p.Sg, G, pre_bias, gamma, beta, (const T *)residual, act, slope, eps, momentum, training,            \
                            running_mean, running_var, part, (T *)out, save_mean, save_invstd);                         \
     } while (0)
     if (dtype == GRAFP_F32) {
-        if (bn_vec_ok<float>(x, out, residual, nullptr, M)) BN_FWD(float, true); else BN_FWD(float, false);
+        if (bn_vec_ok<float>(x, out, residual, nullptr, Mg)) BN_FWD(float, true); else BN_FWD(float, false);
     } else {
-        if (bn_vec_ok<unsigned short>(x, out, residual, nullptr, M)) BN_FWD(unsigned short, true); else BN_FWD(unsigned short, false);
+        if (bn_vec_ok<unsigned short>(x, out, residual, nullptr, Mg)) BN_FWD(unsigned short, true); else BN_FWD(unsigned short, false);
     }
 #undef BN_FWD
     GRAFP_CHECK_LAUNCH("bn_stats_kernel / bn_apply_kernel");
     return GRAFP_OK;
 }
 
-extern "C" int grafp_bn_bwd(const void *x, const void *dz, int dtype, int C, int64_t M, const float *pre_bias,
+extern "C" int grafp_bn_bwd(const void *x, const void *dz, int dtype, int C, int64_t M, int groups, const float *pre_bias,
                             const float *gamma, const float *beta, const float *save_mean, const float *save_invstd,
                             int act, float slope, int training, void *dx, float *dgamma, float *dbeta, void *ws,
                             size_t ws_bytes, grafp_stream_t stream) {
     using namespace grafp;
     GRAFP_REQUIRE(x && dz && gamma && beta && save_mean && save_invstd && dx && dgamma && dbeta, "bn_bwd: null pointer");
     GRAFP_REQUIRE(C > 0 && M > 0 && C <= 65535, "bn_bwd: bad shape C=%d M=%lld", C, (long long)M);
+    GRAFP_REQUIRE(groups >= 1 && groups <= 8 && M % groups == 0, "bn_bwd: groups=%d must be in [1,8] and divide M=%lld", groups, (long long)M);
+    const int G = groups;
+    const int64_t Mg = M / G;
     GRAFP_REQUIRE(dtype == GRAFP_F32 || dtype == GRAFP_BF16, "bn_bwd: dtype %d not in {f32, bf16}", dtype);
     GRAFP_REQUIRE(act >= 0 && act <= 2, "bn_bwd: act %d not in {0 none, 1 relu, 2 leaky}", act);
     if (!ws || ws_bytes < grafp_bn_workspace(C, M)) {
@@ -377,18 +413,18 @@ extern "C" int grafp_bn_bwd(const void *x, const void *dz, int dtype, int C, int
     float *part = (float *)ws;
 #define BN_BWD(T, VEC)                                                                                                 \
     do {                                                                                                               \
-        const BnPlan p = bn_plan(C, M, BnIO<T>::W);                                                                    \
-        const dim3 grid(p.S, C);                                                                                       \
+        const BnPlan p = bn_plan(C, Mg, G, VEC ? BnIO<T>::W : 1);                                                      \
+        const dim3 grid(p.Sg * G, C);                                                                                  \
         hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, VEC>), grid, dim3(BN_THREADS), 0, s, (const T *)x, (const T *)dz,  \
-                           M, p.chunk, p.S, pre_bias, gamma, beta, save_mean, save_invstd, act, slope, part);          \
+                           M, Mg, p.chunk, p.Sg, G, pre_bias, gamma, beta, save_mean, save_invstd, act, slope, part);  \
         hipLaunchKernelGGL((bn_bwd_dx_kernel<T, VEC>), grid, dim3(BN_THREADS), 0, s, (const T *)x, (const T *)dz, M,   \
-                           p.chunk, p.S, pre_bias, gamma, beta, save_mean, save_invstd, act, slope, training, part,    \
+                           Mg, p.chunk, p.Sg, G, pre_bias, gamma, beta, save_mean, save_invstd, act, slope, training, part,    \
                            (T *)dx, dgamma, dbeta);                                                                    \
     } while (0)
     if (dtype == GRAFP_F32) {
-        if (bn_vec_ok<float>(x, dz, dx, nullptr, M)) BN_BWD(float, true); else BN_BWD(float, false);
+        if (bn_vec_ok<float>(x, dz, dx, nullptr, Mg)) BN_BWD(float, true); else BN_BWD(float, false);
     } else {
-        if (bn_vec_ok<unsigned short>(x, dz, dx, nullptr, M)) BN_BWD(unsigned short, true); else BN_BWD(unsigned short, false);
+        if (bn_vec_ok<unsigned short>(x, dz, dx, nullptr, Mg)) BN_BWD(unsigned short, true); else BN_BWD(unsigned short, false);
     }
 #undef BN_BWD
     GRAFP_CHECK_LAUNCH("bn_bwd_reduce_kernel / bn_bwd_dx_kernel");

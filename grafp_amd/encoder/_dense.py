@@ -56,11 +56,13 @@ def conv3_stride2(conv, x):
     return ops.conv1x1_rows(taps.reshape(3 * cin, B * n_out), w).reshape(cout, B, n_out)
 
 
-def bn_act(bn, y, pre_bias=None, residual=None, act=ops.ACT_NONE, slope=0.0):
+def bn_act(bn, y, pre_bias=None, residual=None, act=ops.ACT_NONE, slope=0.0, groups=1):
     """nn.BatchNorm2d semantics (batch statistics + running-stat update in train mode) over the rows of y (C,B,N),
-    fused with the preceding conv's bias, the activation and the residual add."""
+    fused with the preceding conv's bias, the activation and the residual add.  groups = number of views stacked
+    along B: each view keeps its OWN batch statistics and the running statistics advance once per view, exactly
+    as when the views pass through the module one after the other (simclr/simclr.py:35,43)."""
     training = bn.training or not bn.track_running_stats
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+        bn.num_batches_tracked.add_(groups)
     return ops.bn_act(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, training,
-                      0.0 if bn.momentum is None else bn.momentum, bn.eps, pre_bias, residual, act, slope)
+                      0.0 if bn.momentum is None else bn.momentum, bn.eps, pre_bias, residual, act, slope, groups)

@@ -70,7 +70,7 @@ class BasicConv(nn.Sequential):
                 m.weight.data.fill_(1)
                 m.bias.data.zero_()
 
-    def forward_cbn(self, x):
+    def forward_cbn(self, x, groups=1):
         """x (Cin,B,N) -> (Cout,B,N).  [conv, BatchNorm, ReLU] triples run as GEMM + one fused kernel."""
         mods, i = list(self), 0
         while i < len(mods):
@@ -81,15 +81,15 @@ class BasicConv(nn.Sequential):
                 if isinstance(nxt, nn.BatchNorm2d):
                     act_mod = mods[i + 2] if i + 2 < len(mods) else None
                     if isinstance(act_mod, nn.ReLU):
-                        x, i = bn_act(nxt, y, pre_bias=m.bias, act=ops.ACT_RELU), i + 3
+                        x, i = bn_act(nxt, y, pre_bias=m.bias, act=ops.ACT_RELU, groups=groups), i + 3
                     elif isinstance(act_mod, nn.LeakyReLU):
-                        x, i = bn_act(nxt, y, pre_bias=m.bias, act=ops.ACT_LEAKY, slope=act_mod.negative_slope), i + 3
+                        x, i = bn_act(nxt, y, pre_bias=m.bias, act=ops.ACT_LEAKY, slope=act_mod.negative_slope, groups=groups), i + 3
                     else:
-                        x, i = bn_act(nxt, y, pre_bias=m.bias), i + 2
+                        x, i = bn_act(nxt, y, pre_bias=m.bias, groups=groups), i + 2
                     continue
                 x = y if m.bias is None else y + m.bias.reshape(-1, 1, 1).to(y.dtype)
             elif isinstance(m, (nn.BatchNorm2d, nn.InstanceNorm2d, nn.Dropout2d)):
-                x = bn_act(m, x) if isinstance(m, nn.BatchNorm2d) else to_cbn(m(from_cbn(x, x.new_empty(0, 0, 0, 0))))
+                x = bn_act(m, x, groups=groups) if isinstance(m, nn.BatchNorm2d) else to_cbn(m(from_cbn(x, x.new_empty(0, 0, 0, 0))))
             else:
                 x = m(x)
             i += 1

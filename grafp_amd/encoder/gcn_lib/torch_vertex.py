@@ -24,9 +24,9 @@ class MRConv2d(nn.Module):
         super().__init__()
         self.nn = BasicConv([in_channels * 2, out_channels], act, norm, bias)
 
-    def aggregate_cbn(self, x, nn_idx):
+    def aggregate_cbn(self, x, nn_idx, groups=1):
         """x (C,B,N), nn_idx (B,N,k) -> (Cout,B,N)."""
-        return self.nn.forward_cbn(ops.max_relative(x, nn_idx, layout="cbn"))
+        return self.nn.forward_cbn(ops.max_relative(x, nn_idx, layout="cbn"), groups)
 
     def forward(self, x, edge_index, y=None):
         if y is not None:
@@ -56,8 +56,8 @@ class DyGraphConv2d(GraphConv2d):
         self.k, self.d, self.r = kernel_size, dilation, r
         self.dilated_knn_graph = DenseDilatedKnnGraph(kernel_size, dilation, stochastic, epsilon)
 
-    def forward_cbn(self, x):
-        return self.gconv.aggregate_cbn(x, self.dilated_knn_graph.neighbours(x, layout="cbn"))
+    def forward_cbn(self, x, groups=1):
+        return self.gconv.aggregate_cbn(x, self.dilated_knn_graph.neighbours(x, layout="cbn"), groups)
 
     def forward(self, x, relative_pos=None):
         shape = x.shape
@@ -86,11 +86,11 @@ class Grapher(nn.Module):
             table = F.interpolate(table[None, None], size=(n, n // (r * r)), mode="bicubic", align_corners=False)
             self.relative_pos = nn.Parameter(-table.squeeze(1), requires_grad=False)
 
-    def forward_cbn(self, x):
+    def forward_cbn(self, x, groups=1):
         """x (C,B,N) -> (C,B,N): 3 GEMMs, 3 fused BN kernels, the k-NN build and the max-relative gather."""
-        y = bn_act(self.fc1[1], conv1x1(self.fc1[0], x), pre_bias=self.fc1[0].bias)
-        y = self.graph_conv.forward_cbn(y)
-        return bn_act(self.fc2[1], conv1x1(self.fc2[0], y), pre_bias=self.fc2[0].bias, residual=x)
+        y = bn_act(self.fc1[1], conv1x1(self.fc1[0], x), pre_bias=self.fc1[0].bias, groups=groups)
+        y = self.graph_conv.forward_cbn(y, groups)
+        return bn_act(self.fc2[1], conv1x1(self.fc2[0], y), pre_bias=self.fc2[0].bias, residual=x, groups=groups)
 
     def forward(self, x):
         return from_cbn(self.forward_cbn(to_cbn(x)), x)

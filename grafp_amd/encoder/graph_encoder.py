@@ -28,8 +28,8 @@ class Downsample(nn.Module):
         super().__init__()
         self.conv = nn.Sequential(nn.Conv2d(in_dim, out_dim, 3, stride=2, padding=1), nn.BatchNorm2d(out_dim))
 
-    def forward_cbn(self, x):
-        return bn_act(self.conv[1], conv3_stride2(self.conv[0], x), pre_bias=self.conv[0].bias)
+    def forward_cbn(self, x, groups=1):
+        return bn_act(self.conv[1], conv3_stride2(self.conv[0], x), pre_bias=self.conv[0].bias, groups=groups)
 
     def forward(self, x):
         return from_cbn(self.forward_cbn(to_cbn(x)), x)
@@ -42,8 +42,8 @@ class ChannelConv(nn.Module):
         super().__init__()
         self.conv = nn.Sequential(nn.Conv2d(in_dim, out_dim, kernel_size=1, bias=False), nn.BatchNorm2d(out_dim))
 
-    def forward_cbn(self, x):
-        return bn_act(self.conv[1], conv1x1(self.conv[0], x))
+    def forward_cbn(self, x, groups=1):
+        return bn_act(self.conv[1], conv1x1(self.conv[0], x), groups=groups)
 
     def forward(self, x):
         return from_cbn(self.forward_cbn(to_cbn(x)), x)
@@ -61,13 +61,13 @@ class FFN(nn.Module):
         self.fc1 = nn.Sequential(nn.Conv2d(in_features, hidden_features, 1, bias=False), nn.BatchNorm2d(hidden_features))
         self.fc2 = nn.Sequential(nn.Conv2d(hidden_features, out_features, 1, bias=False), nn.BatchNorm2d(out_features))
 
-    def forward_cbn(self, x):
+    def forward_cbn(self, x, groups=1):
         """x (C,B,N) -> (C,B,N): 2 GEMMs + 2 fused BN kernels (ReLU and the shortcut add are inside them)."""
         if isinstance(self.act, torch.nn.ReLU):
-            h = bn_act(self.fc1[1], conv1x1(self.fc1[0], x), act=ops.ACT_RELU)
+            h = bn_act(self.fc1[1], conv1x1(self.fc1[0], x), act=ops.ACT_RELU, groups=groups)
         else:
-            h = self.act(bn_act(self.fc1[1], conv1x1(self.fc1[0], x)))
-        return bn_act(self.fc2[1], conv1x1(self.fc2[0], h), residual=x)
+            h = self.act(bn_act(self.fc1[1], conv1x1(self.fc1[0], x), groups=groups))
+        return bn_act(self.fc2[1], conv1x1(self.fc2[0], h), residual=x, groups=groups)
 
     def forward(self, x):
         return from_cbn(self.forward_cbn(to_cbn(x)), x)
@@ -111,15 +111,18 @@ class GraphEncoder(nn.Module):
                     m.bias.data.zero_()
                     m.bias.requires_grad = True
 
-    def forward(self, x):
-        """x (B, C_in, N) node features -> (B, 1024).  Internally every activation is a (C, B, N) matrix."""
+    def forward(self, x, views=1):
+        """x (B, C_in, N) node features -> (B, 1024).  Internally every activation is a (C, B, N) matrix.
+        views > 1: the batch holds that many equally sized views stacked along B; BatchNorm keeps separate batch
+        statistics per view (the reference runs the views one after the other), everything else is per clip."""
         x = to_cbn(x)
-        x = bn_act(self.stem[1], conv1x1(self.stem[0], x), act=ops.ACT_LEAKY, slope=self.stem[2].negative_slope)
+        g = int(views)
+        x = bn_act(self.stem[1], conv1x1(self.stem[0], x), act=ops.ACT_LEAKY, slope=self.stem[2].negative_slope, groups=g)
         for mod in self.backbone:
             if isinstance(mod, Downsample):
-                x = mod.forward_cbn(x)
+                x = mod.forward_cbn(x, g)
             else:
-                x = mod[1].forward_cbn(mod[0].forward_cbn(x))
+                x = mod[1].forward_cbn(mod[0].forward_cbn(x, g), g)
         # readout: mean over nodes commutes with the (linear) 1x1 projection -- project the (C,B) means instead
         # of the (C,B,N) activations (graph_encoder.py:187-188 projects first: same result, 128x the work)
         pooled = x.float().mean(dim=2)                                              # (C, B)

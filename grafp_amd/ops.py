@@ -293,7 +293,7 @@ ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 class _BnAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, pre_bias, residual, running_mean, running_var, training, momentum, eps, act,
-                slope):
+                slope, groups):
         _require_gpu(x, gamma, beta)
         if x.dtype not in _DT:
             x = x.float()
@@ -304,22 +304,22 @@ class _BnAct(torch.autograd.Function):
         g32, b32 = _f32c(gamma), _f32c(beta)
         pb = None if pre_bias is None else _f32c(pre_bias)
         out = torch.empty_like(x)
-        mean = torch.empty((C,), dtype=torch.float32, device=x.device)
-        invstd = torch.empty((C,), dtype=torch.float32, device=x.device)
+        mean = torch.empty((C, groups), dtype=torch.float32, device=x.device)
+        invstd = torch.empty((C, groups), dtype=torch.float32, device=x.device)
         nbytes = lib.grafp_bn_workspace(C, M)
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
         with _timed("bn_fwd", (C, M, x.element_size())):
-            check(lib.grafp_bn_fwd(_p(x), _DT[x.dtype], C, M, _p(pb), _p(g32), _p(b32), _p(res), act, float(slope),
+            check(lib.grafp_bn_fwd(_p(x), _DT[x.dtype], C, M, groups, _p(pb), _p(g32), _p(b32), _p(res), act, float(slope),
                                    float(eps), float(momentum), int(bool(training)), _p(running_mean), _p(running_var),
                                    _p(out), _p(mean), _p(invstd), _p(ws), nbytes, _stream()), "bn_fwd")
         ctx.save_for_backward(x, g32, b32, pb if pb is not None else mean.new_empty(0), mean, invstd)
-        ctx.cfg = (C, M, act, float(slope), bool(training), pre_bias is not None, residual is not None)
+        ctx.cfg = (C, M, act, float(slope), bool(training), pre_bias is not None, residual is not None, groups)
         return out
 
     @staticmethod
     def backward(ctx, dz):
         x, g32, b32, pb, mean, invstd = ctx.saved_tensors
-        C, M, act, slope, training, has_pb, has_res = ctx.cfg
+        C, M, act, slope, training, has_pb, has_res, groups = ctx.cfg
         dz = dz.detach().to(x.dtype).contiguous()
         dx = torch.empty_like(x)
         dgamma = torch.empty((C,), dtype=torch.float32, device=x.device)
@@ -327,22 +327,23 @@ class _BnAct(torch.autograd.Function):
         nbytes = lib.grafp_bn_workspace(C, M)
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
         with _timed("bn_bwd", (C, M, x.element_size())):
-            check(lib.grafp_bn_bwd(_p(x), _p(dz), _DT[x.dtype], C, M, _p(pb) if has_pb else None, _p(g32), _p(b32),
+            check(lib.grafp_bn_bwd(_p(x), _p(dz), _DT[x.dtype], C, M, groups, _p(pb) if has_pb else None, _p(g32), _p(b32),
                                    _p(mean), _p(invstd), act, slope, int(training), _p(dx), _p(dgamma), _p(dbeta),
                                    _p(ws), nbytes, _stream()), "bn_bwd")
         dpb = None
         if has_pb:      # cancels exactly under batch statistics; a plain bias in eval mode
             dpb = torch.zeros_like(dgamma) if training else dx.reshape(C, -1).float().sum(dim=1)
-        return dx, dgamma, dbeta, dpb, (dz if has_res else None), None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, dpb, (dz if has_res else None), None, None, None, None, None, None, None, None
 
 
 def bn_act(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, pre_bias=None, residual=None,
-           act=ACT_NONE, slope=0.0):
+           act=ACT_NONE, slope=0.0, groups=1):
     """z = act(BatchNorm(x + pre_bias)) + residual over ROWS of x (C, ...): one fused HIP forward (2 passes) and
     backward (2 passes).  x / residual / z share a dtype (f32 or bf16); parameters and statistics are f32.
-    running_mean / running_var are updated in place when training."""
+    running_mean / running_var are updated in place when training.  groups > 1: each row is that many equal
+    column segments (the views of a contrastive batch) normalised with their own batch statistics."""
     return _BnAct.apply(x, gamma, beta, pre_bias, residual, running_mean, running_var, training, momentum, eps, act,
-                        slope)
+                        slope, int(groups))
 
 
 # ------------------------------------------------------------------------------------------------

@@ -129,15 +129,19 @@ int grafp_mrconv_bwd_strided(const void *x, int dtype, int64_t x_sb, int64_t x_s
  * training != 0: mean/var are the batch statistics of row c (biased variance); running_mean/var (optional) are
  * updated with `momentum` (unbiased variance), as nn.BatchNorm2d does.  training == 0: running statistics.
  * x, residual (optional), out, dz, dx: (C, M) rows contiguous, elements of `dtype`; everything else f32.
- * act: 0 none, 1 ReLU, 2 LeakyReLU(slope).  save_mean / save_invstd (C) feed the backward.
+ * act: 0 none, 1 ReLU, 2 LeakyReLU(slope).  save_mean / save_invstd (C, groups) feed the backward.
+ * groups (1..8, dividing M): every row is `groups` equal column segments with SEPARATE batch statistics and shared
+ * gamma/beta -- the two views of a contrastive batch side by side; running statistics advance once per group in
+ * order, i.e. exactly what `groups` sequential BatchNorm calls do (simclr/simclr.py:35,43).
  * Backward returns dx, dgamma, dbeta; the residual's gradient is dz itself; the gradient of pre_bias is exactly
  * zero in training mode (it cancels in the normalisation) and sum_m dx in eval mode. */
 size_t grafp_bn_workspace(int C, int64_t M);
-int grafp_bn_fwd(const void *x, int dtype, int C, int64_t M, const float *pre_bias, const float *gamma,
+int grafp_bn_fwd(const void *x, int dtype, int C, int64_t M, int groups, const float *pre_bias, const float *gamma,
                  const float *beta, const void *residual, int act, float slope, float eps, float momentum,
                  int training, float *running_mean, float *running_var, void *out, float *save_mean,
                  float *save_invstd, void *ws, size_t ws_bytes, grafp_stream_t stream);
-int grafp_bn_bwd(const void *x, const void *dz, int dtype, int C, int64_t M, const float *pre_bias, const float *gamma,
+int grafp_bn_bwd(const void *x, const void *dz, int dtype, int C, int64_t M, int groups, const float *pre_bias,
+                 const float *gamma,
                  const float *beta, const float *save_mean, const float *save_invstd, int act, float slope,
                  int training, void *dx, float *dgamma, float *dbeta, void *ws, size_t ws_bytes,
                  grafp_stream_t stream);

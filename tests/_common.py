@@ -80,8 +80,15 @@ class RecordedGraphs:
     def __exit__(self, *exc):
         self._ops.knn_graph = self._orig
 
-    def replay_fn(self):
-        it = iter(self.graphs)
+    def sequential(self, views=2):
+        """The model stacks its views along the batch (one graph per block over all views); the oracle runs the
+        views one after the other: re-order [block][view-stacked] -> view-major list of per-view graphs."""
+        if views == 1:
+            return list(self.graphs)
+        return [g.chunk(views, dim=0)[v].contiguous() for v in range(views) for g in self.graphs]
+
+    def replay_fn(self, views=2):
+        it = iter(self.sequential(views))
         self.flips = 0
 
         def idx_fn(x, k):
@@ -121,12 +128,13 @@ class CpuOps:
             return om.peak_extract({"peak_extractor.convs.0.weight": w, "peak_extractor.convs.0.bias": b}, spec, s)
 
         def bn_act(x, gamma, beta, rm, rv, training, momentum=0.1, eps=1e-5, pre_bias=None, residual=None, act=0,
-                   slope=0.0):
+                   slope=0.0, groups=1):
             C = x.shape[0]
             y = x.reshape(1, C, -1)
             if pre_bias is not None:
                 y = y + pre_bias.reshape(1, C, 1)
-            y = F.batch_norm(y, rm, rv, gamma, beta, training, momentum, eps).reshape(x.shape)
+            y = torch.cat([F.batch_norm(seg, rm, rv, gamma, beta, training, momentum, eps)
+                           for seg in y.chunk(groups, dim=2)], dim=2).reshape(x.shape)
             y = F.relu(y) if act == 1 else (F.leaky_relu(y, slope) if act == 2 else y)
             return y if residual is None else y + residual
         ops.knn_graph, ops.max_relative, ops.peak_extract, ops.bn_act = knn, maxrel, peak, bn_act
@@ -154,9 +162,14 @@ def reference_graphs(sd, xi, xj, train):
 
 
 class ReplayGraphs:
-    """TEST-ONLY: make grafp_amd.ops.knn_graph return pre-computed graphs (moved to the input's device)."""
+    """TEST-ONLY: make grafp_amd.ops.knn_graph return pre-computed graphs (moved to the input's device).
+    `views` > 1: `graphs` is the oracle's view-major list (all blocks of view 0, then view 1, ...); the model stacks
+    the views along the batch, so block b gets cat(view0[b], view1[b], ...)."""
 
-    def __init__(self, graphs):
+    def __init__(self, graphs, views=1):
+        if views > 1:
+            nb = len(graphs) // views
+            graphs = [torch.cat([graphs[v * nb + b] for v in range(views)], dim=0) for b in range(nb)]
         self.graphs = graphs
 
     def __enter__(self):

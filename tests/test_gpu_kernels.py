@@ -439,3 +439,35 @@ def test_conv1x1_wgrad_bf16(dev, cout, cin, groups, M):
     dense = torch.block_diag(*w.to(torch.bfloat16).double().reshape(groups, cout // groups, cin // groups).unbind(0))
     np.testing.assert_allclose(y.detach().float().cpu().numpy(), (dense @ xd).numpy(), rtol=2e-2, atol=2e-2)
     np.testing.assert_allclose(xg.grad.float().cpu().numpy(), (dense.t() @ gd).numpy(), rtol=2e-2, atol=3e-2)
+
+
+@pytest.mark.parametrize("C,M,G,dt", [(64, 8192, 2, "f32"), (256, 1536, 2, "f32"), (16, 3000, 3, "f32"), (128, 4096, 2, "bf16")])
+def test_bn_act_groups_equal_sequential_calls(dev, C, M, G, dt):
+    """groups=G (views stacked along the columns) == G separate calls on the column segments: same outputs, same
+    input gradients, parameter gradients = the sum, running statistics advanced once per view in order."""
+    from grafp_amd import ops
+    dtype = torch.float32 if dt == "f32" else torch.bfloat16
+    x = (t(hash_normalish(f"gpu:bng.x.{C}.{M}", (C, M))) * 1.5 + 3.0 * t(hash_uniform(f"gpu:bng.mu.{C}", (C, 1)))).to(dtype)
+    res = t(hash_normalish(f"gpu:bng.r.{C}.{M}", (C, M))).to(dtype)
+    gz = t(hash_normalish(f"gpu:bng.gz.{C}.{M}", (C, M))).to(dtype)
+    gamma = 1.0 + 0.2 * t(hash_uniform(f"gpu:bng.g.{C}", (C,))); beta = 0.3 * t(hash_uniform(f"gpu:bng.b.{C}", (C,)))
+    pb = 0.5 * t(hash_uniform(f"gpu:bng.pb.{C}", (C,)))
+    def run(groups):
+        xg = x.to(dev).requires_grad_(True); gg = gamma.to(dev).requires_grad_(True); bg = beta.to(dev).requires_grad_(True)
+        rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        if groups > 1:
+            out = ops.bn_act(xg, gg, bg, rm, rv, True, 0.1, 1e-5, pb.to(dev), res.to(dev), 1, 0.0, groups)
+        else:
+            segs = [ops.bn_act(xs.contiguous(), gg, bg, rm, rv, True, 0.1, 1e-5, pb.to(dev), rs.contiguous(), 1, 0.0)
+                    for xs, rs in zip(xg.chunk(G, dim=1), res.to(dev).chunk(G, dim=1))]
+            out = torch.cat(segs, dim=1)
+        out.backward(gz.to(dev))
+        return out.detach().float().cpu(), xg.grad.float().cpu(), gg.grad.cpu(), bg.grad.cpu(), rm.cpu(), rv.cpu()
+    a, b = run(G), run(1)
+    tol = dict(rtol=1e-5, atol=1e-5) if dt == "f32" else dict(rtol=2 ** -7, atol=2 ** -7)
+    np.testing.assert_allclose(a[0].numpy(), b[0].numpy(), **tol)
+    np.testing.assert_allclose(a[1].numpy(), b[1].numpy(), rtol=tol["rtol"], atol=tol["atol"] * float(b[1].abs().max()) + 1e-7)
+    for i in (2, 3):
+        np.testing.assert_allclose(a[i].numpy(), b[i].numpy(), rtol=2e-3 if dt == "bf16" else 1e-4, atol=1e-3 * float(b[i].abs().max()))
+    np.testing.assert_allclose(a[4].numpy(), b[4].numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(a[5].numpy(), b[5].numpy(), rtol=1e-5, atol=1e-6)

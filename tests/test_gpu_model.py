@@ -47,7 +47,7 @@ def test_simclr_forward_vs_oracle_with_equal_edges(dev):
         sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
         with RecordedGraphs() as rg, torch.no_grad():
             h_i, h_j, z_i, z_j = model(xi.to(dev), xj.to(dev))
-        assert len(rg.graphs) == 24
+        assert len(rg.graphs) == 12                 # one graph per block over the two stacked views
         with torch.no_grad():
             o = om.simclr_forward(sd, xi, xj, train, idx_fn=rg.replay_fn())
         for got, want in zip((h_i, h_j, z_i, z_j), o):
@@ -69,14 +69,14 @@ def test_simclr_forward_matches_reference_golden(dev):
     xi, xj = simclr_inputs()
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     model.train()
-    with ReplayGraphs(reference_graphs(sd, xi, xj, True)), torch.no_grad():
+    with ReplayGraphs(reference_graphs(sd, xi, xj, True), views=2), torch.no_grad():
         h_i, h_j, z_i, z_j = model(xi.to(dev), xj.to(dev))
     for got, want in ((z_i, g["z_i"]), (z_j, g["z_j"]), (h_i, g["h_i"]), (h_j, g["h_j"])):
         assert _rel_l2(got, want) <= 1e-4
     np.testing.assert_allclose(model.encoder.stem[1].running_mean.cpu().numpy(), g["stem_running_mean"], rtol=1e-5, atol=1e-6)
     model.eval()
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-    with ReplayGraphs(reference_graphs(sd, xi, xj, False)), torch.no_grad():
+    with ReplayGraphs(reference_graphs(sd, xi, xj, False), views=2), torch.no_grad():
         eh_i, _, ez_i, ez_j = model(xi.to(dev), xj.to(dev))
     # eval mode runs on the running statistics this model accumulated on the GPU (equal to the reference's only to
     # rounding), so the replayed graphs can differ from the golden run's by a near-tie: 5e-3 instead of 1e-4
@@ -135,7 +135,7 @@ def test_train_step_matches_reference_golden(dev):
     xi, xj = simclr_inputs()
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     opt.zero_grad()
-    with ReplayGraphs(reference_graphs(sd, xi, xj, True)):
+    with ReplayGraphs(reference_graphs(sd, xi, xj, True), views=2):
         _, _, z_i, z_j = model(xi.to(dev), xj.to(dev))
     loss = ntxent_loss(z_i, z_j, cfg)
     loss.backward()
@@ -266,6 +266,9 @@ def test_db_writers(dev, tmp_path):
         want = torch.cat([model.embed(aug(t.to(dev), None)[0])[1] for t in tracks]).cpu().numpy()
     np.testing.assert_allclose(np.asarray(dd), want, rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(fp, want, rtol=1e-5, atol=1e-6)
-    np.testing.assert_allclose(np.asarray(d), want, rtol=1e-5, atol=1e-6)
-    np.testing.assert_allclose(np.asarray(q), want, rtol=1e-5, atol=1e-6)     # identity augmentation
+    # create_fp_db embeds (x, x) as one stacked two-view batch: other GEMM shapes -> other rounding -> a near-tie
+    # neighbour may flip; each fingerprint still agrees to 5e-3 relative L2, and db == query row for row
+    for got in (np.asarray(d), np.asarray(q)):
+        assert (np.linalg.norm(got - want, axis=1) / np.linalg.norm(want, axis=1)).max() <= 5e-3
+    np.testing.assert_allclose(np.asarray(q), np.asarray(d), rtol=1e-5, atol=1e-6)     # identity augmentation
     np.testing.assert_allclose(np.linalg.norm(want, axis=1), 1.0, rtol=1e-5)

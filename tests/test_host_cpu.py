@@ -132,7 +132,7 @@ def test_dense_part_of_the_model_matches_the_oracle_on_cpu():
     gn = max(float(osd[k].grad.norm()) for k in P if P[k].requires_grad)
     rel = [float((P[k].grad - osd[k].grad).norm()) / max(float(osd[k].grad.norm()), 1e-4 * gn)
            for k in P if P[k].requires_grad]
-    assert max(rel) < 5e-2 and np.median(rel) < 5e-3, (max(rel), np.median(rel))
+    assert max(rel) < 5e-2 and np.median(rel) < 1e-2, (max(rel), np.median(rel))
 
 
 def test_sequence_rerank_matches_oracle():
