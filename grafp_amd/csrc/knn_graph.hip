@@ -143,9 +143,9 @@ __device__ __forceinline__ void stage_tile(float (*dst)[TR], const float *__rest
     }
 }
 
-template <int K>
+template <int K, typename I>
 __global__ __launch_bounds__(256, 2) void knn_topk_kernel(const float *__restrict__ xn, const float *__restrict__ sq,
-                                                          int64_t *__restrict__ idx, int C, int N,
+                                                          I *__restrict__ idx, int C, int N,
                                                           int tiles_per_clip, int nblocks) {
     __shared__ __attribute__((aligned(16))) float sA[KC][TR];  // candidates
     __shared__ __attribute__((aligned(16))) float sB[KC][TQ];  // queries
@@ -207,17 +207,17 @@ __global__ __launch_bounds__(256, 2) void knn_topk_kernel(const float *__restric
 #pragma unroll
     for (int t = 0; t < K; ++t) best.push_lex(od[t], oi[t]);
     if (half == 0 && myq < N) {
-        int64_t *o = idx + ((size_t)b * N + myq) * K;
+        I *o = idx + ((size_t)b * N + myq) * K;
 #pragma unroll
-        for (int t = 0; t < K; ++t) o[t] = (int64_t)best.i[t];
+        for (int t = 0; t < K; ++t) o[t] = (I)best.i[t];
     }
 }
 
-template <int K>
-static void launch_topk(const float *xn, const float *sq, int64_t *idx, int B, int C, int N, hipStream_t s) {
+template <int K, typename I>
+static void launch_topk(const float *xn, const float *sq, I *idx, int B, int C, int N, hipStream_t s) {
     const int tiles = (N + TQ - 1) / TQ;
     const int nblocks = B * tiles;
-    hipLaunchKernelGGL(knn_topk_kernel<K>, dim3(nblocks), dim3(256), 0, s, xn, sq, idx, C, N, tiles, nblocks);
+    hipLaunchKernelGGL((knn_topk_kernel<K, I>), dim3(nblocks), dim3(256), 0, s, xn, sq, idx, C, N, tiles, nblocks);
 }
 
 }  // namespace grafp
@@ -229,17 +229,18 @@ extern "C" size_t grafp_knn_graph_workspace(int B, int C, int N) {
     return xn + sq;
 }
 
-static int knn_topk_launch(const float *xn, const float *sq, int B, int C, int N, int k, int64_t *idx, hipStream_t s) {
+template <typename I>
+static int knn_topk_launch(const float *xn, const float *sq, int B, int C, int N, int k, I *idx, hipStream_t s) {
     using namespace grafp;
     switch (k) {
-        case 1: launch_topk<1>(xn, sq, idx, B, C, N, s); break;
-        case 2: launch_topk<2>(xn, sq, idx, B, C, N, s); break;
-        case 3: launch_topk<3>(xn, sq, idx, B, C, N, s); break;
-        case 4: launch_topk<4>(xn, sq, idx, B, C, N, s); break;
-        case 5: launch_topk<5>(xn, sq, idx, B, C, N, s); break;
-        case 6: launch_topk<6>(xn, sq, idx, B, C, N, s); break;
-        case 7: launch_topk<7>(xn, sq, idx, B, C, N, s); break;
-        default: launch_topk<8>(xn, sq, idx, B, C, N, s); break;
+        case 1: launch_topk<1, I>(xn, sq, idx, B, C, N, s); break;
+        case 2: launch_topk<2, I>(xn, sq, idx, B, C, N, s); break;
+        case 3: launch_topk<3, I>(xn, sq, idx, B, C, N, s); break;
+        case 4: launch_topk<4, I>(xn, sq, idx, B, C, N, s); break;
+        case 5: launch_topk<5, I>(xn, sq, idx, B, C, N, s); break;
+        case 6: launch_topk<6, I>(xn, sq, idx, B, C, N, s); break;
+        case 7: launch_topk<7, I>(xn, sq, idx, B, C, N, s); break;
+        default: launch_topk<8, I>(xn, sq, idx, B, C, N, s); break;
     }
     GRAFP_CHECK_LAUNCH("knn_topk_kernel");
     return GRAFP_OK;
@@ -280,7 +281,13 @@ extern "C" int grafp_knn_normalize_f32(const float *x, int B, int C, int N, int 
 extern "C" int grafp_knn_topk_f32(const float *xn, const float *sq, int B, int C, int N, int k, int64_t *idx,
                                   grafp_stream_t stream) {
     if (!knn_args_ok(xn, idx, B, C, N, k) || !knn_args_ok(sq, idx, B, C, N, k)) return GRAFP_ERR_ARG;
-    return knn_topk_launch(xn, sq, B, C, N, k, idx, (hipStream_t)stream);
+    return knn_topk_launch<int64_t>(xn, sq, B, C, N, k, idx, (hipStream_t)stream);
+}
+
+extern "C" int grafp_knn_topk_i32(const float *xn, const float *sq, int B, int C, int N, int k, int32_t *idx,
+                                  grafp_stream_t stream) {
+    if (!knn_args_ok(xn, idx, B, C, N, k) || !knn_args_ok(sq, idx, B, C, N, k)) return GRAFP_ERR_ARG;
+    return knn_topk_launch<int32_t>(xn, sq, B, C, N, k, idx, (hipStream_t)stream);
 }
 
 extern "C" int grafp_knn_graph_f32(const float *x, int B, int C, int N, int k, int normalize, int64_t *idx, void *ws,

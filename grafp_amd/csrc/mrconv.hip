@@ -68,14 +68,15 @@ __device__ __forceinline__ void mr_st4(unsigned short *p, const float (&v)[4]) {
         while (n >= (N)) { n -= (N); ++c; }         \
     } while (0)
 
-__device__ __forceinline__ void stage_idx(int *sidx, const int64_t *__restrict__ idxb, int N, int K, int tid) {
+template <typename I>
+__device__ __forceinline__ void stage_idx(int *sidx, const I *__restrict__ idxb, int N, int K, int tid) {
     for (int n = tid; n < N; n += MR_THREADS)
-        for (int k = 0; k < K; ++k) sidx[k * N + n] = clampi(idxb[(size_t)n * K + k], N);
+        for (int k = 0; k < K; ++k) sidx[k * N + n] = clampi((int64_t)idxb[(size_t)n * K + k], N);
 }
 
-template <typename T, int V>
+template <typename T, int V, typename I>
 __global__ __launch_bounds__(MR_THREADS) void mrconv_fwd_kernel(const T *__restrict__ x, int64_t x_sb, int64_t x_sc,
-                                                                const int64_t *__restrict__ idx, T *__restrict__ out,
+                                                                const I *__restrict__ idx, T *__restrict__ out,
                                                                 int64_t o_sb, int64_t o_sc, int C, int N, int K,
                                                                 int CC) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(MR_THREADS) void mrconv_fwd_kernel(const T *__restr
             MR_NEXT(V, N, c, n);
         }
     }
-    stage_idx(sidx, idx + (size_t)b * N * K, N, K, tid);
+    stage_idx<I>(sidx, idx + (size_t)b * N * K, N, K, tid);
     __syncthreads();
 
     T *ob = out + (size_t)b * o_sb + (size_t)(2 * c0) * o_sc;
@@ -123,11 +124,11 @@ __global__ __launch_bounds__(MR_THREADS) void mrconv_fwd_kernel(const T *__restr
 
 // BWD_ITEMS * 256 * V elements per workgroup: the odd-channel gradients stay in registers between the
 // accumulator initialisation and the scatter phase.
-constexpr int BWD_ITEMS = 4;
+constexpr int BWD_ITEMS = 8;
 
-template <typename T, int V>
+template <typename T, int V, typename I>
 __global__ __launch_bounds__(MR_THREADS) void mrconv_bwd_kernel(const T *__restrict__ x, int64_t x_sb, int64_t x_sc,
-                                                                const int64_t *__restrict__ idx,
+                                                                const I *__restrict__ idx,
                                                                 const T *__restrict__ gout, int64_t g_sb, int64_t g_sc,
                                                                 T *__restrict__ dx, int C, int N, int K, int CC) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(MR_THREADS) void mrconv_bwd_kernel(const T *__restr
             MR_NEXT(V, N, c, n);
         }
     }
-    stage_idx(sidx, idx + (size_t)b * N * K, N, K, tid);
+    stage_idx<I>(sidx, idx + (size_t)b * N * K, N, K, tid);
     __syncthreads();
     {   // route g_odd[c][m] to the arg-max neighbour of m (first maximum)
         MR_WALK(V, tid, N, c, n);
@@ -212,9 +213,8 @@ static int pick_cc(int C, int N, int target_elems) {
 
 }  // namespace grafp
 
-extern "C" int grafp_mrconv_fwd_strided(const void *x, int dtype, int64_t x_sb, int64_t x_sc, const int64_t *idx, int B,
-                                        int C, int N, int K, void *out, int64_t o_sb, int64_t o_sc,
-                                        grafp_stream_t stream) {
+static int mrconv_fwd_impl(const void *x, int dtype, int64_t x_sb, int64_t x_sc, const void *idx, int idx32, int B,
+                           int C, int N, int K, void *out, int64_t o_sb, int64_t o_sc, grafp_stream_t stream) {
     using namespace grafp;
     GRAFP_REQUIRE(x && idx && out, "mrconv_fwd: null pointer");
     GRAFP_REQUIRE(B > 0 && C > 0 && N > 0 && K > 0, "mrconv_fwd: bad shape B=%d C=%d N=%d K=%d", B, C, N, K);
@@ -226,21 +226,24 @@ extern "C" int grafp_mrconv_fwd_strided(const void *x, int dtype, int64_t x_sb, 
     const size_t es = dtype == GRAFP_F32 ? 4 : 2;
     const bool v4 = (N % 4 == 0) && (x_sb % 4 == 0) && (x_sc % 4 == 0) && (o_sb % 4 == 0) && (o_sc % 4 == 0) &&
                     ((uintptr_t)x % (4 * es) == 0) && ((uintptr_t)out % (4 * es) == 0);
-#define MR_FWD(T, V)                                                                                                   \
-    (void)hipFuncSetAttribute((const void *)mrconv_fwd_kernel<T, V>, hipFuncAttributeMaxDynamicSharedMemorySize,       \
+#define MR_FWD_I(T, V, I)                                                                                              \
+    (void)hipFuncSetAttribute((const void *)mrconv_fwd_kernel<T, V, I>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
                               (int)lds);                                                                               \
-    hipLaunchKernelGGL((mrconv_fwd_kernel<T, V>), grid, dim3(MR_THREADS), lds, (hipStream_t)stream, (const T *)x, x_sb,  \
-                       x_sc, idx, (T *)out, o_sb, o_sc, C, N, K, CC)
+    hipLaunchKernelGGL((mrconv_fwd_kernel<T, V, I>), grid, dim3(MR_THREADS), lds, (hipStream_t)stream, (const T *)x,   \
+                       x_sb, x_sc, (const I *)idx, (T *)out, o_sb, o_sc, C, N, K, CC)
+#define MR_FWD(T, V)                                                                                                   \
+    if (idx32) { MR_FWD_I(T, V, int32_t); } else { MR_FWD_I(T, V, int64_t); }
     if (dtype == GRAFP_F32) { if (v4) { MR_FWD(float, 4); } else { MR_FWD(float, 1); } }
     else { if (v4) { MR_FWD(unsigned short, 4); } else { MR_FWD(unsigned short, 1); } }
 #undef MR_FWD
+#undef MR_FWD_I
     GRAFP_CHECK_LAUNCH("mrconv_fwd_kernel");
     return GRAFP_OK;
 }
 
-extern "C" int grafp_mrconv_bwd_strided(const void *x, int dtype, int64_t x_sb, int64_t x_sc, const int64_t *idx,
-                                        const void *grad_out, int64_t g_sb, int64_t g_sc, int B, int C, int N, int K,
-                                        void *dx, grafp_stream_t stream) {
+static int mrconv_bwd_impl(const void *x, int dtype, int64_t x_sb, int64_t x_sc, const void *idx, int idx32,
+                           const void *grad_out, int64_t g_sb, int64_t g_sc, int B, int C, int N, int K, void *dx,
+                           grafp_stream_t stream) {
     using namespace grafp;
     GRAFP_REQUIRE(x && idx && grad_out && dx, "mrconv_bwd: null pointer");
     GRAFP_REQUIRE(B > 0 && C > 0 && N > 0 && K > 0, "mrconv_bwd: bad shape B=%d C=%d N=%d K=%d", B, C, N, K);
@@ -257,16 +260,40 @@ extern "C" int grafp_mrconv_bwd_strided(const void *x, int dtype, int64_t x_sb, 
     const size_t lds = ((size_t)2 * CC * N + (size_t)K * N) * 4;
     GRAFP_REQUIRE(lds <= 160 * 1024, "mrconv_bwd: N=%d K=%d needs %zu B of LDS (> 160 KiB)", N, K, lds);
     const dim3 grid((C + CC - 1) / CC, B);
-#define MR_BWD(T, V)                                                                                                   \
-    (void)hipFuncSetAttribute((const void *)mrconv_bwd_kernel<T, V>, hipFuncAttributeMaxDynamicSharedMemorySize,       \
+#define MR_BWD_I(T, V, I)                                                                                              \
+    (void)hipFuncSetAttribute((const void *)mrconv_bwd_kernel<T, V, I>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
                               (int)lds);                                                                               \
-    hipLaunchKernelGGL((mrconv_bwd_kernel<T, V>), grid, dim3(MR_THREADS), lds, (hipStream_t)stream, (const T *)x, x_sb,  \
-                       x_sc, idx, (const T *)grad_out, g_sb, g_sc, (T *)dx, C, N, K, CC)
+    hipLaunchKernelGGL((mrconv_bwd_kernel<T, V, I>), grid, dim3(MR_THREADS), lds, (hipStream_t)stream, (const T *)x,   \
+                       x_sb, x_sc, (const I *)idx, (const T *)grad_out, g_sb, g_sc, (T *)dx, C, N, K, CC)
+#define MR_BWD(T, V)                                                                                                   \
+    if (idx32) { MR_BWD_I(T, V, int32_t); } else { MR_BWD_I(T, V, int64_t); }
     if (dtype == GRAFP_F32) { if (v4) { MR_BWD(float, 4); } else { MR_BWD(float, 1); } }
     else { if (v4) { MR_BWD(unsigned short, 4); } else { MR_BWD(unsigned short, 1); } }
 #undef MR_BWD
+#undef MR_BWD_I
     GRAFP_CHECK_LAUNCH("mrconv_bwd_kernel");
     return GRAFP_OK;
+}
+
+extern "C" int grafp_mrconv_fwd_strided(const void *x, int dtype, int64_t x_sb, int64_t x_sc, const int64_t *idx, int B,
+                                        int C, int N, int K, void *out, int64_t o_sb, int64_t o_sc,
+                                        grafp_stream_t stream) {
+    return mrconv_fwd_impl(x, dtype, x_sb, x_sc, idx, 0, B, C, N, K, out, o_sb, o_sc, stream);
+}
+extern "C" int grafp_mrconv_fwd_strided_i32(const void *x, int dtype, int64_t x_sb, int64_t x_sc, const int32_t *idx,
+                                            int B, int C, int N, int K, void *out, int64_t o_sb, int64_t o_sc,
+                                            grafp_stream_t stream) {
+    return mrconv_fwd_impl(x, dtype, x_sb, x_sc, idx, 1, B, C, N, K, out, o_sb, o_sc, stream);
+}
+extern "C" int grafp_mrconv_bwd_strided(const void *x, int dtype, int64_t x_sb, int64_t x_sc, const int64_t *idx,
+                                        const void *grad_out, int64_t g_sb, int64_t g_sc, int B, int C, int N, int K,
+                                        void *dx, grafp_stream_t stream) {
+    return mrconv_bwd_impl(x, dtype, x_sb, x_sc, idx, 0, grad_out, g_sb, g_sc, B, C, N, K, dx, stream);
+}
+extern "C" int grafp_mrconv_bwd_strided_i32(const void *x, int dtype, int64_t x_sb, int64_t x_sc, const int32_t *idx,
+                                            const void *grad_out, int64_t g_sb, int64_t g_sc, int B, int C, int N,
+                                            int K, void *dx, grafp_stream_t stream) {
+    return mrconv_bwd_impl(x, dtype, x_sb, x_sc, idx, 1, grad_out, g_sb, g_sc, B, C, N, K, dx, stream);
 }
 
 extern "C" int grafp_mrconv_fwd_f32(const float *x, const int64_t *idx, int B, int C, int N, int K, float *out,

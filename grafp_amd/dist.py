@@ -80,14 +80,20 @@ class GradSync:
     so the per-rank parameter gradients are the disjoint terms of the full gradient, exactly what
     DataParallel's reduce-to-GPU-0 adds up (train.py:165-168)."""
 
-    def __init__(self, params, group=None, n_buckets=4, overlap=True):
+    def __init__(self, params, group=None, n_buckets=4, overlap=True, force_flat=False):
         self.group = group
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
         dev, total = self.params[0].device, sum(p.numel() for p in self.params)
-        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         self.world = world_size(group)
+        self.flat = None
+        if self.world == 1 and not force_flat:
+            # nothing to reduce: let autograd ASSIGN fresh gradients (zero() drops them) instead of launching one
+            # tiny accumulate kernel per parameter into pre-existing views
+            self.bounds, self._hooks, self._handles = [], [], []
+            return
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         # gradients become ready roughly in reverse registration order: lay the buffer out that way so
         # every bucket is a contiguous slice that completes early
         order = list(reversed(self.params))
@@ -114,7 +120,11 @@ class GradSync:
 
     def zero(self):
         """Use instead of optimizer.zero_grad(): keeps every .grad a view of the flat buffer."""
-        self.flat.zero_()
+        if self.flat is None:
+            for p in self.params:
+                p.grad = None
+        else:
+            self.flat.zero_()
 
     def _launch(self, b):
         lo, hi = self.bounds[b]
@@ -129,6 +139,8 @@ class GradSync:
 
     def finish(self):
         """Call after backward(): launches whatever has not fired, waits for all buckets."""
+        if self.flat is None:
+            return
         if self.world > 1:
             for b in range(len(self.bounds)):
                 if not self._fired[b]:

@@ -47,11 +47,11 @@ class DenseDilatedKnnGraph(nn.Module):
         self.k, self.dilation, self.stochastic, self.epsilon = k, dilation, stochastic, epsilon
         self._dilated = DenseDilated(k, dilation, stochastic, epsilon)
 
-    def neighbours(self, x, layout="bcn"):
+    def neighbours(self, x, layout="bcn", index_dtype=torch.int64):
         """(B,C,N[,1]) ['bcn'] or (C,B,N) ['cbn'] -> int64 (B,N,k): the neighbour half of the edge index
         (centres are arange)."""
         with torch.no_grad():
-            idx = ops.knn_graph(x, self.k * self.dilation, normalize=True, layout=layout)
+            idx = ops.knn_graph(x, self.k * self.dilation, normalize=True, layout=layout, index_dtype=index_dtype)
         if self.dilation > 1 or self.stochastic:
             idx = self._dilated(idx.unsqueeze(0)).squeeze(0).contiguous()
         return idx

@@ -57,7 +57,10 @@ class DyGraphConv2d(GraphConv2d):
         self.dilated_knn_graph = DenseDilatedKnnGraph(kernel_size, dilation, stochastic, epsilon)
 
     def forward_cbn(self, x, groups=1):
-        return self.gconv.aggregate_cbn(x, self.dilated_knn_graph.neighbours(x, layout="cbn"), groups)
+        # edges stay in the compact int32 format between the two graph kernels (the int64 (2,B,N,k) edge_index of the
+        # reference is only materialised by the public forward())
+        idx = self.dilated_knn_graph.neighbours(x, layout="cbn", index_dtype=torch.int32)
+        return self.gconv.aggregate_cbn(x, idx, groups)
 
     def forward(self, x, relative_pos=None):
         shape = x.shape

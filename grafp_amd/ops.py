@@ -223,7 +223,7 @@ def _act_view(x, layout):
     return x, B, C, N, N, B * N
 
 
-def knn_graph(x, k, normalize=True, layout="bcn"):
+def knn_graph(x, k, normalize=True, layout="bcn", index_dtype=torch.int64):
     """x (B,C,N) / (B,C,N,1) [layout 'bcn'] or (C,B,N) [layout 'cbn'], f32 or bf16 -> int64 (B,N,k)
     nearest-neighbour indices (ascending distance, ties to the lowest index).  Non-differentiable, as in the
     reference (torch_edge.py:78 `no_grad`).  bf16 inputs are widened exactly; all arithmetic is f32."""
@@ -231,14 +231,15 @@ def knn_graph(x, k, normalize=True, layout="bcn"):
     if x.dim() == 4:
         x = x.squeeze(-1)
     x, B, C, N, sb, sc = _act_view(x.detach(), layout)
-    idx = torch.empty((B, N, k), dtype=torch.int64, device=x.device)
+    idx = torch.empty((B, N, k), dtype=index_dtype, device=x.device)
     xn = torch.empty((B, C, N), dtype=torch.float32, device=x.device)
     sq = torch.empty((B, N), dtype=torch.float32, device=x.device)
     with _timed("knn_normalize", (B, C, N, k)):
         check(lib.grafp_knn_normalize_strided(_p(x), _DT[x.dtype], sb, sc, B, C, N, int(bool(normalize)), _p(xn),
                                               _p(sq), _stream()), "knn_normalize")
     with _timed("knn_topk", (B, C, N, k)):
-        check(lib.grafp_knn_topk_f32(_p(xn), _p(sq), B, C, N, k, _p(idx), _stream()), "knn_topk")
+        topk = lib.grafp_knn_topk_i32 if index_dtype == torch.int32 else lib.grafp_knn_topk_f32
+        check(topk(_p(xn), _p(sq), B, C, N, k, _p(idx), _stream()), "knn_topk")
     return idx
 
 
@@ -250,15 +251,15 @@ class _MaxRelative(torch.autograd.Function):
     def forward(ctx, x, idx, layout):
         _require_gpu(x, idx)
         x, B, C, N, sb, sc = _act_view(x.detach(), layout)
-        idx = idx.to(torch.int64).contiguous()
+        idx = (idx if idx.dtype == torch.int32 else idx.to(torch.int64)).contiguous()
         K = idx.shape[-1]
         if tuple(idx.shape) != (B, N, K):
             raise ValueError(f"idx shape {tuple(idx.shape)} does not match activations B={B} N={N}")
+        fwd = lib.grafp_mrconv_fwd_strided_i32 if idx.dtype == torch.int32 else lib.grafp_mrconv_fwd_strided
         out = torch.empty((B, 2 * C, N) if layout == "bcn" else (2 * C, B, N), dtype=x.dtype, device=x.device)
         o_sb, o_sc = (2 * C * N, N) if layout == "bcn" else (N, B * N)
         with _timed("mrconv_fwd", (B, C, N, K)):
-            check(lib.grafp_mrconv_fwd_strided(_p(x), _DT[x.dtype], sb, sc, _p(idx), B, C, N, K, _p(out), o_sb, o_sc,
-                                               _stream()), "mrconv_fwd")
+            check(fwd(_p(x), _DT[x.dtype], sb, sc, _p(idx), B, C, N, K, _p(out), o_sb, o_sc, _stream()), "mrconv_fwd")
         ctx.save_for_backward(x, idx)
         ctx.layout = layout
         return out
@@ -273,8 +274,8 @@ class _MaxRelative(torch.autograd.Function):
         g_sb, g_sc = (2 * C * N, N) if layout == "bcn" else (N, B * N)
         dx = torch.empty_like(x)
         with _timed("mrconv_bwd", (B, C, N, K)):
-            check(lib.grafp_mrconv_bwd_strided(_p(x), _DT[x.dtype], sb, sc, _p(idx), _p(g), g_sb, g_sc, B, C, N, K,
-                                               _p(dx), _stream()), "mrconv_bwd")
+            bwd = lib.grafp_mrconv_bwd_strided_i32 if idx.dtype == torch.int32 else lib.grafp_mrconv_bwd_strided
+            check(bwd(_p(x), _DT[x.dtype], sb, sc, _p(idx), _p(g), g_sb, g_sc, B, C, N, K, _p(dx), _stream()), "mrconv_bwd")
         return dx, None, None
 
 

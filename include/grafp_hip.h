@@ -96,6 +96,10 @@ int grafp_knn_normalize_f32(const float *x, int B, int C, int N, int normalize, 
                             grafp_stream_t stream);
 int grafp_knn_topk_f32(const float *xn, const float *sq, int B, int C, int N, int k, int64_t *idx,
                        grafp_stream_t stream);
+/* topk writing the compact int32 edge format the graph kernels also accept (halves the index traffic of the
+ * gather kernels, which re-read the edges once per channel slab) */
+int grafp_knn_topk_i32(const float *xn, const float *sq, int B, int C, int N, int k, int32_t *idx,
+                       grafp_stream_t stream);
 /* normalize pass reading any (b,c)-strided view with N contiguous: element (b,c,n) at x + b*stride_b + c*stride_c + n
  * (elements of `dtype`), e.g. the GEMM-friendly (C,B,N) layout (stride_b = N, stride_c = B*N). */
 int grafp_knn_normalize_strided(const void *x, int dtype, int64_t stride_b, int64_t stride_c, int B, int C, int N,
@@ -121,6 +125,12 @@ int grafp_mrconv_fwd_strided(const void *x, int dtype, int64_t x_sb, int64_t x_s
 int grafp_mrconv_bwd_strided(const void *x, int dtype, int64_t x_sb, int64_t x_sc, const int64_t *idx,
                              const void *grad_out, int64_t g_sb, int64_t g_sc, int B, int C, int N, int K, void *dx,
                              grafp_stream_t stream);
+
+int grafp_mrconv_fwd_strided_i32(const void *x, int dtype, int64_t x_sb, int64_t x_sc, const int32_t *idx, int B, int C,
+                                 int N, int K, void *out, int64_t o_sb, int64_t o_sc, grafp_stream_t stream);
+int grafp_mrconv_bwd_strided_i32(const void *x, int dtype, int64_t x_sb, int64_t x_sc, const int32_t *idx,
+                                 const void *grad_out, int64_t g_sb, int64_t g_sc, int B, int C, int N, int K,
+                                 void *dx, grafp_stream_t stream);
 
 /* ---- K8/K9 glue: fused [conv bias] + BatchNorm + activation + residual on the (C, M = B*N) layout ----
  * Replaces the `+ bias` -> BatchNorm2d -> ReLU/LeakyReLU -> `+ shortcut` chains around every 1x1 convolution

@@ -70,9 +70,9 @@ class RecordedGraphs:
         from grafp_amd import ops
         self._ops, self._orig, self.graphs = ops, ops.knn_graph, []
 
-        def rec(x, k, normalize=True, layout="bcn"):
-            idx = self._orig(x, k, normalize, layout)
-            self.graphs.append(idx.cpu())
+        def rec(x, k, normalize=True, layout="bcn", index_dtype=torch.int64):
+            idx = self._orig(x, k, normalize, layout, index_dtype)
+            self.graphs.append(idx.cpu().long())
             return idx
         ops.knn_graph = rec
         return self
@@ -115,13 +115,13 @@ class CpuOps:
         def bcn(x, layout):
             return x if layout == "bcn" else x.permute(1, 0, 2)
 
-        def knn(x, k, normalize=True, layout="bcn"):
+        def knn(x, k, normalize=True, layout="bcn", index_dtype=torch.int64):
             if x.dim() == 4:
                 x = x.squeeze(-1)
-            return om.knn_graph_torch(bcn(x, layout).float(), k)
+            return om.knn_graph_torch(bcn(x, layout).float(), k).to(index_dtype)
 
         def maxrel(x, idx, layout="bcn"):
-            out = om.max_relative(bcn(x, layout), idx)
+            out = om.max_relative(bcn(x, layout), idx.long())
             return out if layout == "bcn" else out.permute(1, 0, 2).contiguous()
 
         def peak(spec, w, b, s):
@@ -175,7 +175,8 @@ class ReplayGraphs:
     def __enter__(self):
         from grafp_amd import ops
         self._ops, self._orig, it = ops, ops.knn_graph, iter(self.graphs)
-        ops.knn_graph = lambda x, k, normalize=True, layout="bcn": next(it).to(x.device)
+        ops.knn_graph = lambda x, k, normalize=True, layout="bcn", index_dtype=torch.int64: next(it).to(
+            x.device, dtype=index_dtype)
         return self
 
     def __exit__(self, *exc):
