@@ -12,6 +12,8 @@
 // matrix rate (157.3 TFLOP/s), not HBM.  See DESIGN.md "knn_topk_kernel".
 #include <math.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace grafp {
@@ -119,9 +121,13 @@ struct TopK {
     }
 };
 
-// Stage a KC x 128 tile of xn (channels c0.., nodes n0..) into LDS; zero-fill outside (C, N).
-__device__ __forceinline__ void stage_tile(float (*dst)[TR], const float *__restrict__ xb, int C, int N, int c0,
-                                           int n0, int tid, bool vec_ok) {
+// One KC x 128 tile of xn (channels c0.., nodes n0..), 4 float4 per thread, zero-filled outside (C, N):
+// fetched to registers first (so the loads fly under the MFMAs of the previous chunk), written to LDS later.
+struct TileRegs {
+    float4 v[(KC * TR / 4) / 256];
+};
+__device__ __forceinline__ void fetch_tile(TileRegs &t, const float *__restrict__ xb, int C, int N, int c0, int n0,
+                                           int tid, bool vec_ok) {
 #pragma unroll
     for (int it = 0; it < (KC * TR / 4) / 256; ++it) {
         const int i = tid + it * 256;
@@ -139,17 +145,30 @@ __device__ __forceinline__ void stage_tile(float (*dst)[TR], const float *__rest
                 if (n + 3 < N) v.w = src[3];
             }
         }
-        *reinterpret_cast<float4 *>(&dst[row][c4 * 4]) = v;
+        t.v[it] = v;
+    }
+}
+__device__ __forceinline__ void store_tile(float *dst, const TileRegs &t, int tid) {
+#pragma unroll
+    for (int it = 0; it < (KC * TR / 4) / 256; ++it) {
+        const int i = tid + it * 256;
+        *reinterpret_cast<float4 *>(dst + (i / (TR / 4)) * TR + (i % (TR / 4)) * 4) = t.v[it];
     }
 }
 
-template <int K, typename I>
+// dynamic LDS: sA[2][KC][TR] | sB[2][KC][TQ] | sSq[3][TR]   (66 KB: two workgroups per CU)
+constexpr int KNN_LDS_FLOATS = 2 * KC * TR + 2 * KC * TQ + 3 * TR;
+
+// PIPE (C a multiple of 2*KC = 64, i.e. every stage of the encoder): chunks are processed in unrolled PAIRS and the
+// top-k insertion of candidate block i-1 (64 distances per lane, ~30 % of the work at C = 64) is spread over the
+// 32 MFMA steps of the first chunk pair of block i, so the VALU work runs in the shadow of the matrix pipe.
+// !PIPE: any C, insertion after each block.
+template <int K, typename I, bool PIPE>
 __global__ __launch_bounds__(256, 2) void knn_topk_kernel(const float *__restrict__ xn, const float *__restrict__ sq,
-                                                          I *__restrict__ idx, int C, int N,
-                                                          int tiles_per_clip, int nblocks) {
-    __shared__ __attribute__((aligned(16))) float sA[KC][TR];  // candidates
-    __shared__ __attribute__((aligned(16))) float sB[KC][TQ];  // queries
-    __shared__ float sSq[TR];
+                                                          I *__restrict__ idx, int C, int N, int tiles_per_clip,
+                                                          int nblocks) {
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    float *sA = smem_f, *sB = smem_f + 2 * KC * TR, *sSq = smem_f + 2 * KC * TR + 2 * KC * TQ;
 
     const int bid = xcd_remap(blockIdx.x, nblocks);
     const int b = bid / tiles_per_clip;
@@ -164,36 +183,145 @@ __global__ __launch_bounds__(256, 2) void knn_topk_kernel(const float *__restric
     TopK<K> best;
     best.init();
 
-    for (int r0 = 0; r0 < N; r0 += TR) {
-        f32x16 acc[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    const int nch = (C + KC - 1) / KC;
+    const int nblk = (N + TR - 1) / TR;
+    const int T = nblk * nch;
 
-        for (int c0 = 0; c0 < C; c0 += KC) {
-            __syncthreads();  // previous chunk (and previous pass's sSq) fully consumed
-            stage_tile(sA, xb, C, N, c0, r0, tid, vec_ok);
-            stage_tile(sB, xb, C, N, c0, q0, tid, vec_ok);
-            if (c0 == 0 && tid < TR) sSq[tid] = (r0 + tid < N) ? sqb[r0 + tid] : INFINITY;
-            __syncthreads();
-#pragma unroll 4
-            for (int kk = 0; kk < KC; kk += 2) {
-                const float bq = sB[kk + half][wave * 32 + l31];
+    f32x16 acc[4], prev[4];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc[t] = mfma32x32x2(sA[kk + half][t * 32 + l31], bq, acc[t]);
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[t][r] = 0.0f; prev[t][r] = 0.0f; }
+
+    // distance of element e (tile e/16, register e%16) of a finished block; +inf beyond N: never inserted.
+    // fmaf(-2, g, sq_q) == sq_q + (-2*g) exactly (the product is exact), i.e. the oracle's (sq_i + (-2 g)) + sq_j.
+    auto insert = [&](const f32x16 (&a)[4], int e, int sq_base, int idx_base) {
+        const int loc = (e >> 4) * 32 + mfma_row(e & 15, half);
+        const float d = __builtin_fmaf(-2.0f, a[e >> 4][e & 15], sq_q) + sSq[sq_base + loc];
+        best.push_ascending(d, idx_base + loc);
+    };
+    auto stage_next = [&](TileRegs &ra, TileRegs &rb, int t1) {   // write chunk t1 (already in registers) to LDS
+        const int blk1 = t1 / nch, ch1 = t1 - blk1 * nch;
+        int off = (t1 & 1) * KC * TR;
+        asm volatile("" : "+v"(off));
+        store_tile(sA + off, ra, tid);
+        store_tile(sB + off, rb, tid);
+        if (ch1 == 0 && tid < TR) {
+            const int n = blk1 * TR + tid;
+            sSq[(blk1 % 3) * TR + tid] = (n < N) ? sqb[n] : INFINITY;
+        }
+    };
+    auto fetch_next = [&](TileRegs &ra, TileRegs &rb, int t1) {
+        const int blk1 = t1 / nch, ch1 = t1 - blk1 * nch;
+        // opaque offsets: otherwise unrolled copies keep their own pre-computed addresses live (spills)
+        int c_off = ch1 * KC, n_off = blk1 * TR;
+        asm volatile("" : "+v"(c_off), "+v"(n_off));
+        fetch_tile(ra, xb, C, N, c_off, n_off, tid, vec_ok);
+        fetch_tile(rb, xb, C, N, c_off, q0, tid, vec_ok);
+    };
+
+    if (PIPE) {
+        // Tiles arrive by LDS-DMA (global_load_lds_dwordx4: no staging VGPRs, no ds_write pass).  One wave
+        // instruction moves 1 KiB = two 128-float channel rows (lanes 0-31 row r, lanes 32-63 row r+1) to a
+        // wave-uniform, lane-linear LDS destination -- exactly the [KC][128] tile layout.  Shapes are exact
+        // multiples here (C % 64 == 0, N % 128 == 0), so no bounds are needed.  The DMA of chunk t+1 is issued
+        // before chunk t is consumed and is drained by the barrier that ends chunk t.
+        typedef const void __attribute__((address_space(1))) *gptr_t;
+        typedef void __attribute__((address_space(3))) *lptr_t;
+        auto dma_chunk = [&](int t1) {
+            const int blk1 = t1 / nch, ch1 = t1 - blk1 * nch;
+            int off = (t1 & 1) * KC * TR;
+            asm volatile("" : "+v"(off));
+            const float *src = xb + (size_t)(ch1 * KC + half) * N + l31 * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = wave * 8 + 2 * i;
+                __builtin_amdgcn_global_load_lds((gptr_t)(src + (size_t)row * N + blk1 * TR), (lptr_t)(sA + off + row * TR),
+                                                 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(src + (size_t)row * N + q0), (lptr_t)(sB + off + row * TR), 16, 0,
+                                                 0);
+            }
+            if (ch1 == 0 && tid < TR) sSq[(blk1 % 3) * TR + tid] = sqb[blk1 * TR + tid];
+        };
+        // One unrolled pair of chunks starting at flat chunk index t0.  INS / HAS are compile-time so that every
+        // MFMA step is straight-line code: HAS = this block exists (issue MFMAs + next DMA), INS = spread the 64
+        // inserts of the previous block (prev) over the pair's 32 MFMA steps, two per step.
+        auto chunk_pair = [&](auto INS, auto HAS, int t0, int sq_prev, int idx_prev) {
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) {
+                const int t = t0 + c2;
+                if (HAS.value && (t + 1 < T)) dma_chunk(t + 1);
+                int buf_off = (t & 1) * KC * TR;
+                asm volatile("" : "+v"(buf_off));
+                const float *a = sA + buf_off, *bq_ = sB + buf_off;
+#pragma unroll
+                for (int kk = 0; kk < KC; kk += 2) {
+                    if (HAS.value) {
+                        const float bq = bq_[(kk + half) * TQ + wave * 32 + l31];
+#pragma unroll
+                        for (int tt = 0; tt < 4; ++tt)
+                            acc[tt] = mfma32x32x2(a[(kk + half) * TR + tt * 32 + l31], bq, acc[tt]);
+                    }
+                    if (INS.value) {
+                        const int step = c2 * 16 + (kk >> 1);          // 0..31
+                        insert(prev, step * 2, sq_prev, idx_prev);
+                        insert(prev, step * 2 + 1, sq_prev, idx_prev);
+                    }
+                }
+                __syncthreads();
+            }
+        };
+        using std::true_type;
+        using std::false_type;
+        dma_chunk(0);
+        __syncthreads();
+        for (int blk = 0; blk < nblk; ++blk) {
+            const int sq_prev = ((blk + 2) % 3) * TR, idx_prev = (blk - 1) * TR;
+            if (blk > 0) chunk_pair(true_type{}, true_type{}, blk * nch, sq_prev, idx_prev);
+            else chunk_pair(false_type{}, true_type{}, blk * nch, 0, 0);
+            for (int cp = 1; cp < nch / 2; ++cp) chunk_pair(false_type{}, true_type{}, blk * nch + cp * 2, 0, 0);
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                prev[tt] = acc[tt];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[tt][r] = 0.0f;
             }
         }
-        // lane holds G[cand][query = myq] for 64 candidates, visited in ascending candidate order
+        // drain: the last block's distances (no MFMAs left to hide behind)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int e = 0; e < 64; ++e) {
+            insert(prev, e, ((nblk + 2) % 3) * TR, (nblk - 1) * TR);
+            if ((e & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+        TileRegs ra, rb;
+        fetch_next(ra, rb, 0);
+        stage_next(ra, rb, 0);
+        __syncthreads();
+        for (int t = 0; t < T; ++t) {
+            const int blk = t / nch, ch = t - blk * nch;
+            const bool more = t + 1 < T;
+            if (more) fetch_next(ra, rb, t + 1);
+            const float *a = sA + (t & 1) * KC * TR, *bq_ = sB + (t & 1) * KC * TQ;
+#pragma unroll 4
+            for (int kk = 0; kk < KC; kk += 2) {
+                const float bq = bq_[(kk + half) * TQ + wave * 32 + l31];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int loc = t * 32 + mfma_row(r, half);
-                const float d = (sq_q + (-2.0f * acc[t][r])) + sSq[loc];  // +inf beyond N: never inserted
-                best.push_ascending(d, r0 + loc);
-                if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // keep the 64 distances from being hoisted
+                for (int tt = 0; tt < 4; ++tt) acc[tt] = mfma32x32x2(a[(kk + half) * TR + tt * 32 + l31], bq, acc[tt]);
             }
+            if (more) stage_next(ra, rb, t + 1);
+            if (ch == nch - 1) {      // block complete: lane holds G[cand][query = myq] for 64 candidates, ascending
+#pragma unroll
+                for (int e = 0; e < 64; ++e) {
+                    insert(acc, e, (blk % 3) * TR, blk * TR);
+                    if ((e & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // keep the 64 distances from being hoisted
+                }
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[tt][r] = 0.0f;
+            }
+            __syncthreads();
         }
     }
     // the two half-waves saw disjoint candidate subsets of the same query: merge them
@@ -217,7 +345,15 @@ template <int K, typename I>
 static void launch_topk(const float *xn, const float *sq, I *idx, int B, int C, int N, hipStream_t s) {
     const int tiles = (N + TQ - 1) / TQ;
     const int nblocks = B * tiles;
-    hipLaunchKernelGGL((knn_topk_kernel<K, I>), dim3(nblocks), dim3(256), 0, s, xn, sq, idx, C, N, tiles, nblocks);
+    const size_t lds = (size_t)KNN_LDS_FLOATS * sizeof(float);
+#define KNN_LAUNCH(PIPE)                                                                                             \
+    (void)hipFuncSetAttribute((const void *)knn_topk_kernel<K, I, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              (int)lds);                                                                             \
+    hipLaunchKernelGGL((knn_topk_kernel<K, I, PIPE>), dim3(nblocks), dim3(256), lds, s, xn, sq, idx, C, N, tiles,    \
+                       nblocks)
+    if (K <= 4 && C % (2 * KC) == 0 && N % TR == 0 && (((uintptr_t)xn) & 15) == 0) { KNN_LAUNCH(true); }
+    else { KNN_LAUNCH(false); }
+#undef KNN_LAUNCH
 }
 
 }  // namespace grafp
