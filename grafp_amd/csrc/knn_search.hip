@@ -2,19 +2,26 @@
 //
 // Replaces faiss.IndexFlatL2 add/search as used at /root/reference/eval.py:54,212-213,269-270.
 // The database stays resident in HBM as (n,128) f32 plus one squared norm per row (the `add` step).
-// A workgroup (4 waves, 1 per SIMD) owns one contiguous slice of rows and one group of queries.  The 4
-// waves are arranged as QW query-waves x RW row-waves (1x4 for <= 32 queries, 2x2 for <= 64, else 4x1):
-//   - the query operand (32 queries x 128 dims) lives in 64 VGPRs per lane for the whole kernel;
-//   - database rows stream HBM -> registers (prefetched one tile ahead) -> LDS -> exact-f32 MFMA
-//     (v_mfma_f32_32x32x2_f32, a c-ordered fmaf chain = the order oracle/csrc/flat_search.c fixes);
-//   - dis = (qq + dd) - 2*ip, clamped at 0; a lane keeps a candidate only if dis <= the query's current
-//     k-th best; survivors go to a per-query LDS queue and are folded into the sorted top list by a
-//     64-lane bitonic sort once 17+ have accumulated (amortised ~8 VALU per survivor).
-// Partial lists (one per row slice) are merged by search_merge_kernel (also grafp_merge_topk for
-// per-GPU shards).  Ordering everywhere is (distance, id) lexicographic => lowest id wins ties.
+// A search is four small-to-large launches, none of which keeps per-query sorted state while it streams:
+//   1. search_bound_kernel  over a sample (first max(64k, n/16) rows): every lane keeps the minimum distance it
+//      sees; lanes fall into 64 groups with DISJOINT row sets, one integer atomicMin per lane at the end.
+//   2. search_thr_kernel    per query, the k-th smallest of the 64 group minima: at least k rows are <= it, so it
+//      bounds the k-th best distance from above (typically ~25 x n/sample rows fall under it).
+//   3. search_scan_kernel   the one pass over the whole database: HBM -> registers (one tile ahead) -> LDS ->
+//      exact-f32 MFMA (v_mfma_f32_32x32x2_f32 = the k-ordered fmaf chain oracle/csrc/flat_search.c fixes),
+//      dis = (qq + dd) - 2*ip clamped at 0, and a lane appends (dis, row) to its query's candidate list only when
+//      dis <= the bound -- 16 compares and one ballot per 32x32 block in the common case.  No selection state in
+//      LDS, so two workgroups share a CU and one's MFMA chain hides the other's loads, stores and barriers.
+//   4. search_select_kernel one workgroup per query sorts its few hundred candidates by (distance, id) with
+//      64-lane bitonic folds.  A query whose list overflowed (pathological data: thousands of exact ties) is
+//      rescanned exactly by that workgroup with the same arithmetic -- slow, never wrong.
+// A workgroup is 4 waves arranged as QW query-waves x RW row-waves (1x4 for <= 32 queries, 2x2 for <= 64,
+// else 4x1); the query operand (32 queries x 128 dims) lives in 64 VGPRs per lane for the whole kernel.
+// Ordering everywhere is (distance, id) lexicographic => lowest id wins ties.  search_merge_kernel
+// (grafp_merge_topk) merges per-GPU shard results.
 //
 // Roofline: one pass streams n*(512+4) bytes; 2*128 flops per (row, query).  HBM-bound up to ~50
-// queries per pass, f32-matrix-bound (157.3 TFLOP/s) beyond.  See DESIGN.md "search_partial_kernel".
+// queries per pass, f32-matrix-bound (157.3 TFLOP/s) beyond.  See DESIGN.md "search_scan_kernel".
 #include <math.h>
 
 #include "common.h"
@@ -22,14 +29,16 @@
 namespace grafp {
 
 constexpr int SR_D = 128;
-constexpr int SR_LS = 129;       // LDS row stride of the database tile (bank spread for ds_read_b32)
-constexpr int SR_QS = 65;        // slot stride per query in the selection arrays
+constexpr int SR_LS = 129;       // LDS row stride of the database tile (ds_read_b32 banks are mod 32)
 constexpr int SR_EMPTY = 0x7fffffff;
-constexpr int SR_TRIGGER = 16;   // fold the queue when more than this many survivors are pending
+constexpr int SR_GROUPS = 64;    // disjoint sample groups per query in the pre-pass
+constexpr int SR_CAP = 4096;     // candidate slots per query (typical fill: a few hundred)
 
+// Order LDS traffic between the lanes of ONE wave: wait for this wave's LDS operations only (lgkmcnt) -- a full
+// fence would also drain vmcnt, i.e. stall on the database prefetch that is deliberately left in flight.
 #define WAVE_SYNC()                                                   \
     do {                                                              \
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");        \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            \
         __builtin_amdgcn_wave_barrier();                              \
     } while (0)
 
@@ -61,56 +70,54 @@ __device__ __forceinline__ void wave_sort64(float &d, I &i, int lane) {
     }
 }
 
-// Per-wave selection state in LDS: 32 queries x (32 sorted best | 32 pending), counts, thresholds.
-struct Sel {
-    float *sd;
-    int *si;
-    int *cnt;
-    float *thr;
-    __device__ __forceinline__ void bind(float *base) {
-        sd = base;
-        si = reinterpret_cast<int *>(base + 32 * SR_QS);
-        cnt = si + 32 * SR_QS;
-        thr = reinterpret_cast<float *>(cnt + 32);
+// Running top-32 of one wave: sorted list in lanes 0..31 of (td, ti); survivors of the threshold test are compacted
+// (ballot prefix, no atomics) into an LDS queue and folded in 32 at a time.  thr only ever tightens.
+constexpr int WT_PEND = 96;      // <= 31 left over + 64 new per push
+struct WaveTop {
+    float td;
+    int ti;
+    float thr;
+    int pc;
+    float *pd;
+    int *pi;
+    __device__ __forceinline__ void init(float *qd, int *qi, float thr0) {
+        td = INFINITY;
+        ti = SR_EMPTY;
+        thr = thr0;
+        pc = 0;
+        pd = qd;
+        pi = qi;
     }
-    static constexpr int kFloats = 2 * 32 * SR_QS + 64;
-    __device__ __forceinline__ void init(int lane) {
-        for (int j = lane; j < 32 * SR_QS; j += 64) {
-            sd[j] = INFINITY;
-            si[j] = SR_EMPTY;
+    __device__ __forceinline__ void fold(int k, int lane) {
+        WAVE_SYNC();
+        for (int off = 0; off < pc; off += 32) {
+            float d = td;
+            int i = ti;
+            if (lane >= 32) {
+                const int e = off + lane - 32;
+                d = e < pc ? pd[e] : INFINITY;
+                i = e < pc ? pi[e] : SR_EMPTY;
+            }
+            wave_sort64(d, i, lane);
+            td = d;                        // lanes 0..31: the 32 best so far
+            ti = i;
         }
-        if (lane < 32) {
-            cnt[lane] = 0;
-            thr[lane] = INFINITY;
-        }
+        thr = fminf(thr, __shfl(td, k - 1));
+        pc = 0;
+        WAVE_SYNC();
     }
-    // fold query q's pending entries into its sorted list (whole wave cooperates)
-    __device__ __forceinline__ void fold(int q, int k, int lane) {
-        const int c = cnt[q];
-        float d = INFINITY;
-        int i = SR_EMPTY;
-        if (lane < 32 || lane - 32 < c) {
-            d = sd[q * SR_QS + lane];
-            i = si[q * SR_QS + lane];
+    // wave-uniform call; every lane offers one (d, i) or nothing
+    __device__ __forceinline__ void push(bool valid, float d, int i, int k, int lane) {
+        const bool pass = valid && d <= thr;
+        const unsigned long long m = __ballot(pass);
+        if (m == 0) return;
+        if (pass) {
+            const int pos = pc + __popcll(m & ((1ull << lane) - 1ull));
+            pd[pos] = d;
+            pi[pos] = i;
         }
-        wave_sort64(d, i, lane);
-        if (lane < 32) {
-            sd[q * SR_QS + lane] = d;
-            si[q * SR_QS + lane] = i;
-        }
-        const float t = __shfl(d, k - 1);
-        if (lane == 0) {
-            cnt[q] = 0;
-            thr[q] = t;
-        }
-    }
-    __device__ __forceinline__ void fold_where(bool need, int k, int lane) {
-        unsigned long long mask = __ballot(need && lane < 32);
-        while (mask) {
-            const int q = __ffsll((long long)mask) - 1;
-            mask &= mask - 1;
-            fold(q, k, lane);
-        }
+        pc += __popcll(m);
+        if (pc >= 32) fold(k, lane);
     }
 };
 
@@ -138,58 +145,39 @@ __global__ __launch_bounds__(256) void row_sqnorm_kernel(const float *__restrict
     }
 }
 
-// ---- main pass -----------------------------------------------------------------------------------
-template <int QW>
-__global__ __launch_bounds__(256, 1) void search_partial_kernel(const float *__restrict__ db,
-                                                                const float *__restrict__ dd, int64_t n,
-                                                                const float *__restrict__ q,
-                                                                const float *__restrict__ qq, int nq, int k,
-                                                                int64_t rows_per_split, int64_t id_base,
-                                                                float *__restrict__ part_d,
-                                                                int64_t *__restrict__ part_i) {
+// ---- the streaming loop shared by the pre-pass and the main pass -------------------------------------------------
+// Tiles of TROWS rows go HBM -> registers (tile t+1 is in flight while tile t is consumed) -> LDS; wave (qw, rw)
+// multiplies rows [rw*32, rw*32+32) of the tile with its 32 queries and hands the 32x32 accumulator block to
+// `on_block(t, acc)`: lane (l31, half) holds query l31 x rows mfma_row(r, half), r = 0..15.
+template <int QW, typename F>
+__device__ __forceinline__ void stream_tiles(const float *__restrict__ db, const float *__restrict__ dd,
+                                             int64_t row_begin, int64_t row_end, float *tile, float *sDD,
+                                             const float (&bq)[64], F &&on_block) {
     constexpr int RW = 4 / QW;
     constexpr int TROWS = 32 * RW;
     constexpr int NV = TROWS * 32 / 256;  // float4 per thread per tile
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *tile = reinterpret_cast<float *>(smem);  // [TROWS][SR_LS]
-    float *sDD = tile + TROWS * SR_LS;              // [TROWS]
-    float *selbase = sDD + TROWS;
-
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
-    const int qw = wave % QW, rw = wave / QW;
-    Sel sel;
-    sel.bind(selbase + wave * Sel::kFloats);
-    sel.init(lane);
-
-    const int split = blockIdx.x;
-    const int qbase = (blockIdx.y * QW + qw) * 32;
-    const int64_t row_begin = (int64_t)split * rows_per_split;
-    const int64_t row_end = (row_begin + rows_per_split < n) ? row_begin + rows_per_split : n;
-    const int qi = qbase + l31;
-    const bool qvalid = qi < nq;
-
-    float bq[64];  // query operand: B[k = 2s + half][j = l31]
-    {
-        const float *qrow = q + (size_t)(qvalid ? qi : 0) * SR_D + half;
-#pragma unroll
-        for (int s = 0; s < 64; ++s) bq[s] = qvalid ? qrow[2 * s] : 0.0f;
-    }
-    const float myqq = qvalid ? qq[qi] : 0.0f;
-
-    const int ntiles = (int)((row_end - row_begin + TROWS - 1) / TROWS);
+    const int rw = wave / QW;
+    const int ntiles = row_end > row_begin ? (int)((row_end - row_begin + TROWS - 1) / TROWS) : 0;
+    const int nrows = (int)(row_end - row_begin);
+    const float4 *base4 = reinterpret_cast<const float4 *>(db) + row_begin * 32;
+    const float *ddb = dd + row_begin;
     float4 pf[NV];
-    const float4 *db4 = reinterpret_cast<const float4 *>(db);
+    float pdd = 0.0f;
     auto prefetch = [&](int t) {
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const int item = tid + v * 256;
-            const int64_t grow = row_begin + (int64_t)t * TROWS + (item >> 5);
-            pf[v] = grow < row_end ? db4[grow * 32 + (item & 31)] : make_float4(0.f, 0.f, 0.f, 0.f);
+            int lr = t * TROWS + (item >> 5);
+            lr = lr < nrows ? lr : nrows - 1;          // rows past the end: any readable data, their norm is NaN
+            pf[v] = base4[(size_t)lr * 32 + (item & 31)];
+        }
+        if (tid < TROWS) {
+            const int lr = t * TROWS + tid;
+            pdd = lr < nrows ? ddb[lr] : __builtin_nanf("");   // NaN fails every comparison downstream
         }
     };
     if (ntiles > 0) prefetch(0);
-    WAVE_SYNC();
-
     for (int t = 0; t < ntiles; ++t) {
         __syncthreads();  // every wave is done reading the previous tile
 #pragma unroll
@@ -198,170 +186,359 @@ __global__ __launch_bounds__(256, 1) void search_partial_kernel(const float *__r
             float *o = tile + (item >> 5) * SR_LS + (item & 31) * 4;
             o[0] = pf[v].x; o[1] = pf[v].y; o[2] = pf[v].z; o[3] = pf[v].w;
         }
-        if (tid < TROWS) {
-            const int64_t grow = row_begin + (int64_t)t * TROWS + tid;
-            sDD[tid] = grow < row_end ? dd[grow] : INFINITY;
-        }
+        if (tid < TROWS) sDD[tid] = pdd;
         __syncthreads();
-        if (t + 1 < ntiles) prefetch(t + 1);  // in flight while this tile is consumed
-
+        if (t + 1 < ntiles) prefetch(t + 1);
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-        {
-            const float *arow = tile + (rw * 32 + l31) * SR_LS + half;
+        // A operand: AB LDS reads are issued a batch ahead of the AB dependent MFMAs that consume them (the
+        // scheduler barriers keep the compiler from sinking each read next to its use and exposing LDS latency)
+        const float *arow = tile + (rw * 32 + l31) * SR_LS + half;
+        constexpr int AB = QW == 1 ? 8 : 16;   // batch depth (register budget: the 1x4 shape prefetches 64 VGPRs)
+        float a[2][AB];
 #pragma unroll
-            for (int s = 0; s < 64; ++s) acc = mfma32x32x2(arow[2 * s], bq[s], acc);
+        for (int i = 0; i < AB; ++i) a[0][i] = arow[2 * i];
+#pragma unroll
+        for (int b = 0; b < 64 / AB; ++b) {
+            if (b + 1 < 64 / AB) {
+#pragma unroll
+                for (int i = 0; i < AB; ++i) a[(b + 1) & 1][i] = arow[2 * (AB * (b + 1) + i)];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < AB; ++i) acc = mfma32x32x2(a[b & 1][i], bq[AB * b + i], acc);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        // selection: lane holds 16 distances of query l31 against rows mfma_row(r, half) of its 32-row slab
-        float thr_q = sel.thr[l31];
-        const int64_t slab0 = row_begin + (int64_t)t * TROWS + rw * 32;
+        on_block(t, acc);
+    }
+}
+
+// query operand of the MFMA: B[k = 2s + half][j = l31]
+__device__ __forceinline__ void load_queries(const float *__restrict__ q, int qi, bool qvalid, int half,
+                                             float (&bq)[64]) {
+    const float *qrow = q + (size_t)(qvalid ? qi : 0) * SR_D + half;
 #pragma unroll
-        for (int ph = 0; ph < 2; ++ph) {
+    for (int s = 0; s < 64; ++s) bq[s] = qvalid ? qrow[2 * s] : 0.0f;
+}
+
+// ---- launch 0: query norms, empty group minima, empty candidate lists ---------------------------------------------
+__global__ __launch_bounds__(256) void search_init_kernel(const float *__restrict__ q, int nq, float *__restrict__ qq,
+                                                          int *__restrict__ gmin, int *__restrict__ cnt) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < (int64_t)nq * SR_GROUPS) gmin[i] = 0x7f800000;  // +inf
+    if (i < nq) {
+        cnt[i] = 0;
+        const float *row = q + i * SR_D;
+        float s = 0.0f;
+        for (int c = 0; c < SR_D; ++c) s = __builtin_fmaf(row[c], row[c], s);   // same chain as row_sqnorm_kernel
+        qq[i] = s;
+    }
+}
+
+// ---- launch 1: pre-pass over the sample --------------------------------------------------------------------------
+// Distances are >= 0, so their f32 bit patterns order like ints and the group minimum is one integer atomicMin.
+template <int QW>
+__global__ __launch_bounds__(256, 2) void search_bound_kernel(const float *__restrict__ db,
+                                                              const float *__restrict__ dd, int64_t n_sample,
+                                                              const float *__restrict__ q,
+                                                              const float *__restrict__ qq, int nq,
+                                                              int64_t rows_per_split, int *__restrict__ gmin) {
+    constexpr int RW = 4 / QW;
+    constexpr int TROWS = 32 * RW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *tile = reinterpret_cast<float *>(smem);  // [TROWS][SR_LS]
+    float *sDD = tile + TROWS * SR_LS;              // [TROWS]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int qw = wave % QW, rw = wave / QW;
+    const int split = blockIdx.x;
+    const int qi = (blockIdx.y * QW + qw) * 32 + l31;
+    const bool qvalid = qi < nq;
+    const int64_t row_begin = (int64_t)split * rows_per_split;
+    const int64_t row_end = (row_begin + rows_per_split < n_sample) ? row_begin + rows_per_split : n_sample;
+    float bq[64];
+    load_queries(q, qi, qvalid, half, bq);
+    const float myqq = qvalid ? qq[qi] : 0.0f;
+    float best = INFINITY;
+    stream_tiles<QW>(db, dd, row_begin, row_end, tile, sDD, bq, [&](int, const f32x16 &acc) {
 #pragma unroll
-            for (int r8 = 0; r8 < 8; ++r8) {
-                const int r = ph * 8 + r8;
-                const int lrow = mfma_row(r, half);
-                const int64_t grow = slab0 + lrow;
-                float dis = (myqq + sDD[rw * 32 + lrow]) - 2.0f * acc[r];
-                dis = dis < 0.0f ? 0.0f : dis;
-                if (qvalid && grow < row_end && dis <= thr_q) {
-                    const int pos = atomicAdd(&sel.cnt[l31], 1);
-                    sel.sd[l31 * SR_QS + 32 + pos] = dis;
-                    sel.si[l31 * SR_QS + 32 + pos] = (int)grow;
+        for (int r = 0; r < 16; ++r) {
+            // (qq + dd) - 2*ip in one rounding (2*ip is exact); rows past the end carry NaN and are ignored by fminf
+            const float x = __builtin_fmaf(-2.0f, acc[r], myqq + sDD[rw * 32 + mfma_row(r, half)]);
+            best = fminf(best, x);
+        }
+    });
+    best = best < 0.0f ? 0.0f : best;     // the clamp commutes with the minimum
+    if (qvalid && best < INFINITY) {
+        // the lanes serving one query differ in (split, row-wave, half): consecutive ids cover all 64 groups
+        const int g = (((split * RW + rw) * 2) + half) & (SR_GROUPS - 1);
+        atomicMin(&gmin[(size_t)qi * SR_GROUPS + g], __float_as_int(best));
+    }
+}
+
+// ---- launch 2: bound = k-th smallest group minimum (one wave per query) -------------------------------------------
+__global__ __launch_bounds__(256) void search_thr_kernel(const int *__restrict__ gmin, int nq, int k,
+                                                         float *__restrict__ thr) {
+    const int lane = threadIdx.x & 63;
+    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (qi >= nq) return;
+    float d = __int_as_float(gmin[(size_t)qi * SR_GROUPS + lane]);
+    int i = lane;
+    wave_sort64(d, i, lane);
+    if (lane == k - 1) thr[qi] = d;      // +inf when fewer than k groups saw a row: every row is a candidate
+}
+
+// ---- launch 3: the pass over the database -------------------------------------------------------------------------
+template <int QW>
+__global__ __launch_bounds__(256, 2) void search_scan_kernel(const float *__restrict__ db,
+                                                             const float *__restrict__ dd, int64_t n,
+                                                             const float *__restrict__ q,
+                                                             const float *__restrict__ qq, int nq,
+                                                             int64_t rows_per_split, const float *__restrict__ thr,
+                                                             int *__restrict__ cnt, float *__restrict__ cand_d,
+                                                             int *__restrict__ cand_i) {
+    constexpr int RW = 4 / QW;
+    constexpr int TROWS = 32 * RW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *tile = reinterpret_cast<float *>(smem);
+    float *sDD = tile + TROWS * SR_LS;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int qw = wave % QW, rw = wave / QW;
+    const int split = blockIdx.x;
+    const int qi = (blockIdx.y * QW + qw) * 32 + l31;
+    const bool qvalid = qi < nq;
+    const int64_t row_begin = (int64_t)split * rows_per_split;
+    const int64_t row_end = (row_begin + rows_per_split < n) ? row_begin + rows_per_split : n;
+    float bq[64];
+    load_queries(q, qi, qvalid, half, bq);
+    const float myqq = qvalid ? qq[qi] : 0.0f;
+    const float thr_q = qvalid ? thr[qi] : -1.0f;      // -1: nothing passes (distances are clamped at 0)
+    stream_tiles<QW>(db, dd, row_begin, row_end, tile, sDD, bq, [&](int t, const f32x16 &acc) {
+        // dis = max(0, x), x = (qq + dd) - 2*ip in one rounding (2*ip is exact).  thr >= 0, so dis <= thr <=> x <= thr:
+        // the common case is one add, one fma and one compare per element, the lane masks OR-ed in scalar registers.
+        // Rows past the end carry NaN norms and fail the compare.
+        float x[16];
+        unsigned long long any = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            x[r] = __builtin_fmaf(-2.0f, acc[r], myqq + sDD[rw * 32 + mfma_row(r, half)]);
+            any |= __ballot(x[r] <= thr_q);
+        }
+        if (any != 0) {
+            const int64_t slab0 = row_begin + (int64_t)t * TROWS + rw * 32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (x[r] <= thr_q) {
+                    const int pos = atomicAdd(&cnt[qi], 1);
+                    if (pos < SR_CAP) {                 // beyond: cnt > SR_CAP tells the select kernel to rescan
+                        cand_d[(size_t)qi * SR_CAP + pos] = x[r] < 0.0f ? 0.0f : x[r];
+                        cand_i[(size_t)qi * SR_CAP + pos] = (int)(slab0 + mfma_row(r, half));
+                    }
                 }
             }
-            WAVE_SYNC();
-            sel.fold_where(sel.cnt[l31] > SR_TRIGGER, k, lane);
-            WAVE_SYNC();
-            thr_q = sel.thr[l31];
+        }
+    });
+}
+
+// ---- launch 4: per query, the k best of its candidates by (distance, id) ------------------------------------------
+__global__ __launch_bounds__(256) void search_select_kernel(const float *__restrict__ db,
+                                                            const float *__restrict__ dd, int64_t n,
+                                                            const float *__restrict__ q,
+                                                            const float *__restrict__ qq, int nq, int k,
+                                                            int64_t id_base, const float *__restrict__ thr,
+                                                            const int *__restrict__ cnt,
+                                                            const float *__restrict__ cand_d,
+                                                            const int *__restrict__ cand_i,
+                                                            float *__restrict__ out_d, int64_t *__restrict__ out_i) {
+    __shared__ float pend_d[4][WT_PEND];
+    __shared__ int pend_i[4][WT_PEND];
+    __shared__ float wtop_d[4][32];
+    __shared__ int wtop_i[4][32];
+    __shared__ float sq[SR_D];
+    const int qi = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    WaveTop top;
+    top.init(pend_d[wave], pend_i[wave], thr[qi]);
+    const int c = cnt[qi];
+    if (c <= SR_CAP) {
+        for (int e0 = 0; e0 < c; e0 += 256) {
+            const int e = e0 + tid;
+            const bool valid = e < c;
+            const float d = valid ? cand_d[(size_t)qi * SR_CAP + e] : INFINITY;
+            const int i = valid ? cand_i[(size_t)qi * SR_CAP + e] : SR_EMPTY;
+            top.push(valid, d, i, k, lane);
+        }
+    } else {
+        // the list overflowed: exact rescan of the whole database for this query, one row per thread, same
+        // c-ordered fmaf chain and distance expression as the MFMA path
+        if (tid < SR_D) sq[tid] = q[(size_t)qi * SR_D + tid];
+        __syncthreads();
+        const float myqq = qq[qi];
+        const float4 *db4 = reinterpret_cast<const float4 *>(db);
+        for (int64_t r0 = 0; r0 < n; r0 += 256) {
+            const int64_t row = r0 + tid;
+            const bool valid = row < n;
+            float d = INFINITY;
+            if (valid) {
+                float ip = 0.0f;
+                for (int c4 = 0; c4 < SR_D / 4; ++c4) {
+                    const float4 x = db4[row * 32 + c4];
+                    ip = __builtin_fmaf(x.x, sq[4 * c4 + 0], ip);
+                    ip = __builtin_fmaf(x.y, sq[4 * c4 + 1], ip);
+                    ip = __builtin_fmaf(x.z, sq[4 * c4 + 2], ip);
+                    ip = __builtin_fmaf(x.w, sq[4 * c4 + 3], ip);
+                }
+                d = (myqq + dd[row]) - 2.0f * ip;
+                d = d < 0.0f ? 0.0f : d;
+            }
+            top.push(valid, d, (int)row, k, lane);
         }
     }
-    WAVE_SYNC();
-    sel.fold_where(sel.cnt[l31] > 0, k, lane);
+    if (top.pc > 0) top.fold(k, lane);
+    if (lane < 32) {
+        wtop_d[wave][lane] = top.td;
+        wtop_i[wave][lane] = top.ti;
+    }
     __syncthreads();
-    // fold the other row-waves' lists into row-wave 0's
-    if (rw == 0) {
-        for (int orw = 1; orw < RW; ++orw) {
-            Sel oth;
-            oth.bind(selbase + (orw * QW + qw) * Sel::kFloats);
-            for (int qs = 0; qs < 32; ++qs) {
-                float d;
-                int i;
-                if (lane < 32) {
-                    d = sel.sd[qs * SR_QS + lane];
-                    i = sel.si[qs * SR_QS + lane];
-                } else {
-                    d = oth.sd[qs * SR_QS + lane - 32];
-                    i = oth.si[qs * SR_QS + lane - 32];
-                }
-                wave_sort64(d, i, lane);
-                if (lane < 32) {
-                    sel.sd[qs * SR_QS + lane] = d;
-                    sel.si[qs * SR_QS + lane] = i;
-                }
+    if (wave == 0) {
+        float td = top.td;
+        int ti = top.ti;
+        for (int w = 1; w < 4; ++w) {
+            if (lane >= 32) {
+                td = wtop_d[w][lane - 32];
+                ti = wtop_i[w][lane - 32];
             }
-            WAVE_SYNC();
+            wave_sort64(td, ti, lane);
         }
-        for (int qs = 0; qs < 32; ++qs) {
-            const int qo = qbase + qs;
-            if (qo < nq && lane < k) {
-                const size_t o = ((size_t)split * nq + qo) * k + lane;
-                const int i = sel.si[qs * SR_QS + lane];
-                part_d[o] = sel.sd[qs * SR_QS + lane];
-                part_i[o] = i == SR_EMPTY ? (int64_t)-1 : id_base + (int64_t)i;
-            }
+        if (lane < k) {
+            out_d[(size_t)qi * k + lane] = td;
+            out_i[(size_t)qi * k + lane] = ti == SR_EMPTY ? (int64_t)-1 : id_base + (int64_t)ti;
         }
     }
 }
 
-// ---- merge of P sorted partial lists per query (one wave per query) -----------------------------
-__global__ __launch_bounds__(64) void search_merge_kernel(const float *__restrict__ part_d,
-                                                          const int64_t *__restrict__ part_i, int P, int nq, int k,
-                                                          float *__restrict__ out_d, int64_t *__restrict__ out_i) {
-    __shared__ float sd[64];
-    __shared__ long long si[64];
-    const int q = blockIdx.x, lane = threadIdx.x;
-    constexpr long long EMPTY = 0x7fffffffffffffffll;
-    // every part's k-th best bounds the global k-th best from above
-    float thr = INFINITY;
-    for (int p = lane; p < P; p += 64) {
-        const size_t o = ((size_t)p * nq + q) * k + (k - 1);
-        if (part_i[o] >= 0) thr = fminf(thr, part_d[o]);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) thr = fminf(thr, __shfl_xor(thr, o));
+// ---- merge of P partial lists per query: one workgroup per query ------------------------------------------
+// 256 threads sweep the P*k entries 2048 at a time (8 independent loads per thread), keep only entries that are
+// valid and <= the running threshold (+inf, tightened by every fold), append them to an LDS buffer,
+// and wave 0 folds the buffer into the sorted top list 32 entries at a time with the 64-lane bitonic sort.
+constexpr int MG_ITEMS = 8;
+constexpr int MG_CAP = 256 * MG_ITEMS + 64;
 
-    sd[lane] = INFINITY;
-    si[lane] = EMPTY;
-    int cnt = 0;  // wave-uniform
-    const int total = P * k;
-    WAVE_SYNC();
-    auto fold = [&]() {
-        float d = sd[lane];
-        long long i = si[lane];
-        if (lane >= 32 + cnt) { d = INFINITY; i = EMPTY; }
-        wave_sort64(d, i, lane);
-        WAVE_SYNC();
-        sd[lane] = lane < 32 ? d : INFINITY;
-        si[lane] = lane < 32 ? i : EMPTY;
-        const float t = __shfl(d, k - 1);
-        thr = fminf(thr, t);
-        cnt = 0;
-        WAVE_SYNC();
-    };
-    for (int base = 0; base < total; base += 32) {
-        const int e = base + lane;
-        bool pass = false;
-        float d = INFINITY;
-        long long i = EMPTY;
-        if (lane < 32 && e < total) {
-            const int p = e / k, j = e - p * k;
-            const size_t o = ((size_t)p * nq + q) * k + j;
-            i = part_i[o];
-            d = part_d[o];
-            pass = i >= 0 && d <= thr;
-        }
-        const unsigned long long mask = __ballot(pass);
-        const int add = __popcll(mask);
-        if (add == 0) continue;
-        if (cnt + add > 32) fold();
-        if (pass) {
-            const int pos = cnt + __popcll(mask & ((1ull << lane) - 1ull));
-            sd[32 + pos] = d;
-            si[32 + pos] = i;
-        }
-        cnt += add;
-        WAVE_SYNC();
+__global__ __launch_bounds__(256) void search_merge_kernel(const float *__restrict__ part_d,
+                                                           const int64_t *__restrict__ part_i, int P, int nq, int k,
+                                                           float *__restrict__ out_d,
+                                                           int64_t *__restrict__ out_i) {
+    __shared__ float top_d[32];
+    __shared__ long long top_i[32];
+    __shared__ float buf_d[MG_CAP];
+    __shared__ long long buf_i[MG_CAP];
+    __shared__ int s_cnt;
+    __shared__ float s_thr;
+    constexpr long long EMPTY = 0x7fffffffffffffffll;
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    if (tid < 32) {
+        top_d[tid] = INFINITY;
+        top_i[tid] = EMPTY;
     }
-    if (cnt > 0) fold();
-    if (lane < k) {
-        const long long i = si[lane];
-        out_d[(size_t)q * k + lane] = sd[lane];
-        out_i[(size_t)q * k + lane] = i == EMPTY ? (int64_t)-1 : (int64_t)i;
+    if (tid == 0) {
+        s_thr = INFINITY;
+        s_cnt = 0;
+    }
+    __syncthreads();
+    const int total = P * k;
+    for (int base = 0; base < total; base += 256 * MG_ITEMS) {
+        const float thr = s_thr;
+        float d[MG_ITEMS];
+        long long id[MG_ITEMS];
+#pragma unroll
+        for (int u = 0; u < MG_ITEMS; ++u) {
+            const int e = base + u * 256 + tid;
+            d[u] = INFINITY;
+            id[u] = -1;
+            if (e < total) {
+                const int p = e / k, j = e - p * k;
+                const size_t o = ((size_t)p * nq + q) * k + j;
+                id[u] = part_i[o];
+                d[u] = part_d[o];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < MG_ITEMS; ++u)
+            if (id[u] >= 0 && d[u] <= thr) {
+                const int pos = atomicAdd(&s_cnt, 1);
+                buf_d[pos] = d[u];
+                buf_i[pos] = id[u];
+            }
+        __syncthreads();
+        const int cnt = s_cnt;
+        if (tid < 64 && cnt > 0) {      // wave 0 folds the buffer, 32 entries per sort
+            float td = lane < 32 ? top_d[lane] : INFINITY;
+            long long ti = lane < 32 ? top_i[lane] : EMPTY;
+            for (int off = 0; off < cnt; off += 32) {
+                float sd = td;
+                long long si = ti;
+                if (lane >= 32) {
+                    const int e = off + lane - 32;
+                    sd = e < cnt ? buf_d[e] : INFINITY;
+                    si = e < cnt ? buf_i[e] : EMPTY;
+                }
+                wave_sort64(sd, si, lane);
+                td = sd;                     // lanes 0..31 now hold the 32 best so far
+                ti = si;
+            }
+            if (lane < 32) {
+                top_d[lane] = td;
+                top_i[lane] = ti;
+            }
+            const float kth = __shfl(td, k - 1);
+            if (lane == 0) {
+                s_thr = fminf(s_thr, kth);
+                s_cnt = 0;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid < k) {
+        const long long i = top_i[tid];
+        out_d[(size_t)q * k + tid] = top_d[tid];
+        out_i[(size_t)q * k + tid] = i == EMPTY ? (int64_t)-1 : (int64_t)i;
     }
 }
 
 struct SearchPlan {
-    int qw, qgroups, splits, trows;
+    int qw, rw, qgroups, trows;
+    int splits;                   // main pass: grid = (splits, qgroups)
     int64_t rows_per_split;
+    int b_splits;                 // pre-pass launch over the first b_rows rows
+    int64_t b_rows, b_rows_per_split;
 };
+
+static void split_rows(int64_t rows, int trows, int64_t want, int *splits, int64_t *rows_per_split) {
+    const int64_t tiles = (rows + trows - 1) / trows;
+    if (want > tiles) want = tiles;
+    if (want < 1) want = 1;
+    const int64_t tps = (tiles + want - 1) / want;        // whole tiles per split
+    *rows_per_split = tps * trows;
+    *splits = (int)((tiles + tps - 1) / tps);
+}
 
 static SearchPlan make_plan(int64_t n, int nq) {
     SearchPlan p;
     p.qw = nq <= 32 ? 1 : (nq <= 64 ? 2 : 4);
-    p.trows = 32 * (4 / p.qw);
+    p.rw = 4 / p.qw;
+    p.trows = 32 * p.rw;
     p.qgroups = (nq + 32 * p.qw - 1) / (32 * p.qw);
-    int64_t splits = 256 / p.qgroups;  // one workgroup per CU when the query groups allow it
-    if (splits < 1) splits = 1;
-    const int64_t max_splits = n / (4 * p.trows) > 1 ? n / (4 * p.trows) : 1;
-    if (splits > max_splits) splits = max_splits;
-    int64_t rps = (n + splits - 1) / splits;
-    rps = (rps + p.trows - 1) / p.trows * p.trows;
-    if (rps < p.trows) rps = p.trows;
-    p.rows_per_split = rps;
-    p.splits = (int)((n + rps - 1) / rps);
-    if (p.splits < 1) p.splits = 1;
+    // two workgroups per CU (256 CUs), three for the 4x1 shape (registers and LDS allow it), when the query
+    // groups allow it
+    int64_t want = (p.qw == 4 ? 768 : 512) / p.qgroups;
+    split_rows(n, p.trows, want < 1 ? 1 : want, &p.splits, &p.rows_per_split);
+    // pre-pass: the first max(64k, n/16) rows; >= 32 (split, row-wave) pairs per query so that all 64 groups
+    // (pair x half) see rows, and enough workgroups to fill the chip for a handful of tiles each
+    p.b_rows = n / 16 > 65536 ? n / 16 : 65536;
+    if (p.b_rows > n) p.b_rows = n;
+    int64_t bwant = 1024 / p.qgroups;
+    const int64_t need = (32 + p.rw - 1) / p.rw;
+    if (bwant < need) bwant = need;
+    split_rows(p.b_rows, p.trows, bwant, &p.b_splits, &p.b_rows_per_split);
     return p;
 }
 
@@ -386,9 +563,9 @@ extern "C" int grafp_row_sqnorm_f32(const float *m, int64_t n, int d, float *out
 extern "C" size_t grafp_knn_search_workspace(int64_t n, int nq, int d, int k) {
     using namespace grafp;
     if (n <= 0 || nq <= 0 || d != SR_D || k < 1) return 0;
-    const SearchPlan p = make_plan(n, nq);
-    return align256((size_t)nq * sizeof(float)) + align256((size_t)p.splits * nq * k * sizeof(float)) +
-           align256((size_t)p.splits * nq * k * sizeof(int64_t));
+    return align256((size_t)nq * sizeof(float)) * 2 + align256((size_t)nq * sizeof(int)) +
+           align256((size_t)nq * SR_GROUPS * sizeof(int)) + align256((size_t)nq * SR_CAP * sizeof(float)) +
+           align256((size_t)nq * SR_CAP * sizeof(int));
 }
 
 extern "C" int grafp_knn_search_l2_f32(const float *db, const float *db_sqnorm, int64_t n, const float *q, int nq,
@@ -407,26 +584,36 @@ extern "C" int grafp_knn_search_l2_f32(const float *db, const float *db_sqnorm, 
     }
     hipStream_t s = (hipStream_t)stream;
     const SearchPlan p = make_plan(n, nq);
-    float *qq = (float *)ws;
-    float *part_d = (float *)((char *)ws + align256((size_t)nq * sizeof(float)));
-    int64_t *part_i = (int64_t *)((char *)part_d + align256((size_t)p.splits * nq * k * sizeof(float)));
-    int rc = grafp_row_sqnorm_f32(q, nq, d, qq, stream);
-    if (rc != GRAFP_OK) return rc;
-    const size_t lds = ((size_t)p.trows * SR_LS + p.trows + 4 * Sel::kFloats) * sizeof(float);
-    const dim3 grid(p.splits, p.qgroups);
+    char *w = (char *)ws;
+    float *qq = (float *)w;                 w += align256((size_t)nq * sizeof(float));
+    float *thr = (float *)w;                w += align256((size_t)nq * sizeof(float));
+    int *cnt = (int *)w;                    w += align256((size_t)nq * sizeof(int));
+    int *gmin = (int *)w;                   w += align256((size_t)nq * SR_GROUPS * sizeof(int));
+    float *cand_d = (float *)w;             w += align256((size_t)nq * SR_CAP * sizeof(float));
+    int *cand_i = (int *)w;
+    const int64_t ng = (int64_t)nq * SR_GROUPS;
+    hipLaunchKernelGGL(search_init_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, s, q, nq, qq, gmin, cnt);
+    const size_t lds = ((size_t)p.trows * SR_LS + p.trows) * sizeof(float);
+    const dim3 grid_b(p.b_splits, p.qgroups), grid(p.splits, p.qgroups);
 #define SR_LAUNCH(QW)                                                                                               \
-    (void)hipFuncSetAttribute((const void *)search_partial_kernel<QW>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+    (void)hipFuncSetAttribute((const void *)search_bound_kernel<QW>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
                               (int)lds);                                                                            \
-    hipLaunchKernelGGL(search_partial_kernel<QW>, grid, dim3(256), lds, s, db, db_sqnorm, n, q, qq, nq, k,          \
-                       p.rows_per_split, id_base, part_d, part_i)
+    hipLaunchKernelGGL(search_bound_kernel<QW>, grid_b, dim3(256), lds, s, db, db_sqnorm, p.b_rows, q, qq, nq,      \
+                       p.b_rows_per_split, gmin);                                                                   \
+    hipLaunchKernelGGL(search_thr_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, (const int *)gmin, nq, k, thr);      \
+    (void)hipFuncSetAttribute((const void *)search_scan_kernel<QW>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                              (int)lds);                                                                            \
+    hipLaunchKernelGGL(search_scan_kernel<QW>, grid, dim3(256), lds, s, db, db_sqnorm, n, q, qq, nq,                \
+                       p.rows_per_split, (const float *)thr, cnt, cand_d, cand_i)
     if (p.qw == 1) { SR_LAUNCH(1); }
     else if (p.qw == 2) { SR_LAUNCH(2); }
     else { SR_LAUNCH(4); }
 #undef SR_LAUNCH
-    GRAFP_CHECK_LAUNCH("search_partial_kernel");
-    hipLaunchKernelGGL(search_merge_kernel, dim3(nq), dim3(64), 0, s, part_d, part_i, p.splits, nq, k, out_dist,
-                       out_ids);
-    GRAFP_CHECK_LAUNCH("search_merge_kernel");
+    GRAFP_CHECK_LAUNCH("search_bound_kernel / search_scan_kernel");
+    hipLaunchKernelGGL(search_select_kernel, dim3(nq), dim3(256), 0, s, db, db_sqnorm, n, q, (const float *)qq, nq, k,
+                       id_base, (const float *)thr, (const int *)cnt, (const float *)cand_d, (const int *)cand_i,
+                       out_dist, out_ids);
+    GRAFP_CHECK_LAUNCH("search_select_kernel");
     return GRAFP_OK;
 }
 
@@ -435,7 +622,7 @@ extern "C" int grafp_merge_topk(const float *part_dist, const int64_t *part_ids,
     using namespace grafp;
     GRAFP_REQUIRE(part_dist && part_ids && out_dist && out_ids, "merge_topk: null pointer");
     GRAFP_REQUIRE(P >= 1 && nq >= 1 && k >= 1 && k <= GRAFP_SEARCH_MAX_K, "merge_topk: bad P=%d nq=%d k=%d", P, nq, k);
-    hipLaunchKernelGGL(search_merge_kernel, dim3(nq), dim3(64), 0, (hipStream_t)stream, part_dist, part_ids, P, nq, k,
+    hipLaunchKernelGGL(search_merge_kernel, dim3(nq), dim3(256), 0, (hipStream_t)stream, part_dist, part_ids, P, nq, k,
                        out_dist, out_ids);
     GRAFP_CHECK_LAUNCH("search_merge_kernel");
     return GRAFP_OK;

@@ -453,7 +453,7 @@ def row_sqnorm(m):
     return out
 
 
-def search_l2(db, db_sqnorm, q, k, id_base=0, max_queries_per_launch=16384):
+def search_l2(db, db_sqnorm, q, k, id_base=0, max_queries_per_launch=4096):
     """Exact squared-L2 top-k of q (nq,128) against the resident db (n,128): (dist f32, ids int64), (nq,k)."""
     _require_gpu(db, db_sqnorm, q)
     q = _f32c(q)

@@ -272,6 +272,35 @@ def test_search_edge_cases(dev):
     assert isinstance(I, np.ndarray) and np.array_equal(I, wi) and np.array_equal(D, wd)
 
 
+def test_search_candidate_overflow_rescan(dev):
+    """More exact ties than a query's candidate list holds (SR_CAP = 4096 in knn_search.hip): the select kernel
+    must fall back to its exact rescan and still return the lowest ids, bit-equal to the C oracle."""
+    from grafp_amd import ops
+    from oracle import native
+    db, q, _ = _planted(12000, 3, "overflow")
+    db = db.copy()
+    db[1000:7000] = db[1000]                                          # 6000 identical rows
+    qs = np.stack([db[1000], q[0], db[1000] * 0.5 + q[1] * 0.5]).astype(np.float32)
+    dbt = t(db).to(dev)
+    d, i = ops.search_l2(dbt, ops.row_sqnorm(dbt), t(qs).to(dev), 20)
+    wd, wi = native.flat_search_l2(db, qs, 20)
+    assert np.array_equal(i.cpu().numpy(), wi) and np.array_equal(d.cpu().numpy(), wd)
+    assert (i[0].cpu().numpy() == np.arange(1000, 1020)).all()
+
+
+@pytest.mark.parametrize("n,nq", [(1, 1), (31, 2), (33, 33), (127, 65), (4097, 40), (70001, 7)])
+def test_search_ragged_sizes(dev, n, nq):
+    """Row counts around the tile (32/64/128 rows) and sample (64k rows) boundaries, k > n included."""
+    from grafp_amd import ops
+    from oracle import native
+    db, q, _ = _planted(max(n, 64), max(nq, 8), f"ragged{n}")
+    db, q = db[:n], q[:nq]
+    dbt = t(db).to(dev)
+    d, i = ops.search_l2(dbt, ops.row_sqnorm(dbt), t(q).to(dev), 20)
+    wd, wi = native.flat_search_l2(db, q, 20)
+    assert np.array_equal(i.cpu().numpy(), wi) and np.array_equal(d.cpu().numpy(), wd)
+
+
 def test_merge_topk_and_sharded_search(dev):
     from grafp_amd import ops
     from oracle import native
