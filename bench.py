@@ -90,11 +90,13 @@ def summarise_kernels(timed, esize=4):
 
 def cpu_baseline(cfg, seconds):
     """The oracle's CPU train step (test infrastructure used ONLY as the reported baseline): B = 32 pairs,
-    log-mel -> peak extractor -> GraphEncoder -> projector -> NT-Xent, fwd + bwd + Adam, f32, all host
-    threads.  1 warm-up step, then timed steps until >= 3 steps or `seconds` have elapsed."""
+    log-mel -> peak extractor -> GraphEncoder -> projector -> NT-Xent, fwd + bwd + Adam, f32, on at most 32 host
+    threads (more only adds contention at this batch size).  1 warm-up step, then timed steps until >= 2 steps
+    or `seconds` have elapsed."""
     from grafp_amd.train import build_model
     from oracle import model as om
     B = 32
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
     torch.manual_seed(0)
     sd = {k: v.clone() for k, v in build_model(dict(cfg, bsz_train=B)).state_dict().items()}
     for k, v in sd.items():
@@ -112,10 +114,10 @@ def cpu_baseline(cfg, seconds):
         return om.train_step(sd, opt, S_i, S_j, cfg["tau"])
     step()
     n, t0 = 0, time.perf_counter()
-    while n < 3 or (time.perf_counter() - t0 < seconds and n < 50):
+    while n < 2 or (time.perf_counter() - t0 < seconds and n < 50):
         step()
         n += 1
-        if time.perf_counter() - t0 > 4 * seconds:
+        if time.perf_counter() - t0 > 2 * seconds:
             break
     dt = time.perf_counter() - t0
     return {"value": round(B * n / dt, 3), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
