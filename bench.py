@@ -208,6 +208,18 @@ def main():
                 "avg_launch_us": dom.get("avg_us"), "launches": dom.get("calls"),
                 "note": "exact-f32 MFMA (v_mfma_f32_32x32x2_f32); algorithmic flops 2*N^2*C per clip per block; "
                         "HIP events on the launch stream inside the timed region"}
+        # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes over this same command
+        # (FETCH_SIZE and WRITE_SIZE cannot share a pass); their committed summary is read back here.
+        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_knn_topk.json")
+        if os.path.exists(pmc_path):
+            with open(pmc_path) as f:
+                pmc = json.load(f)
+            if pmc.get("batch_per_gpu") == B and pmc.get("dtype") == args.dtype:
+                # gfx950: FETCH_SIZE tallies the 128-B requests of 16 B/lane streams at 64 B -> doubled
+                roof["traffic"] = int((2 * pmc["fetch_kb_per_launch"] + pmc["write_kb_per_launch"]) * 1024)
+                roof["traffic_unit"] = "bytes/launch"
+                roof["traffic_source"] = pmc.get("source")
+                roof["algorithmic_bytes_per_launch"] = pmc.get("algorithmic_bytes_per_launch")
         line = {
             "metric": "clips/sec contrastive step", "value": round(clips / elapsed, 2), "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
