@@ -125,7 +125,7 @@ def cpu_baseline(cfg, seconds):
                       f"steps in {dt:.1f} s"}
 
 
-def retrieval_probe(device):
+def retrieval_probe(device, cpu_check=True):
     """Secondary metric of BASELINE.json: exact top-20 search QPS on a 1 000 000 x 128 resident database
     (L2-normalised randn, seed 2), planted noisy queries; batch sizes 1, 41, 4096."""
     from grafp_amd import ops
@@ -151,6 +151,20 @@ def retrieval_probe(device):
             res["tflops_nq4096"] = round(2.0 * 128 * n * nq / dt / 1e12, 2)
         if nq == 1:
             res["db_stream_GBps_nq1"] = round(n * 516.0 / dt / 1e9, 1)
+    if cpu_check:
+        # CPU exact search beside it (oracle/csrc/flat_search.c, scalar, 1 thread) on a bounded sample of the
+        # nq=41 batch, which also checks the GPU's ids and distances bit for bit
+        from oracle import native
+        ns = 8
+        D, I = ops.search_l2(db, sq, q[:ns], 20)
+        db_h, q_h = db.cpu().numpy(), q[:ns].cpu().numpy()
+        t0 = time.perf_counter()
+        wd, wi = native.flat_search_l2(db_h, q_h, 20)
+        dt = time.perf_counter() - t0
+        res["cpu_baseline"] = {"value": round(ns / dt, 2), "unit": "queries/s", "cores": 1, "kind": "port",
+                               "sample": f"{ns} of the nq=41 queries against the full 1M x 128 database, {dt:.1f} s"}
+        res["ids_equal_cpu_exact"] = bool((I.cpu().numpy() == wi).all())
+        res["dist_equal_cpu_exact"] = bool((D.cpu().numpy() == wd).all())
     return res
 
 
@@ -234,7 +248,7 @@ def main():
             "kernels": kernels,
         }
         if world == 1 and not args.no_retrieval:
-            line["retrieval"] = retrieval_probe(device)
+            line["retrieval"] = retrieval_probe(device, cpu_check=not args.no_cpu_baseline)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, args.cpu_baseline_seconds)
         print(json.dumps(line), flush=True)

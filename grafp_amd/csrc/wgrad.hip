@@ -6,8 +6,10 @@
 // torch_nn.py:56, encoder/graph_encoder.py:52-55,131,156) w.r.t. its weight.  The output is tiny (64x64 ... 2048x512)
 // and the contraction is enormous, with BOTH operands contiguous along the contraction: the library GEMM reaches
 // ~10 TFLOP/s here (80-210 us where the operands stream in 13-34 us).  It is a streaming reduction:
-//   * split-K: blockIdx.x owns a slice of M; blockIdx.y a 64x64 output tile; blockIdx.z a conv group;
-//   * 128-column chunks of the G and X tiles are staged in LDS with coalesced 16-byte loads;
+//   * split-K: a block owns a slice of M and a 64x64 (128x128) output tile, blockIdx.z a conv group; blocks are
+//     numbered so that the tiles of one slice run next to each other on one XCD;
+//   * 128-column chunks of the G and X tiles go HBM -> registers (one chunk ahead of the MFMAs) -> LDS with
+//     coalesced 16-byte loads;
 //   * each of the 4 waves owns a 32x32 quadrant: A and B fragments of v_mfma_f32_32x32x16_bf16 are 16 contiguous
 //     bytes of a G / X row (8 consecutive m), read with ds_read_b128 from rows padded to 272 B (conflict-free);
 //   * partial tiles go to a (S, Cout, Cin/g) f32 scratch, summed by wgrad_reduce_kernel (deterministic, no atomics).
@@ -26,14 +28,19 @@ constexpr int WG_LS = WG_KC * 2 + 16;    // LDS row stride in bytes (272: ds_rea
 template <int TW>
 __global__ __launch_bounds__(256) void wgrad_partial_kernel(const unsigned short *__restrict__ G,
                                                             const unsigned short *__restrict__ X, int64_t M,
-                                                            int cout_g, int cin_g, int tiles_c, int64_t cols_per_split,
+                                                            int cout_g, int cin_g, int tiles_o, int tiles_c,
+                                                            int64_t cols_per_split,
                                                             float *__restrict__ part) {
     constexpr int Q = TW / 2;        // quadrant edge per wave
     constexpr int NT = Q / 32;       // MFMA tiles per quadrant edge
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *sG = smem, *sX = smem + TW * WG_LS;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
-    const int split = blockIdx.x, tile = blockIdx.y, grp = blockIdx.z;
+    // one XCD (= one L2) owns a contiguous range of logical blocks, and the output tiles of one K-slice are
+    // consecutive logical blocks: tiles that re-read the same G rows / X rows of a slice hit that L2
+    const int ntiles = tiles_o * tiles_c;
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = logical / ntiles, tile = logical - split * ntiles, grp = blockIdx.z;
     const int o0 = (tile / tiles_c) * TW, c0 = (tile % tiles_c) * TW;
     const unsigned short *Gg = G + (size_t)grp * cout_g * M;
     const unsigned short *Xg = X + (size_t)grp * cin_g * M;
@@ -50,9 +57,9 @@ __global__ __launch_bounds__(256) void wgrad_partial_kernel(const unsigned short
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
     const bool vec_ok = (M & 7) == 0;
-    for (int64_t m0 = m_begin; m0 < m_end; m0 += WG_KC) {
-        __syncthreads();
-        // stage TW rows x 128 columns of G and X: thread -> (row = i*16 + tid/16, 16-byte column tid%16)
+    // chunk m0 of both operands -> registers: thread -> (row = i*16 + tid/16, 16-byte column tid%16)
+    uint4 pg[TW / 16], px[TW / 16];
+    auto fetch = [&](int64_t m0) {
 #pragma unroll
         for (int i = 0; i < TW / 16; ++i) {
             const int row = i * 16 + (tid >> 4), cb = tid & 15;
@@ -70,10 +77,21 @@ __global__ __launch_bounds__(256) void wgrad_partial_kernel(const unsigned short
                 vg = make_uint4(tg[0] | (tg[1] << 16), tg[2] | (tg[3] << 16), tg[4] | (tg[5] << 16), tg[6] | (tg[7] << 16));
                 vx = make_uint4(tx[0] | (tx[1] << 16), tx[2] | (tx[3] << 16), tx[4] | (tx[5] << 16), tx[6] | (tx[7] << 16));
             }
-            *reinterpret_cast<uint4 *>(sG + row * WG_LS + cb * 16) = vg;
-            *reinterpret_cast<uint4 *>(sX + row * WG_LS + cb * 16) = vx;
+            pg[i] = vg;
+            px[i] = vx;
+        }
+    };
+    if (m_begin < m_end) fetch(m_begin);
+    for (int64_t m0 = m_begin; m0 < m_end; m0 += WG_KC) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TW / 16; ++i) {
+            const int row = i * 16 + (tid >> 4), cb = tid & 15;
+            *reinterpret_cast<uint4 *>(sG + row * WG_LS + cb * 16) = pg[i];
+            *reinterpret_cast<uint4 *>(sX + row * WG_LS + cb * 16) = px[i];
         }
         __syncthreads();
+        if (m0 + WG_KC < m_end) fetch(m0 + WG_KC);      // in flight while this chunk is multiplied
         const unsigned char *ga = sG + (wo * Q + l31) * WG_LS + half * 16;
         const unsigned char *xa = sX + (wc * Q + l31) * WG_LS + half * 16;
 #pragma unroll
@@ -131,7 +149,7 @@ struct WgradPlan {
 };
 static WgradPlan wgrad_plan(int cout_g, int cin_g, int groups, int64_t M) {
     WgradPlan p;
-    p.tw = (cout_g >= 256 && cin_g >= 256) ? 128 : 64;
+    p.tw = (cout_g >= 128 && cin_g >= 128 && (int64_t)cout_g * cin_g >= 65536) ? 128 : 64;   // measured crossover
     p.tiles_o = (cout_g + p.tw - 1) / p.tw;
     p.tiles_c = (cin_g + p.tw - 1) / p.tw;
     const int64_t tiles = (int64_t)p.tiles_o * p.tiles_c * groups;
@@ -173,17 +191,17 @@ extern "C" int grafp_conv1x1_wgrad_bf16(const void *grad_out, const void *x, int
     }
     const int cout_g = Cout / groups, cin_g = Cin / groups;
     const WgradPlan p = wgrad_plan(cout_g, cin_g, groups, M);
-    GRAFP_REQUIRE(p.tiles_o * p.tiles_c <= 65535, "conv1x1_wgrad: output too large");
+    GRAFP_REQUIRE((int64_t)p.S * p.tiles_o * p.tiles_c < (1ll << 31), "conv1x1_wgrad: output too large");
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid(p.S, p.tiles_o * p.tiles_c, groups);
+    const dim3 grid(p.S * p.tiles_o * p.tiles_c, 1, groups);
     const size_t lds = (size_t)2 * p.tw * WG_LS;
     if (p.tw == 64) {
         hipLaunchKernelGGL(wgrad_partial_kernel<64>, grid, dim3(256), lds, s, (const unsigned short *)grad_out,
-                           (const unsigned short *)x, M, cout_g, cin_g, p.tiles_c, p.cols, (float *)ws);
+                           (const unsigned short *)x, M, cout_g, cin_g, p.tiles_o, p.tiles_c, p.cols, (float *)ws);
     } else {
         (void)hipFuncSetAttribute((const void *)wgrad_partial_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(wgrad_partial_kernel<128>, grid, dim3(256), lds, s, (const unsigned short *)grad_out,
-                           (const unsigned short *)x, M, cout_g, cin_g, p.tiles_c, p.cols, (float *)ws);
+                           (const unsigned short *)x, M, cout_g, cin_g, p.tiles_o, p.tiles_c, p.cols, (float *)ws);
     }
     GRAFP_CHECK_LAUNCH("wgrad_partial_kernel");
     const int64_t n = (int64_t)Cout * cin_g;
