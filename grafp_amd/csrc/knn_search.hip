@@ -47,11 +47,23 @@ __device__ __forceinline__ bool lex_lt(float d1, I i1, float d2, I i2) {
     return d1 < d2 || (d1 == d2 && i1 < i2);
 }
 
-__device__ __forceinline__ long long shfl_xor_i(long long v, int m) {
-    int lo = __shfl_xor((int)(v & 0xffffffffll), m), hi = __shfl_xor((int)(v >> 32), m);
+// value of lane (lane ^ j), j a power of two (compile-time after unrolling): DPP for 1, 2, 8 (no LDS crossbar trip),
+// ds_swizzle for 4 and 16, ds_bpermute only across the two 32-lane halves
+__device__ __forceinline__ int xor_lane(int v, int j) {
+    switch (j) {
+        case 1: return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+        case 2: return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+        case 8: return __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, true);   // row_ror:8
+        case 4: return __builtin_amdgcn_ds_swizzle(v, (4 << 10) | 0x1F);           // bit mode: xor 4
+        case 16: return __builtin_amdgcn_ds_swizzle(v, (16 << 10) | 0x1F);         // bit mode: xor 16
+        default: return __shfl_xor(v, j);
+    }
+}
+__device__ __forceinline__ float xor_lane(float v, int j) { return __int_as_float(xor_lane(__float_as_int(v), j)); }
+__device__ __forceinline__ long long xor_lane(long long v, int j) {
+    const int lo = xor_lane((int)(v & 0xffffffffll), j), hi = xor_lane((int)(v >> 32), j);
     return ((long long)hi << 32) | (unsigned int)lo;
 }
-__device__ __forceinline__ int shfl_xor_i(int v, int m) { return __shfl_xor(v, m); }
 
 // 64-lane bitonic sort, one (d, i) pair per lane, ascending by (d, i)
 template <typename I>
@@ -60,8 +72,8 @@ __device__ __forceinline__ void wave_sort64(float &d, I &i, int lane) {
     for (int k = 2; k <= 64; k <<= 1) {
 #pragma unroll
         for (int j = k >> 1; j > 0; j >>= 1) {
-            const float od = __shfl_xor(d, j);
-            const I oi = shfl_xor_i(i, j);
+            const float od = xor_lane(d, j);
+            const I oi = xor_lane(i, j);
             const bool want_min = ((lane & j) == 0) == ((lane & k) == 0);
             const bool take = want_min ? lex_lt(od, oi, d, i) : lex_lt(d, i, od, oi);
             d = take ? od : d;
@@ -78,9 +90,11 @@ struct WaveTop {
     int ti;
     float thr;
     int pc;
+    bool empty;
     float *pd;
     int *pi;
     __device__ __forceinline__ void init(float *qd, int *qi, float thr0) {
+        empty = true;
         td = INFINITY;
         ti = SR_EMPTY;
         thr = thr0;
@@ -90,7 +104,15 @@ struct WaveTop {
     }
     __device__ __forceinline__ void fold(int k, int lane) {
         WAVE_SYNC();
-        for (int off = 0; off < pc; off += 32) {
+        int off = 0;
+        if (empty) {                       // nothing kept yet: the first sort takes 64 queue entries
+            td = lane < pc ? pd[lane] : INFINITY;
+            ti = lane < pc ? pi[lane] : SR_EMPTY;
+            wave_sort64(td, ti, lane);
+            off = 64;
+            empty = false;
+        }
+        for (; off < pc; off += 32) {
             float d = td;
             int i = ti;
             if (lane >= 32) {
@@ -394,21 +416,32 @@ __global__ __launch_bounds__(256) void search_select_kernel(const float *__restr
         }
     }
     if (top.pc > 0) top.fold(k, lane);
-    if (lane < 32) {
+    // merge the four wave lists as a tree: (0,1) and (2,3) in parallel, then the two winners
+    if ((wave & 1) && lane < 32) {
         wtop_d[wave][lane] = top.td;
         wtop_i[wave][lane] = top.ti;
     }
     __syncthreads();
-    if (wave == 0) {
-        float td = top.td;
-        int ti = top.ti;
-        for (int w = 1; w < 4; ++w) {
-            if (lane >= 32) {
-                td = wtop_d[w][lane - 32];
-                ti = wtop_i[w][lane - 32];
-            }
-            wave_sort64(td, ti, lane);
+    float td = top.td;
+    int ti = top.ti;
+    if (!(wave & 1)) {
+        if (lane >= 32) {
+            td = wtop_d[wave + 1][lane - 32];
+            ti = wtop_i[wave + 1][lane - 32];
         }
+        wave_sort64(td, ti, lane);
+        if (wave == 2 && lane < 32) {
+            wtop_d[2][lane] = td;
+            wtop_i[2][lane] = ti;
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        if (lane >= 32) {
+            td = wtop_d[2][lane - 32];
+            ti = wtop_i[2][lane - 32];
+        }
+        wave_sort64(td, ti, lane);
         if (lane < k) {
             out_d[(size_t)qi * k + lane] = td;
             out_i[(size_t)qi * k + lane] = ti == SR_EMPTY ? (int64_t)-1 : id_base + (int64_t)ti;

@@ -28,6 +28,9 @@ def init_from_env(backend=None):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if torch.cuda.is_available():
+        # GRAFP_LOCAL_DEVICE / GRAFP_DIST_BACKEND: test hooks for a box with fewer GPUs than ranks (several ranks
+        # share one device over gloo: same code path, no RCCL); unset in production
+        local = int(os.environ.get("GRAFP_LOCAL_DEVICE", local))
         torch.cuda.set_device(local)
         device = torch.device("cuda", local)
     else:
@@ -35,7 +38,7 @@ def init_from_env(backend=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        backend = backend or ("nccl" if device.type == "cuda" else "gloo")
+        backend = backend or os.environ.get("GRAFP_DIST_BACKEND") or ("nccl" if device.type == "cuda" else "gloo")
         kw = {"device_id": device} if backend == "nccl" else {}
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return rank, world, device
@@ -181,10 +184,20 @@ class ShardedFlatL2Index:
         self.ntotal += n
 
     def search(self, q, k):
+        """numpy in -> numpy out, tensors in -> tensors out (like FlatL2Index.search).  The local search, the
+        all-gather and the merge all stay on the local index's device."""
+        as_numpy = not torch.is_tensor(q)
+        dev = getattr(self.local, "device", None)
+        if dev is not None:
+            q = torch.as_tensor(q).to(dev, dtype=torch.float32)
         D, I = self.local.search(q, k)
-        if self.world == 1:
-            return D, I
-        D, I = torch.as_tensor(D), torch.as_tensor(I)
+        if self.world > 1:
+            D, I = self._gather_merge(torch.as_tensor(D), torch.as_tensor(I))
+        if as_numpy and torch.is_tensor(D):
+            return D.cpu().numpy(), I.cpu().numpy()
+        return D, I
+
+    def _gather_merge(self, D, I):
         nq, kk = D.shape
         gd = torch.empty((self.world * nq, kk), dtype=D.dtype, device=D.device)
         gi = torch.empty((self.world * nq, kk), dtype=I.dtype, device=I.device)

@@ -1,0 +1,58 @@
+"""Worker of tests/test_gpu_dist.py: one of WORLD_SIZE ranks sharing cuda:0 over gloo (GRAFP_LOCAL_DEVICE=0,
+GRAFP_DIST_BACKEND=gloo).  Runs one data-parallel training step on its shard of a fixed batch with the real HIP
+kernels and writes its loss share, a few all-reduced gradients and its sharded-search result to OUT.rank.pt."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from grafp_amd import dist as gdist                                    # noqa: E402
+from grafp_amd.train import Trainer, build_model, synthetic_batch      # noqa: E402
+from grafp_amd.util import load_config                                 # noqa: E402
+
+
+def main():
+    out, B = sys.argv[1], int(sys.argv[2])
+    rank, world, device = gdist.init_from_env()
+    cfg = load_config()
+    cfg["bsz_train"] = B
+    torch.manual_seed(1234)
+    model = build_model(cfg, device=device)
+    trainer = Trainer(cfg, model, device, amp_dtype=None)
+    x_i, x_j = synthetic_batch(B, 7, device)
+    per = B // world
+    lo = rank * per
+    # the step of Trainer.step without the optimizer update, so that the gradients can be inspected
+    model.train()
+    trainer.sync.zero()
+    with torch.no_grad():
+        X_i, X_j = trainer.augment(x_i[lo:lo + per], x_j[lo:lo + per])
+    _, _, z_i, z_j = model(X_i, X_j)
+    loss = gdist.ntxent_global(z_i, z_j, cfg["tau"])
+    loss.backward()
+    trainer.sync.finish()
+    torch.cuda.synchronize()
+    names = ["encoder.stem.0.weight", "encoder.backbone.0.0.fc1.0.weight", "encoder.backbone.7.1.fc2.0.weight",
+             "encoder.proj.bias", "projector.0.weight", "peak_extractor.convs.0.weight"]
+    params = dict(model.named_parameters())
+    grads = {n: params[n].grad.detach().float().cpu().clone() for n in names if n in params}
+    total = torch.sqrt(sum((p.grad.float() ** 2).sum() for p in model.parameters() if p.grad is not None)).item()
+
+    # sharded exact search on the same ranks
+    gen = torch.Generator().manual_seed(3)
+    db = torch.nn.functional.normalize(torch.randn(5000, 128, generator=gen), dim=1)
+    q = torch.nn.functional.normalize(db[::97][:20] + 0.05 * torch.randn(20, 128, generator=gen), dim=1)
+    index = gdist.ShardedFlatL2Index(128)
+    index.add_global(db.numpy())
+    D, I = index.search(q.numpy(), 10)
+    torch.save({"loss_share": float(loss), "grads": grads, "grad_norm": total, "z_i": z_i.detach().cpu(),
+                "D": torch.as_tensor(D).cpu(), "I": torch.as_tensor(I).cpu()}, f"{out}.{rank}.pt")
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

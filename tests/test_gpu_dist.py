@@ -1,0 +1,103 @@
+"""Data-parallel path with the real HIP kernels: two ranks share cuda:0 over gloo (the GPU box has one GPU, so RCCL
+itself is out of reach here; everything around the collectives -- shard, all-gather of (z_i, z_j), local rows x
+global columns NT-Xent, flat-buffer bucketed gradient all-reduce from autograd hooks, sharded search + merge -- is
+the production code).  Compared with ONE process that pushes the two shards through the model one after the other
+(per-replica BatchNorm statistics, as under the reference's DataParallel, train.py:165-168) and takes the loss over
+the concatenated batch."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _launch(world, out, B):
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT="29653", GRAFP_LOCAL_DEVICE="0", GRAFP_DIST_BACKEND="gloo",
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_dist_gpu_worker.py"), out, str(B)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    for p in procs:
+        log, _ = p.communicate(timeout=600)
+        assert p.returncode == 0, log[-3000:]
+
+
+def test_two_ranks_match_one_process(tmp_path):
+    from grafp_amd import ops
+    from grafp_amd.simclr.ntxent import ntxent_loss
+    from grafp_amd.train import Trainer, build_model, synthetic_batch
+    from grafp_amd.util import load_config
+    B = 8
+    out = str(tmp_path / "w2")
+    _launch(2, out, B)
+    got = [torch.load(f"{out}.{r}.pt") for r in range(2)]
+
+    device = torch.device("cuda:0")
+    cfg = load_config()
+    cfg["bsz_train"] = B
+    torch.manual_seed(1234)
+    model = build_model(cfg, device=device)
+    trainer = Trainer(cfg, model, device, amp_dtype=None)
+    x_i, x_j = synthetic_batch(B, 7, device)
+    model.train()
+    zs_i, zs_j = [], []
+    for lo in (0, B // 2):
+        with torch.no_grad():
+            X_i, X_j = trainer.augment(x_i[lo:lo + B // 2], x_j[lo:lo + B // 2])
+        _, _, z_i, z_j = model(X_i, X_j)
+        zs_i.append(z_i); zs_j.append(z_j)
+    loss = ntxent_loss(torch.cat(zs_i), torch.cat(zs_j), cfg)
+    loss.backward()
+    # embeddings of each shard: same kernels, same inputs -> equal up to the k-NN near-tie sensitivity (none expected
+    # between two runs of the same code on the same device)
+    for r in range(2):
+        assert torch.allclose(got[r]["z_i"], zs_i[r].detach().cpu(), rtol=0, atol=1e-6)
+    loss_v = float(loss.detach())
+    assert abs(got[0]["loss_share"] + got[1]["loss_share"] - loss_v) <= 1e-5 * max(1.0, abs(loss_v))
+    params = dict(model.named_parameters())
+    for name, g in got[0]["grads"].items():
+        want = params[name].grad.detach().float().cpu()
+        rel = (g - want).norm() / want.norm().clamp_min(1e-12)
+        assert rel < 2e-4, (name, float(rel))
+        assert torch.equal(g, got[1]["grads"][name])                   # every rank holds the same reduced gradient
+    want_norm = torch.sqrt(sum((p.grad.float() ** 2).sum() for p in model.parameters() if p.grad is not None)).item()
+    assert abs(got[0]["grad_norm"] - want_norm) <= 2e-4 * want_norm
+
+    # sharded search == unsharded search, on both ranks
+    gen = torch.Generator().manual_seed(3)
+    db = torch.nn.functional.normalize(torch.randn(5000, 128, generator=gen), dim=1)
+    q = torch.nn.functional.normalize(db[::97][:20] + 0.05 * torch.randn(20, 128, generator=gen), dim=1)
+    dbd = db.to(device)
+    D, I = ops.search_l2(dbd, ops.row_sqnorm(dbd), q.to(device), 10)
+    for r in range(2):
+        assert torch.equal(got[r]["I"], I.cpu()) and torch.equal(got[r]["D"], D.cpu())
+
+
+def test_bench_two_ranks_one_gpu(tmp_path):
+    """bench.py's N > 1 path end to end (barriers, MAX over ranks, rank-0 JSON line) with both ranks on cuda:0."""
+    import json
+    root = os.path.dirname(HERE)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT="29654", GRAFP_LOCAL_DEVICE="0", GRAFP_DIST_BACKEND="gloo",
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
+                                       "--warmup", "1", "--batch-per-gpu", "16", "--no-cpu-baseline", "--no-retrieval"],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    logs = []
+    for p in procs:
+        log, _ = p.communicate(timeout=900)
+        assert p.returncode == 0, log[-3000:]
+        logs.append(log)
+    lines = [ln for ln in logs[0].splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and not any(ln.startswith("{") for ln in logs[1].splitlines())
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    assert line["config"]["global_batch"] == 32 and line["roofline"]["frac"] > 0
