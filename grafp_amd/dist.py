@@ -7,9 +7,9 @@ global, train.py:69-71) and reduces 73.5 MB of gradients to GPU 0.  Here:
   * ONE all-gather of the stacked (z_i, z_j) per step (2 * B/R * 128 f32 per rank: latency-bound, so both
     views travel in a single call); each rank then evaluates its own rows against the global columns with
     ops.ntxent, whose backward already returns d(global loss)/d(local z): no collective in backward;
-  * gradients live in ONE flat f32 buffer (parameter .grad tensors are views into it) and are summed
+  * gradients are packed bucket by bucket (one multi-tensor copy each) into ONE flat f32 buffer and summed
     with a few large all-reduces launched from autograd hooks as soon as a bucket is complete (overlap
-    with the rest of backward).  xGMI is point-to-point, ring collectives are per-link bound (~153 GB/s):
+    with the rest of backward); afterwards every .grad is a view of the reduced buffer.  xGMI is point-to-point, ring collectives are per-link bound (~153 GB/s):
     few, large buckets (default 4 x ~18 MB) keep the ring busy without paying per-call latency 100+ times;
   * the fingerprint database is sharded by contiguous row ranges; a search is a local top-k, one
     all-gather of (nq, k) candidates and a local merge.
@@ -101,20 +101,21 @@ class GradSync:
         # every bucket is a contiguous slice that completes early
         order = list(reversed(self.params))
         per_bucket = (total + n_buckets - 1) // max(1, n_buckets)
-        self.bounds, self._bucket_of, off, b_lo = [], {}, 0, 0
+        self.bounds, self._bucket_of, self._view, self._members, off, b_lo = [], {}, {}, [[]], 0, 0
         for p in order:
             n = p.numel()
-            p.grad = self.flat[off:off + n].view_as(p)
+            self._view[id(p)] = self.flat[off:off + n].view_as(p)
             self._bucket_of[id(p)] = len(self.bounds)
+            self._members[-1].append(p)
             off += n
             if off - b_lo >= per_bucket:
                 self.bounds.append((b_lo, off))
+                self._members.append([])
                 b_lo = off
         if b_lo < off:
             self.bounds.append((b_lo, off))
-        self._size = [0] * len(self.bounds)
-        for p in self.params:
-            self._size[self._bucket_of[id(p)]] += 1
+        self._members = self._members[:len(self.bounds)]
+        self._size = [len(m) for m in self._members]
         self._left, self._handles, self._fired = list(self._size), [], [False] * len(self.bounds)
         self._hooks = []
         if overlap and self.world > 1:
@@ -122,16 +123,30 @@ class GradSync:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
     def zero(self):
-        """Use instead of optimizer.zero_grad(): keeps every .grad a view of the flat buffer."""
-        if self.flat is None:
-            for p in self.params:
-                p.grad = None
-        else:
-            self.flat.zero_()
+        """Use instead of optimizer.zero_grad(): autograd then ASSIGNS fresh gradients (no per-parameter accumulate
+        kernels); finish() leaves every .grad a view of the flat buffer."""
+        for p in self.params:
+            p.grad = None
+
+    def _pack(self, b):
+        """Bucket b's gradients -> its slice of the flat buffer: one multi-tensor copy."""
+        members = self._members[b]
+        have = [p for p in members if p.grad is not None and p.grad.data_ptr() != self._view[id(p)].data_ptr()]
+        if len(have) != len(members):
+            lo, hi = self.bounds[b]
+            missing = [p for p in members if p.grad is None]
+            if missing:
+                self.flat[lo:hi].zero_()           # parameters that took no part in this step contribute zero
+                have = [p for p in members if p.grad is not None]
+        if have:
+            torch._foreach_copy_([self._view[id(p)] for p in have], [p.grad for p in have])
 
     def _launch(self, b):
+        self._pack(b)
         lo, hi = self.bounds[b]
-        self._handles.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if self.world > 1:
+            self._handles.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group,
+                                                 async_op=True))
         self._fired[b] = True
 
     def _on_grad(self, p):
@@ -141,15 +156,17 @@ class GradSync:
             self._launch(b)
 
     def finish(self):
-        """Call after backward(): launches whatever has not fired, waits for all buckets."""
+        """Call after backward(): launches whatever has not fired, waits for all buckets, and points every .grad at
+        its (reduced) slice of the flat buffer."""
         if self.flat is None:
             return
-        if self.world > 1:
-            for b in range(len(self.bounds)):
-                if not self._fired[b]:
-                    self._launch(b)
-            for h in self._handles:
-                h.wait()
+        for b in range(len(self.bounds)):
+            if not self._fired[b]:
+                self._launch(b)
+        for h in self._handles:
+            h.wait()
+        for p in self.params:
+            p.grad = self._view[id(p)]
         self._handles, self._left, self._fired = [], list(self._size), [False] * len(self.bounds)
 
 
