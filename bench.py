@@ -151,6 +151,30 @@ def retrieval_probe(device, cpu_check=True):
             res["tflops_nq4096"] = round(2.0 * 128 * n * nq / dt / 1e12, 2)
         if nq == 1:
             res["db_stream_GBps_nq1"] = round(n * 516.0 / dt / 1e9, 1)
+    # BASELINE config 4 end to end: 2000 test ids x 41-segment runs = 82 000 query segments, one batched search, then
+    # ONE rerank launch over the 8000 (test id, length) items for lengths 1/11/21/41 (eval.py:262-301)
+    n_ids, lens = 2000, (1, 11, 21, 41)
+    starts = torch.randint(0, n - 41, (n_ids,), generator=gen, device=device)
+    seg = (starts[:, None] + torch.arange(41, device=device)[None, :]).reshape(-1)
+    qs = torch.nn.functional.normalize(db[seg] + 0.08 * torch.randn(seg.numel(), 128, generator=gen, device=device),
+                                       dim=1)
+    item_row = (torch.arange(n_ids, device=device) * 41).repeat_interleave(len(lens))
+    item_len = torch.tensor(lens, dtype=torch.int32, device=device).repeat(n_ids)
+    for _ in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        _, I_seg = ops.search_l2(db, sq, qs, 20)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        pred, _ = ops.seq_rerank(db, qs, I_seg, item_row, item_len, top=10)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+    hit = (pred[:, 0].reshape(n_ids, len(lens)) == starts[:, None]).float().mean(0)
+    res["eval_pipeline"] = {"segments": int(seg.numel()), "items": int(item_row.numel()), "lengths": list(lens),
+                            "search_ms": round((t1 - t0) * 1e3, 2), "rerank_ms": round((t2 - t1) * 1e3, 3),
+                            "segment_qps": round(seg.numel() / (t1 - t0), 1),
+                            "items_per_s": round(item_row.numel() / (t2 - t1), 1),
+                            "top1_hit_rate_by_length": [round(float(h), 4) for h in hit]}
     if cpu_check:
         # CPU exact search beside it (oracle/csrc/flat_search.c, scalar, 1 thread) on a bounded sample of the
         # nq=41 batch, which also checks the GPU's ids and distances bit for bit

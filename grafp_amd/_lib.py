@@ -51,6 +51,7 @@ SIGNATURES = {
     "grafp_knn_search_workspace": (_Z, [_L, _I, _I, _I]),
     "grafp_knn_search_l2_f32": (_I, [_P, _P, _L, _P, _I, _I, _I, _L, _P, _P, _P, _Z, _P]),
     "grafp_merge_topk": (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),
+    "grafp_seq_rerank_f32": (_I, [_P, _L, _P, _L, _P, _I, _P, _P, _I, _I, _I, _P, _P, _P]),
 }
 
 

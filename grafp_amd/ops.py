@@ -485,6 +485,31 @@ def merge_topk(part_d, part_i):
     return out_d, out_i
 
 
+def seq_rerank(index_rows, q_rows, topk_ids, item_row, item_len, top=10):
+    """Sequence-level rerank of batched segment-search results (eval.py:272-290, one workgroup per item).
+    index_rows (n,128) f32 resident database, q_rows (n_q,128) f32, topk_ids (n_q,k) int64, item_row (n_items) int64
+    first query row of each item, item_len (n_items) int32 segments per item.
+    Returns (ids int64 (n_items, top) best first, -1 padded; scores f32 (n_items, top), -inf padded)."""
+    _require_gpu(index_rows, q_rows, topk_ids, item_row, item_len)
+    index_rows, q_rows = _f32c(index_rows), _f32c(q_rows)
+    topk_ids = topk_ids.to(torch.int64).contiguous()
+    item_row = item_row.to(torch.int64).contiguous()
+    item_len = item_len.to(torch.int32).contiguous()
+    n_items = item_row.shape[0]
+    out_i = torch.empty((n_items, top), dtype=torch.int64, device=index_rows.device)
+    out_s = torch.empty((n_items, top), dtype=torch.float32, device=index_rows.device)
+    if n_items == 0:
+        return out_i, out_s
+    max_len = int(item_len.max().item())
+    if int((item_row + item_len.to(torch.int64)).max().item()) > q_rows.shape[0] or int(item_row.min().item()) < 0:
+        raise ValueError("seq_rerank: an item reaches outside q_rows")
+    with _timed("seq_rerank", (n_items, max_len, topk_ids.shape[1])):
+        check(lib.grafp_seq_rerank_f32(_p(index_rows), index_rows.shape[0], _p(q_rows), q_rows.shape[0], _p(topk_ids),
+                                       topk_ids.shape[1], _p(item_row), _p(item_len), n_items, max_len, top,
+                                       _p(out_i), _p(out_s), _stream()), "seq_rerank")
+    return out_i, out_s
+
+
 class FlatL2Index:
     """Drop-in for the subset of faiss.IndexFlatL2 that eval.py uses: d, ntotal, add(x), search(q, k).
     The database lives in HBM; `add` also computes the per-row squared norms once."""
@@ -514,6 +539,10 @@ class FlatL2Index:
             self._chunks = [self._db]
             self._sq = row_sqnorm(self._db)
         return self._db, self._sq
+
+    def rows(self):
+        """The resident (ntotal, d) f32 database tensor (what faiss calls reconstruct_n(0, ntotal))."""
+        return self._materialise()[0]
 
     def search(self, q, k):
         """numpy in -> numpy out (D float32 (nq,k), I int64 (nq,k)), like faiss; tensors in -> tensors out."""

@@ -203,6 +203,18 @@ int grafp_knn_search_l2_f32(const float *db, const float *db_sqnorm, int64_t n, 
 int grafp_merge_topk(const float *part_dist, const int64_t *part_ids, int P, int nq, int k, float *out_dist,
                      int64_t *out_ids, grafp_stream_t stream);
 
+/* ---- sequence-level rerank of the segment search results ----------------------------
+ * Replaces the per-item Python loop of eval.py:262-290 after ONE batched segment search:
+ *   index_rows (n,128) f32      the resident database = the reference's fake_recon_index (dummy_db then db)
+ *   q_rows (n_qrows,128) f32    the searched query segments; topk_ids (n_qrows,k) int64 their search results
+ *   item i = query rows [item_row[i], item_row[i] + item_len[i]), item_len[i] <= max_len <= 64, max_len*k <= 2048
+ *   out_ids (n_items,top) int64 candidate start ids, best first (score descending, then lowest id), -1 padded
+ *   out_scores (n_items,top) f32 mean_t <q[t], index[cid+t]> over the rows that exist; -inf padded
+ * Arithmetic order fixed in oracle/csrc/seq_rerank.c. */
+int grafp_seq_rerank_f32(const float *index_rows, int64_t n, const float *q_rows, int64_t n_qrows,
+                         const int64_t *topk_ids, int k, const int64_t *item_row, const int *item_len, int n_items,
+                         int max_len, int top, int64_t *out_ids, float *out_scores, grafp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -43,6 +43,10 @@ def lib():
         L.oracle_merge_topk.restype = None
         L.oracle_row_sqnorm.argtypes = [f32p, ctypes.c_int64, ctypes.c_int, f32p]
         L.oracle_row_sqnorm.restype = None
+        i32p = ctypes.POINTER(ctypes.c_int32)
+        L.oracle_seq_rerank.argtypes = [f32p, ctypes.c_int64, f32p, i64p, ctypes.c_int, i64p, i32p, ctypes.c_int,
+                                        ctypes.c_int, i64p, f32p]
+        L.oracle_seq_rerank.restype = ctypes.c_int
         _LIB = L
     return _LIB
 
@@ -93,3 +97,21 @@ def merge_topk(pd, pi):
     oi = np.empty((nq, k), dtype=np.int64)
     lib().oracle_merge_topk(pdp, _i64(pi), P, nq, k, od.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), _i64(oi))
     return od, oi
+
+
+def seq_rerank(index_rows, q_rows, topk_ids, item_row, item_len, top=10):
+    """csrc/seq_rerank.c: (out_ids int64 (n_items, top), out_scores f32 (n_items, top))."""
+    index_rows, ip = _f32(index_rows)
+    q_rows, qp = _f32(q_rows)
+    topk_ids = np.ascontiguousarray(topk_ids, dtype=np.int64)
+    item_row = np.ascontiguousarray(item_row, dtype=np.int64)
+    item_len = np.ascontiguousarray(item_len, dtype=np.int32)
+    n_items = len(item_row)
+    oi = np.empty((n_items, top), dtype=np.int64)
+    os_ = np.empty((n_items, top), dtype=np.float32)
+    rc = lib().oracle_seq_rerank(ip, index_rows.shape[0], qp, _i64(topk_ids), topk_ids.shape[1], _i64(item_row),
+                                 item_len.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), n_items, top, _i64(oi),
+                                 os_.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+    if rc != 0:
+        raise ValueError(f"oracle_seq_rerank failed ({rc})")
+    return oi, os_

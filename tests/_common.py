@@ -181,3 +181,32 @@ class ReplayGraphs:
 
     def __exit__(self, *exc):
         self._ops.knn_graph = self._orig
+
+
+# ---- synthetic {query, db, dummy_db} set for the eval_faiss goldens (tests/golden/make_eval_golden.py) ------------
+def eval_case():
+    """dummy_db (400,128), db (150,128), query = db + row-dependent noise (so that some items miss), all rows
+    L2-normalised; 40 test ids; lengths 1 3 5 9; k_probe 20.  Everything comes from the closed-form hash filler."""
+    def unit(a):
+        return (a / np.linalg.norm(a, axis=1, keepdims=True)).astype(np.float32)
+    dummy = unit(hash_normalish("eval:dummy", (400, 128)))
+    db = hash_normalish("eval:db", (150, 128))
+    # neighbouring segments of a track overlap: make consecutive rows correlated, as real fingerprints are
+    db = unit(db + 0.6 * np.roll(db, 1, axis=0))
+    sigma = np.linspace(0.3, 2.2, 150, dtype=np.float32)[:, None]      # clean -> hopeless
+    query = unit(db + sigma * hash_normalish("eval:noise", (150, 128)) / np.sqrt(128.0).astype(np.float32) * 4.0)
+    test_ids = (np.arange(40) * 3 + 1).astype(np.int64)               # < 150 - 9
+    return {"dummy_db": dummy, "db": db, "query": query, "test_ids": test_ids, "test_seq_len": "1 3 5 9",
+            "k_probe": 20}
+
+
+def write_eval_case(root, case):
+    """The on-disk layout eval.py:126-168 reads: <name>.mm float32 memmap + <name>_shape.npy."""
+    import os
+    for name in ("query", "db", "dummy_db"):
+        arr = np.ascontiguousarray(case[name], dtype=np.float32)
+        mm = np.memmap(os.path.join(root, name + ".mm"), dtype="float32", mode="w+", shape=arr.shape)
+        mm[:] = arr
+        mm.flush()
+        del mm
+        np.save(os.path.join(root, name + "_shape.npy"), np.asarray(arr.shape))

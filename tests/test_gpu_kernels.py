@@ -500,3 +500,29 @@ def test_bn_act_groups_equal_sequential_calls(dev, C, M, G, dt):
         np.testing.assert_allclose(a[i].numpy(), b[i].numpy(), rtol=2e-3 if dt == "bf16" else 1e-4, atol=1e-3 * float(b[i].abs().max()))
     np.testing.assert_allclose(a[4].numpy(), b[4].numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(a[5].numpy(), b[5].numpy(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("n,nq_rows,k,lens", [(300, 40, 6, (3, 5, 1, 19, 1)), (5000, 200, 20, (1, 11, 21, 41)),
+                                              (1000, 64, 32, (64, 1, 33)), (50, 10, 3, (2, 10))])
+def test_seq_rerank_bit_exact_vs_c_oracle(dev, n, nq_rows, k, lens):
+    """ops.seq_rerank == oracle/csrc/seq_rerank.c: ids AND scores, bit for bit, on items with ids < 0, candidates
+    that run past the end of the index, duplicate candidates, 1..64 segments and up to 2048 candidates per item."""
+    from grafp_amd import ops
+    from oracle import native
+    index_rows = hash_normalish(f"gpu:rr.index{n}", (n, 128)).astype(np.float32)
+    q = hash_normalish(f"gpu:rr.q{n}", (nq_rows, 128)).astype(np.float32)
+    ids = hash_ints(f"gpu:rr.ids{n}", (nq_rows, k), 0, n - 1).astype(np.int64)
+    ids[1, k // 2] = -1
+    ids[2, :] = n - 2
+    ids[3, : k // 2] = ids[2, 0] + 1
+    ids[nq_rows // 2:, 0] = np.arange(nq_rows - nq_rows // 2) + 7      # a planted run: equal start id after compensation
+    rows, ln = [], []
+    for i in range(24):
+        L = lens[i % len(lens)]
+        rows.append((i * 5) % (nq_rows - L + 1)); ln.append(L)
+    item_row, item_len = np.asarray(rows, dtype=np.int64), np.asarray(ln, dtype=np.int32)
+    want_i, want_s = native.seq_rerank(index_rows, q, ids, item_row, item_len, top=10)
+    got_i, got_s = ops.seq_rerank(t(index_rows).to(dev), t(q).to(dev), torch.from_numpy(ids).to(dev),
+                                  torch.from_numpy(item_row).to(dev), torch.from_numpy(item_len).to(dev), top=10)
+    assert np.array_equal(got_i.cpu().numpy(), want_i)
+    assert np.array_equal(got_s.cpu().numpy(), want_s)

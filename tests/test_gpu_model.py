@@ -244,6 +244,22 @@ def test_eval_faiss_end_to_end_vs_oracle(dev, tmp_path):
     assert r2.shape == (4, 2) and (r2[3] >= r2[0]).all()
 
 
+def test_eval_faiss_matches_reference_golden(dev, tmp_path):
+    """eval_faiss (one batched search + one rerank launch on the GPU) on the hash-filled case == the hit-rate table
+    and raw flags the reference's own eval_faiss produced (tests/golden/eval_faiss.npz)."""
+    from _common import eval_case, golden, write_eval_case
+    from grafp_amd.eval import eval_faiss
+    g = golden("eval_faiss.npz")
+    case = eval_case()
+    write_eval_case(str(tmp_path), case)
+    np.save(tmp_path / "ids.npy", case["test_ids"])
+    rates = eval_faiss(str(tmp_path), test_ids=str(tmp_path / "ids.npy"), test_seq_len=case["test_seq_len"],
+                       index_type="l2", k_probe=case["k_probe"])
+    np.testing.assert_array_equal(rates, g["hit_rates"])
+    res_dirs = [d for d in os.listdir(tmp_path) if os.path.isdir(tmp_path / d)]
+    np.testing.assert_array_equal(np.load(tmp_path / res_dirs[0] / "raw_score.npy"), g["raw_score"])
+
+
 def test_db_writers(dev, tmp_path):
     """create_dummy_db / create_fp_db / create_db: on-disk format and contents == direct model output."""
     from grafp_amd.fpdb import create_db, create_dummy_db, create_fp_db

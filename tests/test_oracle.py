@@ -310,3 +310,56 @@ def test_eval_l2_planted_sequences():
     rates, raw, top1 = retrieval.eval_l2(query, db, dummy, np.arange(0, 150, 10), [1, 3, 5], k_probe=20)
     assert rates.shape == (4, 3) and raw.shape == (15, 12)
     assert (rates[0] == 100.0).all() and (top1[:, 0] == np.arange(0, 150, 10) + 500).all()
+
+
+def test_eval_faiss_golden_from_reference():
+    """The reference's own eval_faiss (eval.py:170-332, run by tests/golden/make_eval_golden.py with a stand-in exact
+    search for the absent faiss) on the hash-filled case: the numpy restatement and the C rerank restatement must
+    reproduce its hit-rate table and raw hit flags exactly."""
+    from _common import eval_case
+    g = golden("eval_faiss.npz")
+    case = eval_case()
+    lens = [int(v) for v in case["test_seq_len"].split()]
+    assert np.array_equal(g["test_ids"], case["test_ids"])
+    rates, raw, top1 = retrieval.eval_l2(case["query"], case["db"], case["dummy_db"], case["test_ids"], lens,
+                                         k_probe=case["k_probe"])
+    np.testing.assert_array_equal(rates, g["hit_rates"])
+    np.testing.assert_array_equal(raw, g["raw_score"])
+    assert 40.0 < g["hit_rates"][0, 0] < 60.0 and g["hit_rates"][0, -1] == 100.0      # the case is informative
+    # the C restatement (fixed f32 order, batched items) gives the same flags through the same pipeline
+    index_rows = np.concatenate([case["dummy_db"], case["db"]], axis=0)
+    _, I = native.flat_search_l2(index_rows, case["query"], case["k_probe"])
+    item_row = np.repeat(case["test_ids"], len(lens))
+    item_len = np.tile(np.asarray(lens, dtype=np.int32), len(case["test_ids"]))
+    pred, scores = native.seq_rerank(index_rows, case["query"], I, item_row, item_len, top=10)
+    pred = pred.reshape(len(case["test_ids"]), len(lens), 10)
+    gt = (case["test_ids"] + len(case["dummy_db"]))[:, None]
+    flags = np.stack([pred[:, :, 0] == gt, np.abs(pred[:, :, 0] - gt) <= 1, (pred[:, :, :3] == gt[:, :, None]).any(2),
+                      (pred == gt[:, :, None]).any(2)]).astype(int)
+    np.testing.assert_array_equal(np.concatenate(list(flags), axis=1), g["raw_score"])
+    assert np.array_equal(pred[:, :, 0], top1)
+    assert (np.diff(scores, axis=1) <= 0).all()                                        # best first
+
+
+def test_seq_rerank_c_vs_numpy_scores():
+    """C restatement vs the float64 numpy scores of retrieval.sequence_scores on ragged items (candidates that run
+    past the end of the index, ids < 0, duplicate candidates)."""
+    index_rows = hash_normalish("rr:index", (300, 128)).astype(np.float32)
+    q = hash_normalish("rr:q", (40, 128)).astype(np.float32)
+    ids = hash_ints("rr:ids", (40, 6), 0, 299).astype(np.int64)
+    ids[3, 2] = -1
+    ids[5, :] = 298                                                   # sequences that leave the index
+    ids[6, :3] = ids[5, 0] + 1                                        # same start id after offset compensation
+    item_row = np.array([0, 4, 4, 20, 39], dtype=np.int64)
+    item_len = np.array([3, 5, 1, 19, 1], dtype=np.int32)
+    pred, scores = native.seq_rerank(index_rows, q, ids, item_row, item_len, top=10)
+    for it in range(len(item_row)):
+        r0, ql = int(item_row[it]), int(item_len[it])
+        I = ids[r0:r0 + ql].copy() - np.arange(ql)[:, None]
+        I[ids[r0:r0 + ql] < 0] = -1
+        cand = np.unique(I[I >= 0])
+        sc = retrieval.sequence_scores(q[r0:r0 + ql], index_rows, cand, ql)
+        order = np.argsort(-sc, kind="stable")[:10]
+        n = min(10, len(cand))
+        assert np.array_equal(pred[it, :n], cand[order][:n]) and (pred[it, n:] == -1).all()
+        np.testing.assert_allclose(scores[it, :n], sc[order][:n], rtol=2e-5, atol=2e-6)
