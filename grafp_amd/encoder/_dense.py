@@ -42,6 +42,30 @@ def conv1x1(conv, x):
     return ops.conv1x1_rows(x.reshape(cin, B * N), conv.weight.reshape(cout, cin // g), g).reshape(cout, B, N)
 
 
+# num_batches_tracked of every BatchNorm touched inside a `deferred_counters()` block advance with ONE multi-tensor
+# add at the end of the block instead of one tiny launch per layer (64 per forward pass of the encoder)
+_PENDING_COUNTERS = None
+
+
+class deferred_counters:
+    def __enter__(self):
+        global _PENDING_COUNTERS
+        self._outer = _PENDING_COUNTERS
+        _PENDING_COUNTERS = []
+        return self
+
+    def __exit__(self, *exc):
+        global _PENDING_COUNTERS
+        pending, _PENDING_COUNTERS = _PENDING_COUNTERS, self._outer
+        if pending and exc[0] is None:
+            by_step = {}
+            for t, g in pending:
+                by_step.setdefault(g, []).append(t)
+            for g, ts in by_step.items():
+                torch._foreach_add_(ts, g)
+        return False
+
+
 def conv3_stride2(conv, x):
     """Conv2d(k=3, stride=2, pad=1) on the (N,1) node grid (graph_encoder.py:21-24), bias NOT applied.  Only kernel
     column 1 ever overlaps data (columns 0 and 2 see the zero padding of the width-1 axis), so the op is a 3-tap
@@ -63,6 +87,9 @@ def bn_act(bn, y, pre_bias=None, residual=None, act=ops.ACT_NONE, slope=0.0, gro
     as when the views pass through the module one after the other (simclr/simclr.py:35,43)."""
     training = bn.training or not bn.track_running_stats
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(groups)
+        if _PENDING_COUNTERS is not None:
+            _PENDING_COUNTERS.append((bn.num_batches_tracked, groups))
+        else:
+            bn.num_batches_tracked.add_(groups)
     return ops.bn_act(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, training,
                       0.0 if bn.momentum is None else bn.momentum, bn.eps, pre_bias, residual, act, slope, groups)

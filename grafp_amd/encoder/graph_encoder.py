@@ -10,7 +10,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .. import ops
-from ._dense import bn_act, conv1x1, conv3_stride2, from_cbn, to_cbn
+from ._dense import bn_act, conv1x1, conv3_stride2, deferred_counters, from_cbn, to_cbn
 from .gcn_lib.torch_nn import act_layer
 from .gcn_lib.torch_vertex import Grapher
 
@@ -117,12 +117,14 @@ class GraphEncoder(nn.Module):
         statistics per view (the reference runs the views one after the other), everything else is per clip."""
         x = to_cbn(x)
         g = int(views)
-        x = bn_act(self.stem[1], conv1x1(self.stem[0], x), act=ops.ACT_LEAKY, slope=self.stem[2].negative_slope, groups=g)
-        for mod in self.backbone:
-            if isinstance(mod, Downsample):
-                x = mod.forward_cbn(x, g)
-            else:
-                x = mod[1].forward_cbn(mod[0].forward_cbn(x, g), g)
+        with deferred_counters():
+            x = bn_act(self.stem[1], conv1x1(self.stem[0], x), act=ops.ACT_LEAKY, slope=self.stem[2].negative_slope,
+                       groups=g)
+            for mod in self.backbone:
+                if isinstance(mod, Downsample):
+                    x = mod.forward_cbn(x, g)
+                else:
+                    x = mod[1].forward_cbn(mod[0].forward_cbn(x, g), g)
         # readout: mean over nodes commutes with the (linear) 1x1 projection -- project the (C,B) means instead
         # of the (C,B,N) activations (graph_encoder.py:187-188 projects first: same result, 128x the work)
         pooled = x.float().mean(dim=2)                                              # (C, B)
