@@ -180,14 +180,26 @@ def retrieval_probe(device, cpu_check=True):
         # CPU exact search beside it (oracle/csrc/flat_search.c, scalar, 1 thread) on a bounded sample of the
         # nq=41 batch, which also checks the GPU's ids and distances bit for bit
         from oracle import native
-        ns = 8
+        ns = 41
+        threads = max(1, min(32, os.cpu_count() or 1))
+        os.environ["OMP_NUM_THREADS"] = str(threads)                  # read when libgomp starts its first team
         D, I = ops.search_l2(db, sq, q[:ns], 20)
         db_h, q_h = db.cpu().numpy(), q[:ns].cpu().numpy()
-        t0 = time.perf_counter()
-        wd, wi = native.flat_search_l2(db_h, q_h, 20)
-        dt = time.perf_counter() - t0
-        res["cpu_baseline"] = {"value": round(ns / dt, 2), "unit": "queries/s", "cores": 1, "kind": "port",
-                               "sample": f"{ns} of the nq=41 queries against the full 1M x 128 database, {dt:.1f} s"}
+        native.flat_search_l2(db_h[:1000], q_h[:1], 20)                 # builds / loads the library outside the timing
+        t0, reps = time.perf_counter(), 0
+        while reps < 3 or (time.perf_counter() - t0 < 5.0 and reps < 50):
+            wd, wi = native.flat_search_l2(db_h, q_h, 20)
+            reps += 1
+        dt = (time.perf_counter() - t0) / reps
+        try:
+            import ctypes
+            threads = int(ctypes.CDLL("libgomp.so.1").omp_get_max_threads())      # what the runtime really uses
+        except OSError:
+            pass
+        res["cpu_baseline"] = {"value": round(ns / dt, 2), "unit": "queries/s", "cores": threads, "kind": "port",
+                               "sample": f"the nq=41 batch against the full 1M x 128 database, exact search "
+                                         f"(oracle/csrc/flat_search.c, OpenMP over database rows), {reps} passes of "
+                                         f"{dt:.2f} s"}
         res["ids_equal_cpu_exact"] = bool((I.cpu().numpy() == wi).all())
         res["dist_equal_cpu_exact"] = bool((D.cpu().numpy() == wd).all())
     return res
