@@ -50,6 +50,9 @@ SIGNATURES = {
     "grafp_row_sqnorm_f32": (_I, [_P, _L, _I, _P, _P]),
     "grafp_knn_search_workspace": (_Z, [_L, _I, _I, _I]),
     "grafp_knn_search_l2_f32": (_I, [_P, _P, _L, _P, _I, _I, _I, _L, _P, _P, _P, _Z, _P]),
+    "grafp_f32_to_bf16": (_I, [_P, _L, _P, _P]),
+    "grafp_knn_search_pre_workspace": (_Z, [_L, _I, _I, _I]),
+    "grafp_knn_search_l2_pre": (_I, [_P, _P, _P, _L, _P, _I, _I, _I, _L, _P, _P, _P, _Z, _P]),
     "grafp_merge_topk": (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),
     "grafp_seq_rerank_f32": (_I, [_P, _L, _P, _L, _P, _I, _P, _P, _I, _I, _I, _P, _P, _P]),
 }

@@ -449,6 +449,303 @@ __global__ __launch_bounds__(256) void search_select_kernel(const float *__restr
     }
 }
 
+// =====================================================================================================================
+// bf16 pre-filter path (grafp_knn_search_l2_pre): the SAME exact results, from a 16x cheaper scan.
+//
+// The f32 scan above is bound by the exact-f32 matrix rate for large batches and by the 512 B/row stream for small
+// ones.  Here the scan runs on a bf16 copy of the database (256 B/row) with v_mfma_f32_32x32x16_bf16, and only
+// decides which rows MAY be among the k best; the exact f32 distance (same fmaf chain as the oracle) is then
+// computed for those few hundred rows per query by the select kernel.  The decision is conservative:
+//   x^ = round_bf16(x) has |x^_c - x_c| <= u |x_c|, u = 2^-8, so |<q^,x^> - <q,x>| <= (2u + u^2) |q| |x|
+//   and, with |q||x| <= (qq + dd)/2, the approximate distance d~ = (qq + dd) - 2<q^,x^> obeys
+//   |d~ - d| <= (2u + u^2)(qq + dd) = 0.0078278 (qq + dd);  SB_SLACK = 0.008 leaves 1.7e-4 (qq + dd) for the f32
+//   accumulation inside the MFMA (<= 128 * 2^-24 relative) and the rounding of the test itself.
+//   * bound pre-pass: group minima of d~ + SLACK (qq + dd) >= group minima of d  -> a valid bound, as before;
+//   * scan: a row is kept iff d~ - SLACK (qq + dd) <= bound, i.e. every row with d <= bound is kept.
+// Rearranged, the scan test per element is <q^,x^> >= A_q + H_row: one add and one compare.
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // native vector: stays in registers (uint4 went to scratch)
+constexpr int SB_TR = 128;           // rows per LDS tile
+constexpr int SB_LS = 272;           // bytes per LDS row (256 + 16: ds_read_b128 of 32 rows is conflict-free)
+constexpr float SB_SLACK = 0.008f;
+
+__device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
+    unsigned int u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float *__restrict__ src, int64_t n,
+                                                          unsigned short *__restrict__ dst) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        dst[i] = f32_to_bf16_rne(src[i]);
+}
+
+// query operand of the bf16 MFMA: lane (l31, half) holds dims 16 s + 8 half + 0..7 of query l31, s = 0..7
+__device__ __forceinline__ void load_queries_bf16(const float *__restrict__ q, int qi, bool qvalid, int half,
+                                                  bf16x8 (&bq)[8]) {
+    const float *qrow = q + (size_t)(qvalid ? qi : 0) * SR_D + 8 * half;
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bq[s][e] = qvalid ? (short)f32_to_bf16_rne(qrow[16 * s + e]) : (short)0;
+}
+
+// Tiles of SB_TR bf16 rows: HBM -> registers (one tile ahead) -> LDS; sH[row] = dd[row] * hscale (NaN past the end).
+// Wave (qw, rw) multiplies row blocks rw, rw + RW, ... of the tile with its 32 queries: on_block(t, rb, acc);
+// on_tile(t) runs once per tile on every thread at the quiescent point between the tile barriers.
+template <int QW, typename F, typename G>
+__device__ __forceinline__ void stream_tiles_bf16(const unsigned short *__restrict__ dbh, const float *__restrict__ dd,
+                                                  int64_t row_begin, int64_t row_end, unsigned char *tile, float *sH,
+                                                  float hscale, const bf16x8 (&bq)[8], F &&on_block, G &&on_tile) {
+    constexpr int RW = 4 / QW;
+    constexpr int NV = SB_TR * 16 / 256;   // uint4 per thread per tile
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int rw = wave / QW;
+    const int ntiles = row_end > row_begin ? (int)((row_end - row_begin + SB_TR - 1) / SB_TR) : 0;
+    const int nrows = (int)(row_end - row_begin);
+    const u32x4 *base4 = reinterpret_cast<const u32x4 *>(dbh) + row_begin * 16;
+    const float *ddb = dd + row_begin;
+    u32x4 pf[NV];
+    float pdd = 0.0f;
+    auto prefetch = [&](int t) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int item = tid + v * 256;
+            int lr = t * SB_TR + (item >> 4);
+            lr = lr < nrows ? lr : nrows - 1;          // rows past the end: any readable data, their sH is NaN
+            pf[v] = base4[(size_t)lr * 16 + (item & 15)];
+        }
+        if (tid < SB_TR) {
+            const int lr = t * SB_TR + tid;
+            pdd = lr < nrows ? ddb[lr] * hscale : __builtin_nanf("");
+        }
+    };
+    if (ntiles > 0) prefetch(0);
+    for (int t = 0; t < ntiles; ++t) {
+        __syncthreads();  // every wave is done reading the previous tile
+        on_tile(t);       // quiescent point: no wave is inside on_block, so workgroup state is uniform here
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int item = tid + v * 256;
+            *reinterpret_cast<u32x4 *>(tile + (item >> 4) * SB_LS + (item & 15) * 16) = pf[v];
+        }
+        if (tid < SB_TR) sH[tid] = pdd;
+        __syncthreads();
+        if (t + 1 < ntiles) prefetch(t + 1);
+#pragma unroll
+        for (int rb = rw; rb < SB_TR / 32; rb += RW) {
+            const unsigned char *arow = tile + (rb * 32 + l31) * SB_LS + half * 16;
+            bf16x8 a[8];
+#pragma unroll
+            for (int s2 = 0; s2 < 8; ++s2) a[s2] = *reinterpret_cast<const bf16x8 *>(arow + s2 * 32);
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+            for (int s2 = 0; s2 < 8; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s2], bq[s2], acc, 0, 0, 0);
+            on_block(t, rb, acc);
+        }
+    }
+}
+
+template <int QW>
+__global__ __launch_bounds__(256, 2) void search_bound_bf16_kernel(const unsigned short *__restrict__ dbh,
+                                                                   const float *__restrict__ dd, int64_t n_sample,
+                                                                   const float *__restrict__ q,
+                                                                   const float *__restrict__ qq, int nq,
+                                                                   int64_t rows_per_split, int *__restrict__ gmin) {
+    constexpr int RW = 4 / QW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned char *tile = reinterpret_cast<unsigned char *>(smem);
+    float *sH = reinterpret_cast<float *>(smem + SB_TR * SB_LS);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int qw = wave % QW, rw = wave / QW;
+    const int split = blockIdx.x;
+    const int qi = (blockIdx.y * QW + qw) * 32 + l31;
+    const bool qvalid = qi < nq;
+    const int64_t row_begin = (int64_t)split * rows_per_split;
+    const int64_t row_end = (row_begin + rows_per_split < n_sample) ? row_begin + rows_per_split : n_sample;
+    bf16x8 bq[8];
+    load_queries_bf16(q, qi, qvalid, half, bq);
+    const float kplus = 1.0f + SB_SLACK;
+    const float qk = qvalid ? qq[qi] * kplus : 0.0f;
+    float best = INFINITY;
+    stream_tiles_bf16<QW>(dbh, dd, row_begin, row_end, tile, sH, kplus, bq, [&](int, int rb, const f32x16 &acc) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            // d~ + SLACK (qq + dd) >= d; rows past the end carry NaN and are ignored by fminf
+            const float up = __builtin_fmaf(-2.0f, acc[r], qk + sH[rb * 32 + mfma_row(r, half)]);
+            best = fminf(best, up);
+        }
+    }, [](int) {});
+    best = best < 0.0f ? 0.0f : best;
+    if (qvalid && best < INFINITY) {
+        const int g = (((split * RW + rw) * 2) + half) & (SR_GROUPS - 1);
+        atomicMin(&gmin[(size_t)qi * SR_GROUPS + g], __float_as_int(best));
+    }
+}
+
+// Hits are rare (a few hundred per query over the whole database) but a returning global atomic costs microseconds,
+// so the MFMA loop only appends (query, row) to an LDS queue with an LDS atomic; the queue is drained to the
+// per-query candidate lists by all 256 threads at once -- at a tile boundary when it is half full, and at the end.
+constexpr int HB_CAP = 2048;
+
+template <int QW>
+__global__ __launch_bounds__(256, 3) void search_scan_bf16_kernel(const unsigned short *__restrict__ dbh,
+                                                                  const float *__restrict__ dd, int64_t n,
+                                                                  const float *__restrict__ q,
+                                                                  const float *__restrict__ qq, int nq,
+                                                                  int64_t rows_per_split,
+                                                                  const float *__restrict__ thr,
+                                                                  int *__restrict__ cnt, int *__restrict__ cand_i) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned char *tile = reinterpret_cast<unsigned char *>(smem);
+    float *sH = reinterpret_cast<float *>(smem + SB_TR * SB_LS);
+    __shared__ int hb_row[HB_CAP];
+    __shared__ unsigned char hb_q[HB_CAP];
+    __shared__ int s_hits;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int qw = wave % QW;
+    const int split = blockIdx.x;
+    const int qbase = blockIdx.y * QW * 32;
+    const int qi = qbase + qw * 32 + l31;
+    const bool qvalid = qi < nq;
+    const int64_t row_begin = (int64_t)split * rows_per_split;
+    const int64_t row_end = (row_begin + rows_per_split < n) ? row_begin + rows_per_split : n;
+    if (tid == 0) s_hits = 0;
+    bf16x8 bq[8];
+    load_queries_bf16(q, qi, qvalid, half, bq);
+    // keep iff d~ - SLACK (qq + dd) <= bound  <=>  <q^,x^> >= A_q + H_row
+    const float kminus = 1.0f - SB_SLACK;
+    const float a_q = qvalid ? 0.5f * (qq[qi] * kminus - thr[qi]) : INFINITY;
+    auto append = [&](int qg, int row) {                      // to the global per-query list
+        const int pos = atomicAdd(&cnt[qg], 1);
+        if (pos < SR_CAP) cand_i[(size_t)qg * SR_CAP + pos] = row;      // beyond: cnt > SR_CAP -> exact rescan
+    };
+    auto drain = [&]() {                                      // all threads; callers provide the barriers around it
+        const int nh = s_hits < HB_CAP ? s_hits : HB_CAP;
+        for (int e = tid; e < nh; e += 256) append(qbase + hb_q[e], hb_row[e]);
+    };
+    __syncthreads();
+    stream_tiles_bf16<QW>(dbh, dd, row_begin, row_end, tile, sH, 0.5f * kminus, bq,
+                          [&](int t, int rb, const f32x16 &acc) {
+        unsigned long long any = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)                                 // NaN past the end: the compare fails
+            any |= __ballot(acc[r] >= a_q + sH[rb * 32 + mfma_row(r, half)]);
+        if (any != 0) {
+            const int slab0 = (int)(row_begin + (int64_t)t * SB_TR + rb * 32);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (acc[r] >= a_q + sH[rb * 32 + mfma_row(r, half)]) {
+                    const int row = slab0 + mfma_row(r, half);
+                    const int slot = atomicAdd(&s_hits, 1);
+                    if (slot < HB_CAP) {
+                        hb_row[slot] = row;
+                        hb_q[slot] = (unsigned char)(qw * 32 + l31);
+                    } else {
+                        append(qi, row);                              // queue full (tiny database, bound = +inf)
+                    }
+                }
+            }
+        }
+    }, [&](int) {
+        if (s_hits >= HB_CAP / 2) {                                    // uniform: nobody appends at this point
+            drain();
+            __syncthreads();
+            if (tid == 0) s_hits = 0;
+            __syncthreads();
+        }
+    });
+    __syncthreads();
+    drain();
+}
+
+// per query: exact f32 distances (the oracle's fmaf chain) of the candidate rows, then the k best by (distance, id)
+__global__ __launch_bounds__(256) void search_select_exact_kernel(const float *__restrict__ db,
+                                                                  const float *__restrict__ dd, int64_t n,
+                                                                  const float *__restrict__ q,
+                                                                  const float *__restrict__ qq, int nq, int k,
+                                                                  int64_t id_base, const float *__restrict__ thr,
+                                                                  const int *__restrict__ cnt,
+                                                                  const int *__restrict__ cand_i,
+                                                                  float *__restrict__ out_d,
+                                                                  int64_t *__restrict__ out_i) {
+    __shared__ float pend_d[4][WT_PEND];
+    __shared__ int pend_i[4][WT_PEND];
+    __shared__ float wtop_d[4][32];
+    __shared__ int wtop_i[4][32];
+    __shared__ float sq[SR_D];
+    const int qi = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    WaveTop top;
+    top.init(pend_d[wave], pend_i[wave], thr[qi]);
+    if (tid < SR_D) sq[tid] = q[(size_t)qi * SR_D + tid];
+    __syncthreads();
+    const float myqq = qq[qi];
+    const int c = cnt[qi];
+    const bool listed = c <= SR_CAP;                       // else: exact rescan of every row (pathological ties)
+    const int64_t total = listed ? (int64_t)c : n;
+    for (int64_t e0 = 0; e0 < total; e0 += 256) {
+        const int64_t e = e0 + tid;
+        const bool valid = e < total;
+        int64_t row = 0;
+        if (valid) row = listed ? (int64_t)cand_i[(size_t)qi * SR_CAP + e] : e;
+        float d = INFINITY;
+        if (valid) {
+            // the whole row is requested before the dependent fmaf chain starts: 32 loads in flight per lane
+            // instead of one round trip per float4 (every lane reads a different row)
+            f32x4 xr[SR_D / 4];
+            const f32x4 *rp = reinterpret_cast<const f32x4 *>(db) + row * (SR_D / 4);
+#pragma unroll
+            for (int c4 = 0; c4 < SR_D / 4; ++c4) xr[c4] = rp[c4];
+            const float ddr = dd[row];
+            float ip = 0.0f;
+#pragma unroll
+            for (int c4 = 0; c4 < SR_D / 4; ++c4) {
+                ip = __builtin_fmaf(xr[c4][0], sq[4 * c4 + 0], ip);
+                ip = __builtin_fmaf(xr[c4][1], sq[4 * c4 + 1], ip);
+                ip = __builtin_fmaf(xr[c4][2], sq[4 * c4 + 2], ip);
+                ip = __builtin_fmaf(xr[c4][3], sq[4 * c4 + 3], ip);
+            }
+            d = (myqq + ddr) - 2.0f * ip;
+            d = d < 0.0f ? 0.0f : d;
+        }
+        top.push(valid, d, (int)row, k, lane);
+    }
+    if (top.pc > 0) top.fold(k, lane);
+    if ((wave & 1) && lane < 32) {
+        wtop_d[wave][lane] = top.td;
+        wtop_i[wave][lane] = top.ti;
+    }
+    __syncthreads();
+    float td = top.td;
+    int ti = top.ti;
+    if (!(wave & 1)) {
+        if (lane >= 32) {
+            td = wtop_d[wave + 1][lane - 32];
+            ti = wtop_i[wave + 1][lane - 32];
+        }
+        wave_sort64(td, ti, lane);
+        if (wave == 2 && lane < 32) {
+            wtop_d[2][lane] = td;
+            wtop_i[2][lane] = ti;
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        if (lane >= 32) {
+            td = wtop_d[2][lane - 32];
+            ti = wtop_i[2][lane - 32];
+        }
+        wave_sort64(td, ti, lane);
+        if (lane < k) {
+            out_d[(size_t)qi * k + lane] = td;
+            out_i[(size_t)qi * k + lane] = ti == SR_EMPTY ? (int64_t)-1 : id_base + (int64_t)ti;
+        }
+    }
+}
+
 // ---- merge of P partial lists per query: one workgroup per query ------------------------------------------
 // 256 threads sweep the P*k entries 2048 at a time (8 independent loads per thread), keep only entries that are
 // valid and <= the running threshold (+inf, tightened by every fold), append them to an LDS buffer,
@@ -647,6 +944,80 @@ extern "C" int grafp_knn_search_l2_f32(const float *db, const float *db_sqnorm, 
                        id_base, (const float *)thr, (const int *)cnt, (const float *)cand_d, (const int *)cand_i,
                        out_dist, out_ids);
     GRAFP_CHECK_LAUNCH("search_select_kernel");
+    return GRAFP_OK;
+}
+
+extern "C" int grafp_f32_to_bf16(const float *src, int64_t n_elems, void *dst, grafp_stream_t stream) {
+    using namespace grafp;
+    GRAFP_REQUIRE(src && dst && n_elems >= 0, "f32_to_bf16: bad arguments");
+    if (n_elems == 0) return GRAFP_OK;
+    const int64_t nb = (n_elems + 255) / 256;
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)(nb < 16384 ? nb : 16384)), dim3(256), 0, (hipStream_t)stream,
+                       src, n_elems, (unsigned short *)dst);
+    GRAFP_CHECK_LAUNCH("f32_to_bf16_kernel");
+    return GRAFP_OK;
+}
+
+extern "C" size_t grafp_knn_search_pre_workspace(int64_t n, int nq, int d, int k) {
+    using namespace grafp;
+    if (n <= 0 || nq <= 0 || d != SR_D || k < 1) return 0;
+    return align256((size_t)nq * sizeof(float)) * 2 + align256((size_t)nq * sizeof(int)) +
+           align256((size_t)nq * SR_GROUPS * sizeof(int)) + align256((size_t)nq * SR_CAP * sizeof(int));
+}
+
+extern "C" int grafp_knn_search_l2_pre(const float *db, const void *db_bf16, const float *db_sqnorm, int64_t n,
+                                       const float *q, int nq, int d, int k, int64_t id_base, float *out_dist,
+                                       int64_t *out_ids, void *ws, size_t ws_bytes, grafp_stream_t stream) {
+    using namespace grafp;
+    GRAFP_REQUIRE(db && db_bf16 && db_sqnorm && q && out_dist && out_ids, "knn_search_pre: null pointer");
+    GRAFP_REQUIRE(d == SR_D, "knn_search_pre: d=%d unsupported (fingerprints are 128-d)", d);
+    GRAFP_REQUIRE(n >= 1 && n < 0x7fffffffll && nq >= 1, "knn_search_pre: bad n=%lld nq=%d", (long long)n, nq);
+    GRAFP_REQUIRE(k >= 1 && k <= GRAFP_SEARCH_MAX_K, "knn_search_pre: k=%d not in [1, %d]", k, GRAFP_SEARCH_MAX_K);
+    GRAFP_REQUIRE((((uintptr_t)db | (uintptr_t)db_bf16) & 15) == 0 && ((uintptr_t)q & 3) == 0,
+                  "knn_search_pre: db / db_bf16 must be 16-byte aligned");
+    const size_t need = grafp_knn_search_pre_workspace(n, nq, d, k);
+    if (!ws || ws_bytes < need) {
+        set_error("knn_search_pre: workspace %zu bytes < required %zu", ws_bytes, need);
+        return GRAFP_ERR_WORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int qw = nq <= 32 ? 1 : 4, rw = 4 / qw;     // (the 2x2 shape measured 3.5x slower than 4x1 at nq = 41)
+    const int qgroups = (nq + 32 * qw - 1) / (32 * qw);
+    int splits, b_splits;
+    int64_t rps, b_rps;
+    int64_t want = 768 / qgroups;
+    split_rows(n, SB_TR, want < 1 ? 1 : want, &splits, &rps);
+    int64_t b_rows = n / 16 > 65536 ? n / 16 : 65536;
+    if (b_rows > n) b_rows = n;
+    int64_t bwant = 1024 / qgroups;
+    const int64_t bneed = (32 + rw - 1) / rw;
+    if (bwant < bneed) bwant = bneed;
+    split_rows(b_rows, SB_TR, bwant, &b_splits, &b_rps);
+    char *w = (char *)ws;
+    float *qq = (float *)w;                 w += align256((size_t)nq * sizeof(float));
+    float *thr = (float *)w;                w += align256((size_t)nq * sizeof(float));
+    int *cnt = (int *)w;                    w += align256((size_t)nq * sizeof(int));
+    int *gmin = (int *)w;                   w += align256((size_t)nq * SR_GROUPS * sizeof(int));
+    int *cand_i = (int *)w;
+    const int64_t ng = (int64_t)nq * SR_GROUPS;
+    hipLaunchKernelGGL(search_init_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, s, q, nq, qq, gmin, cnt);
+    const size_t lds = (size_t)SB_TR * SB_LS + SB_TR * sizeof(float);
+    const dim3 grid_b(b_splits, qgroups), grid(splits, qgroups);
+    const unsigned short *dbh = (const unsigned short *)db_bf16;
+#define SB_LAUNCH(QW)                                                                                               \
+    hipLaunchKernelGGL(search_bound_bf16_kernel<QW>, grid_b, dim3(256), lds, s, dbh, db_sqnorm, b_rows, q,          \
+                       (const float *)qq, nq, b_rps, gmin);                                                         \
+    hipLaunchKernelGGL(search_thr_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, (const int *)gmin, nq, k, thr);      \
+    hipLaunchKernelGGL(search_scan_bf16_kernel<QW>, grid, dim3(256), lds, s, dbh, db_sqnorm, n, q,                  \
+                       (const float *)qq, nq, rps, (const float *)thr, cnt, cand_i)
+    if (qw == 1) { SB_LAUNCH(1); }
+    else if (qw == 2) { SB_LAUNCH(2); }
+    else { SB_LAUNCH(4); }
+#undef SB_LAUNCH
+    GRAFP_CHECK_LAUNCH("search_bound_bf16_kernel / search_scan_bf16_kernel");
+    hipLaunchKernelGGL(search_select_exact_kernel, dim3(nq), dim3(256), 0, s, db, db_sqnorm, n, q, (const float *)qq, nq,
+                       k, id_base, (const float *)thr, (const int *)cnt, (const int *)cand_i, out_dist, out_ids);
+    GRAFP_CHECK_LAUNCH("search_select_exact_kernel");
     return GRAFP_OK;
 }
 

@@ -453,22 +453,40 @@ def row_sqnorm(m):
     return out
 
 
-def search_l2(db, db_sqnorm, q, k, id_base=0, max_queries_per_launch=4096):
-    """Exact squared-L2 top-k of q (nq,128) against the resident db (n,128): (dist f32, ids int64), (nq,k)."""
+def rows_to_bf16(db):
+    """Round-to-nearest-even bf16 copy of the resident (n,128) f32 database for the pre-filter scan."""
+    _require_gpu(db)
+    db = _f32c(db)
+    out = torch.empty(db.shape, dtype=torch.bfloat16, device=db.device)
+    check(lib.grafp_f32_to_bf16(_p(db), db.numel(), _p(out), _stream()), "f32_to_bf16")
+    return out
+
+
+def search_l2(db, db_sqnorm, q, k, id_base=0, max_queries_per_launch=4096, db_bf16=None):
+    """Exact squared-L2 top-k of q (nq,128) against the resident db (n,128): (dist f32, ids int64), (nq,k).
+    db_bf16 (rows_to_bf16(db)): same results through the bf16 pre-filter scan + exact f32 rescoring."""
     _require_gpu(db, db_sqnorm, q)
     q = _f32c(q)
     n, d = db.shape
     nq = q.shape[0]
     out_d = torch.empty((nq, k), dtype=torch.float32, device=db.device)
     out_i = torch.empty((nq, k), dtype=torch.int64, device=db.device)
+    pre = db_bf16 is not None
+    if pre and (db_bf16.dtype != torch.bfloat16 or db_bf16.shape != db.shape or not db_bf16.is_contiguous()):
+        raise ValueError("search_l2: db_bf16 must be a contiguous bf16 tensor of db's shape")
     for s in range(0, nq, max_queries_per_launch):
         e = min(nq, s + max_queries_per_launch)
-        nbytes = lib.grafp_knn_search_workspace(n, e - s, d, k)
+        nbytes = (lib.grafp_knn_search_pre_workspace if pre else lib.grafp_knn_search_workspace)(n, e - s, d, k)
         ws = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=db.device)
         with _timed("knn_search", (n, e - s, k)):
-            check(lib.grafp_knn_search_l2_f32(_p(db), _p(db_sqnorm), n, _p(q[s:e]), e - s, d, k, int(id_base),
-                                              _p(out_d[s:e]), _p(out_i[s:e]), _p(ws), nbytes, _stream()),
-                  "knn_search_l2")
+            if pre:
+                check(lib.grafp_knn_search_l2_pre(_p(db), _p(db_bf16), _p(db_sqnorm), n, _p(q[s:e]), e - s, d, k,
+                                                  int(id_base), _p(out_d[s:e]), _p(out_i[s:e]), _p(ws), nbytes,
+                                                  _stream()), "knn_search_l2_pre")
+            else:
+                check(lib.grafp_knn_search_l2_f32(_p(db), _p(db_sqnorm), n, _p(q[s:e]), e - s, d, k, int(id_base),
+                                                  _p(out_d[s:e]), _p(out_i[s:e]), _p(ws), nbytes, _stream()),
+                      "knn_search_l2")
     return out_d, out_i
 
 
@@ -514,10 +532,12 @@ class FlatL2Index:
     """Drop-in for the subset of faiss.IndexFlatL2 that eval.py uses: d, ntotal, add(x), search(q, k).
     The database lives in HBM; `add` also computes the per-row squared norms once."""
 
-    def __init__(self, d=128, device=None, id_base=0):
+    def __init__(self, d=128, device=None, id_base=0, prefilter=True):
         if not torch.cuda.is_available():
             raise RuntimeError("FlatL2Index needs a HIP device: there is no CPU fallback")
         self.d = d
+        self.prefilter = bool(prefilter)     # bf16 pre-filter scan + exact rescoring (same results, 2-4x faster)
+        self._bf16 = None
         self.device = torch.device(device if device is not None else "cuda")
         self.id_base = int(id_base)
         self._chunks = []
@@ -538,6 +558,7 @@ class FlatL2Index:
             self._db = self._chunks[0] if len(self._chunks) == 1 else torch.cat(self._chunks, dim=0)
             self._chunks = [self._db]
             self._sq = row_sqnorm(self._db)
+            self._bf16 = rows_to_bf16(self._db) if self.prefilter else None
         return self._db, self._sq
 
     def rows(self):
@@ -553,5 +574,5 @@ class FlatL2Index:
             I = torch.full((qt.shape[0], k), -1, dtype=torch.int64, device=self.device)
         else:
             db, sq = self._materialise()
-            D, I = search_l2(db, sq, qt.reshape(-1, self.d), k, self.id_base)
+            D, I = search_l2(db, sq, qt.reshape(-1, self.d), k, self.id_base, db_bf16=self._bf16)
         return (D.cpu().numpy(), I.cpu().numpy()) if as_numpy else (D, I)

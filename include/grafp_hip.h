@@ -198,6 +198,16 @@ int grafp_knn_search_l2_f32(const float *db, const float *db_sqnorm, int64_t n, 
                             int k, int64_t id_base, float *out_dist, int64_t *out_ids, void *ws,
                             size_t ws_bytes, grafp_stream_t stream);
 
+/* Same results (bit-identical ids and distances) from a bf16 pre-filter: the scan runs on `db_bf16`, a
+ * round-to-nearest-even bf16 copy of db (grafp_f32_to_bf16; n*128 bf16, 16-byte aligned), with a rigorous error
+ * margin, and exact f32 distances are evaluated only for the few hundred rows per query that can still be among
+ * the k best.  Halves the bytes streamed per pass and lifts large batches off the exact-f32 matrix rate. */
+int grafp_f32_to_bf16(const float *src, int64_t n_elems, void *dst, grafp_stream_t stream);
+size_t grafp_knn_search_pre_workspace(int64_t n, int nq, int d, int k);
+int grafp_knn_search_l2_pre(const float *db, const void *db_bf16, const float *db_sqnorm, int64_t n, const float *q,
+                            int nq, int d, int k, int64_t id_base, float *out_dist, int64_t *out_ids, void *ws,
+                            size_t ws_bytes, grafp_stream_t stream);
+
 /* Merge P partial result lists (e.g. one per database shard/GPU after an all-gather):
  *   part_dist (P,nq,k) f32, part_ids (P,nq,k) int64 (id < 0 = empty) -> out (nq,k), by (dist,id). */
 int grafp_merge_topk(const float *part_dist, const int64_t *part_ids, int P, int nq, int k, float *out_dist,

@@ -229,6 +229,15 @@ def test_peak_extract_reference_golden(dev):
 
 
 # =============================================================== brute-force search (bit-exact ids and distances)
+def _search(ops, dbt, qt, k, id_base=0):
+    """Both search paths (f32 scan; bf16 pre-filter + exact rescoring) must agree bit for bit; returns one."""
+    sq = ops.row_sqnorm(dbt)
+    d0, i0 = ops.search_l2(dbt, sq, qt, k, id_base=id_base)
+    d1, i1 = ops.search_l2(dbt, sq, qt, k, id_base=id_base, db_bf16=ops.rows_to_bf16(dbt))
+    assert torch.equal(i0, i1) and torch.equal(d0, d1)
+    return d1, i1
+
+
 def _planted(n, nq, seed, noise=0.05):
     db = hash_normalish(f"gpu:sr.db.{seed}", (n, 128)); db /= np.linalg.norm(db, axis=1, keepdims=True)
     rows = (np.arange(nq) * 7919) % n
@@ -245,7 +254,7 @@ def test_search_bit_exact_vs_c_oracle(dev, n, nq, k):
     db, q, rows = _planted(n, nq, f"{n}.{nq}")
     want_d, want_i = native.flat_search_l2(db, q, k)
     dbt = t(db).to(dev)
-    got_d, got_i = ops.search_l2(dbt, ops.row_sqnorm(dbt), t(q).to(dev), k)
+    got_d, got_i = _search(ops, dbt, t(q).to(dev), k)
     got_d, got_i = got_d.cpu().numpy(), got_i.cpu().numpy()
     mism = np.argwhere(got_i != want_i)
     assert len(mism) == 0, f"{len(mism)} ids differ; first {mism[:5].tolist()}"
@@ -259,11 +268,11 @@ def test_search_edge_cases(dev):
     db, q, _ = _planted(300, 9, "edge")
     dup = np.tile(db[:25], (8, 1))                                    # every row 8 times: ties -> lowest id
     dupt = t(dup).to(dev)
-    d, i = ops.search_l2(dupt, ops.row_sqnorm(dupt), t(db[:9]).to(dev), 20)
+    d, i = _search(ops, dupt, t(db[:9]).to(dev), 20)
     wd, wi = native.flat_search_l2(dup, db[:9], 20)
     assert np.array_equal(i.cpu().numpy(), wi) and np.array_equal(d.cpu().numpy(), wd)
     small = t(db[:5]).to(dev)                                         # fewer rows than k: -1 / inf padding
-    d, i = ops.search_l2(small, ops.row_sqnorm(small), t(q).to(dev), 20)
+    d, i = _search(ops, small, t(q).to(dev), 20)
     assert (i[:, 5:] == -1).all() and torch.isinf(d[:, 5:]).all() and (i[:, :5] >= 0).all()
     idx = ops.FlatL2Index(128)                                        # faiss-like surface, numpy in/out
     idx.add(db[:100]); idx.add(db[100:])
@@ -282,7 +291,7 @@ def test_search_candidate_overflow_rescan(dev):
     db[1000:7000] = db[1000]                                          # 6000 identical rows
     qs = np.stack([db[1000], q[0], db[1000] * 0.5 + q[1] * 0.5]).astype(np.float32)
     dbt = t(db).to(dev)
-    d, i = ops.search_l2(dbt, ops.row_sqnorm(dbt), t(qs).to(dev), 20)
+    d, i = _search(ops, dbt, t(qs).to(dev), 20)
     wd, wi = native.flat_search_l2(db, qs, 20)
     assert np.array_equal(i.cpu().numpy(), wi) and np.array_equal(d.cpu().numpy(), wd)
     assert (i[0].cpu().numpy() == np.arange(1000, 1020)).all()
@@ -296,7 +305,29 @@ def test_search_ragged_sizes(dev, n, nq):
     db, q, _ = _planted(max(n, 64), max(nq, 8), f"ragged{n}")
     db, q = db[:n], q[:nq]
     dbt = t(db).to(dev)
-    d, i = ops.search_l2(dbt, ops.row_sqnorm(dbt), t(q).to(dev), 20)
+    d, i = _search(ops, dbt, t(q).to(dev), 20)
+    wd, wi = native.flat_search_l2(db, q, 20)
+    assert np.array_equal(i.cpu().numpy(), wi) and np.array_equal(d.cpu().numpy(), wd)
+
+
+def test_search_prefilter_worst_case_rounding(dev):
+    """The bf16 pre-filter must never drop a true neighbour.  Components sit just below the midpoint between two bf16
+    values (relative rounding error ~ 2^-8, the most the margin has to absorb), norms vary over 3 orders of magnitude
+    (the margin scales with qq + dd), and the queries are near-duplicates of rows, so the k-th distances are small
+    compared with the error the margin covers."""
+    from grafp_amd import ops
+    from oracle import native
+    n, nq = 30000, 96
+    base = hash_normalish("gpu:sr.worst", (n, 128)).astype(np.float32)
+    bits = base.view(np.uint32)
+    bits = (bits & np.uint32(0xFFFF0000)) | np.uint32(0x7FFF)          # mantissa tail 0x7fff: rounds down by ~2^-9 rel
+    up = hash_ints("gpu:sr.worst.up", (n, 128), 0, 1).astype(bool)
+    bits = np.where(up, (bits & np.uint32(0xFFFF0000)) | np.uint32(0x8001), bits)    # ... or up by the same amount
+    db = bits.view(np.float32) * (10.0 ** (1.5 * hash_uniform("gpu:sr.worst.scale", (n, 1)))).astype(np.float32)
+    rows = (np.arange(nq) * 311) % n
+    q = (db[rows] * (1.0 + 1e-3 * hash_normalish("gpu:sr.worst.q", (nq, 128)))).astype(np.float32)
+    dbt = t(db).to(dev)
+    d, i = _search(ops, dbt, t(q).to(dev), 20)
     wd, wi = native.flat_search_l2(db, q, 20)
     assert np.array_equal(i.cpu().numpy(), wi) and np.array_equal(d.cpu().numpy(), wd)
 
@@ -308,7 +339,7 @@ def test_merge_topk_and_sharded_search(dev):
     parts_d, parts_i = [], []
     for s in range(0, 9000, 3000):
         sh = t(db[s:s + 3000]).to(dev)
-        d, i = ops.search_l2(sh, ops.row_sqnorm(sh), t(q).to(dev), 20, id_base=s)
+        d, i = _search(ops, sh, t(q).to(dev), 20, id_base=s)
         parts_d.append(d); parts_i.append(i)
     md, mi = ops.merge_topk(torch.stack(parts_d), torch.stack(parts_i))
     wd, wi = native.flat_search_l2(db, q, 20)
@@ -328,11 +359,14 @@ def test_search_1m_planted_top1(dev):
     q = torch.nn.functional.normalize(db[rows] + 0.03 * torch.randn(4096, 128, generator=gen), dim=1)
     dbt = db.to(dev)
     sq = ops.row_sqnorm(dbt)
-    d, i = ops.search_l2(dbt, sq, q.to(dev), 20)
+    dbh = ops.rows_to_bf16(dbt)
+    d, i = ops.search_l2(dbt, sq, q.to(dev), 20, db_bf16=dbh)
+    d0, i0 = ops.search_l2(dbt, sq, q.to(dev), 20)
+    assert torch.equal(i, i0) and torch.equal(d, d0)                  # pre-filter path == f32 scan, 4096 queries
     assert torch.equal(i[:, 0].cpu(), rows)
     assert bool((d[:, 1:] >= d[:, :-1]).all())                        # sorted ascending
     for nq in (1, 41):
-        dd, ii = ops.search_l2(dbt, sq, q[:nq].to(dev), 20)
+        dd, ii = ops.search_l2(dbt, sq, q[:nq].to(dev), 20, db_bf16=dbh)
         wd, wi = native.flat_search_l2(db.numpy(), q[:nq].numpy(), 20)
         assert np.array_equal(ii.cpu().numpy(), wi) and np.array_equal(dd.cpu().numpy(), wd)
         assert torch.equal(ii.cpu(), i[:nq].cpu())                    # batch-size independent
