@@ -22,6 +22,8 @@
 //
 // Roofline: one pass streams n*(512+4) bytes; 2*128 flops per (row, query).  HBM-bound up to ~50
 // queries per pass, f32-matrix-bound (157.3 TFLOP/s) beyond.  See DESIGN.md "search_scan_kernel".
+// The default entry (grafp_knn_search_l2_pre, second half of this file) runs the same pipeline on a bf16 copy of the
+// database with a rigorous rounding margin and rescoring in exact f32: same bits out, 2-5x faster.
 #include <math.h>
 
 #include "common.h"
@@ -589,7 +591,7 @@ __global__ __launch_bounds__(256, 2) void search_bound_bf16_kernel(const unsigne
 // Hits are rare (a few hundred per query over the whole database) but a returning global atomic costs microseconds,
 // so the MFMA loop only appends (query, row) to an LDS queue with an LDS atomic; the queue is drained to the
 // per-query candidate lists by all 256 threads at once -- at a tile boundary when it is half full, and at the end.
-constexpr int HB_CAP = 2048;
+constexpr int HB_CAP = 1024;      // 9 KB: with the 35 KB tile three workgroups still fit the 160 KB of a CU
 
 template <int QW>
 __global__ __launch_bounds__(256, 3) void search_scan_bf16_kernel(const unsigned short *__restrict__ dbh,
@@ -598,11 +600,13 @@ __global__ __launch_bounds__(256, 3) void search_scan_bf16_kernel(const unsigned
                                                                   const float *__restrict__ qq, int nq,
                                                                   int64_t rows_per_split,
                                                                   const float *__restrict__ thr,
-                                                                  int *__restrict__ cnt, int *__restrict__ cand_i) {
+                                                                  int *__restrict__ cnt, int *__restrict__ cand_i,
+                                                                  float *__restrict__ cand_ip) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned char *tile = reinterpret_cast<unsigned char *>(smem);
     float *sH = reinterpret_cast<float *>(smem + SB_TR * SB_LS);
     __shared__ int hb_row[HB_CAP];
+    __shared__ float hb_ip[HB_CAP];
     __shared__ unsigned char hb_q[HB_CAP];
     __shared__ int s_hits;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
@@ -619,13 +623,16 @@ __global__ __launch_bounds__(256, 3) void search_scan_bf16_kernel(const unsigned
     // keep iff d~ - SLACK (qq + dd) <= bound  <=>  <q^,x^> >= A_q + H_row
     const float kminus = 1.0f - SB_SLACK;
     const float a_q = qvalid ? 0.5f * (qq[qi] * kminus - thr[qi]) : INFINITY;
-    auto append = [&](int qg, int row) {                      // to the global per-query list
+    auto append = [&](int qg, int row, float ip) {            // to the global per-query list
         const int pos = atomicAdd(&cnt[qg], 1);
-        if (pos < SR_CAP) cand_i[(size_t)qg * SR_CAP + pos] = row;      // beyond: cnt > SR_CAP -> exact rescan
+        if (pos < SR_CAP) {                                   // beyond: cnt > SR_CAP -> exact rescan
+            cand_i[(size_t)qg * SR_CAP + pos] = row;
+            cand_ip[(size_t)qg * SR_CAP + pos] = ip;          // <q^,x^>: lets the select kernel bound d from both sides
+        }
     };
     auto drain = [&]() {                                      // all threads; callers provide the barriers around it
         const int nh = s_hits < HB_CAP ? s_hits : HB_CAP;
-        for (int e = tid; e < nh; e += 256) append(qbase + hb_q[e], hb_row[e]);
+        for (int e = tid; e < nh; e += 256) append(qbase + hb_q[e], hb_row[e], hb_ip[e]);
     };
     __syncthreads();
     stream_tiles_bf16<QW>(dbh, dd, row_begin, row_end, tile, sH, 0.5f * kminus, bq,
@@ -643,9 +650,10 @@ __global__ __launch_bounds__(256, 3) void search_scan_bf16_kernel(const unsigned
                     const int slot = atomicAdd(&s_hits, 1);
                     if (slot < HB_CAP) {
                         hb_row[slot] = row;
+                        hb_ip[slot] = acc[r];
                         hb_q[slot] = (unsigned char)(qw * 32 + l31);
                     } else {
-                        append(qi, row);                              // queue full (tiny database, bound = +inf)
+                        append(qi, row, acc[r]);                      // queue full (tiny database, bound = +inf)
                     }
                 }
             }
@@ -662,65 +670,22 @@ __global__ __launch_bounds__(256, 3) void search_scan_bf16_kernel(const unsigned
     drain();
 }
 
-// per query: exact f32 distances (the oracle's fmaf chain) of the candidate rows, then the k best by (distance, id)
-__global__ __launch_bounds__(256) void search_select_exact_kernel(const float *__restrict__ db,
-                                                                  const float *__restrict__ dd, int64_t n,
-                                                                  const float *__restrict__ q,
-                                                                  const float *__restrict__ qq, int nq, int k,
-                                                                  int64_t id_base, const float *__restrict__ thr,
-                                                                  const int *__restrict__ cnt,
-                                                                  const int *__restrict__ cand_i,
-                                                                  float *__restrict__ out_d,
-                                                                  int64_t *__restrict__ out_i) {
-    __shared__ float pend_d[4][WT_PEND];
-    __shared__ int pend_i[4][WT_PEND];
-    __shared__ float wtop_d[4][32];
-    __shared__ int wtop_i[4][32];
-    __shared__ float sq[SR_D];
-    const int qi = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    WaveTop top;
-    top.init(pend_d[wave], pend_i[wave], thr[qi]);
-    if (tid < SR_D) sq[tid] = q[(size_t)qi * SR_D + tid];
-    __syncthreads();
-    const float myqq = qq[qi];
-    const int c = cnt[qi];
-    const bool listed = c <= SR_CAP;                       // else: exact rescan of every row (pathological ties)
-    const int64_t total = listed ? (int64_t)c : n;
-    for (int64_t e0 = 0; e0 < total; e0 += 256) {
-        const int64_t e = e0 + tid;
-        const bool valid = e < total;
-        int64_t row = 0;
-        if (valid) row = listed ? (int64_t)cand_i[(size_t)qi * SR_CAP + e] : e;
-        float d = INFINITY;
-        if (valid) {
-            // the whole row is requested before the dependent fmaf chain starts: 32 loads in flight per lane
-            // instead of one round trip per float4 (every lane reads a different row)
-            f32x4 xr[SR_D / 4];
-            const f32x4 *rp = reinterpret_cast<const f32x4 *>(db) + row * (SR_D / 4);
-#pragma unroll
-            for (int c4 = 0; c4 < SR_D / 4; ++c4) xr[c4] = rp[c4];
-            const float ddr = dd[row];
-            float ip = 0.0f;
-#pragma unroll
-            for (int c4 = 0; c4 < SR_D / 4; ++c4) {
-                ip = __builtin_fmaf(xr[c4][0], sq[4 * c4 + 0], ip);
-                ip = __builtin_fmaf(xr[c4][1], sq[4 * c4 + 1], ip);
-                ip = __builtin_fmaf(xr[c4][2], sq[4 * c4 + 2], ip);
-                ip = __builtin_fmaf(xr[c4][3], sq[4 * c4 + 3], ip);
-            }
-            d = (myqq + ddr) - 2.0f * ip;
-            d = d < 0.0f ? 0.0f : d;
-        }
-        top.push(valid, d, (int)row, k, lane);
-    }
-    if (top.pc > 0) top.fold(k, lane);
+// Per query: the k best of its candidates by (exact distance, id).
+// The scan left (row, <q^,x^>) pairs.  With t = qq + dd[row] the true distance lies in [lo, hi],
+//   lo = t (1 - SLACK) - 2 <q^,x^>,   hi = t (1 + SLACK) - 2 <q^,x^>,
+// so phase A takes the k-th smallest hi (at least k rows are truly that close: a bound ~10x tighter than the scan's)
+// and phase B evaluates the exact f32 distance -- the oracle's fmaf chain over the 512-byte row -- only for the rows
+// whose lo does not exceed it: a few dozen random row reads per query instead of several hundred.
+__device__ __forceinline__ void block_merge_tops(WaveTop &top, float (*wtop_d)[32], int (*wtop_i)[32], int wave, int lane,
+                                                 float &td, int &ti) {
+    // merge the four wave lists as a tree: (0,1) and (2,3) in parallel, then the two winners -> wave 0 lanes 0..31
     if ((wave & 1) && lane < 32) {
         wtop_d[wave][lane] = top.td;
         wtop_i[wave][lane] = top.ti;
     }
     __syncthreads();
-    float td = top.td;
-    int ti = top.ti;
+    td = top.td;
+    ti = top.ti;
     if (!(wave & 1)) {
         if (lane >= 32) {
             td = wtop_d[wave + 1][lane - 32];
@@ -739,10 +704,99 @@ __global__ __launch_bounds__(256) void search_select_exact_kernel(const float *_
             ti = wtop_i[2][lane - 32];
         }
         wave_sort64(td, ti, lane);
-        if (lane < k) {
-            out_d[(size_t)qi * k + lane] = td;
-            out_i[(size_t)qi * k + lane] = ti == SR_EMPTY ? (int64_t)-1 : id_base + (int64_t)ti;
+    }
+}
+
+__global__ __launch_bounds__(256) void search_select_exact_kernel(const float *__restrict__ db,
+                                                                  const float *__restrict__ dd, int64_t n,
+                                                                  const float *__restrict__ q,
+                                                                  const float *__restrict__ qq, int nq, int k,
+                                                                  int64_t id_base, const float *__restrict__ thr,
+                                                                  const int *__restrict__ cnt,
+                                                                  const int *__restrict__ cand_i,
+                                                                  const float *__restrict__ cand_ip,
+                                                                  float *__restrict__ out_d,
+                                                                  int64_t *__restrict__ out_i) {
+    __shared__ float pend_d[4][WT_PEND];
+    __shared__ int pend_i[4][WT_PEND];
+    __shared__ float wtop_d[4][32];
+    __shared__ int wtop_i[4][32];
+    __shared__ float sq[SR_D];
+    __shared__ float s_thr2;
+    const int qi = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (tid < SR_D) sq[tid] = q[(size_t)qi * SR_D + tid];
+    const float myqq = qq[qi];
+    const int c = cnt[qi];
+    const bool listed = c <= SR_CAP;                       // else: exact rescan of every row (pathological ties)
+    const int64_t total = listed ? (int64_t)c : n;
+    float thr2 = thr[qi];
+    WaveTop top;
+    float td;
+    int ti;
+    if (listed) {                                          // phase A: k-th smallest upper bound
+        top.init(pend_d[wave], pend_i[wave], INFINITY);
+        for (int e0 = 0; e0 < c; e0 += 256) {
+            const int e = e0 + tid;
+            const bool valid = e < c;
+            float hi = INFINITY;
+            int row = 0;
+            if (valid) {
+                row = cand_i[(size_t)qi * SR_CAP + e];
+                const float t = myqq + dd[row];
+                hi = __builtin_fmaf(-2.0f, cand_ip[(size_t)qi * SR_CAP + e], t * (1.0f + SB_SLACK));
+                hi = hi < 0.0f ? 0.0f : hi;
+            }
+            top.push(valid, hi, row, k, lane);
         }
+        if (top.pc > 0) top.fold(k, lane);
+        block_merge_tops(top, wtop_d, wtop_i, wave, lane, td, ti);
+        if (wave == 0 && lane == k - 1) s_thr2 = td;      // +inf when fewer than k candidates exist
+        __syncthreads();
+        thr2 = fminf(thr2, s_thr2);
+    }
+    __syncthreads();                                       // sq visible; the merge buffers are free again
+    // phase B: exact distances of the rows that can still be among the k best
+    top.init(pend_d[wave], pend_i[wave], thr2);
+    const float kminus = 1.0f - SB_SLACK;
+    for (int64_t e0 = 0; e0 < total; e0 += 256) {
+        const int64_t e = e0 + tid;
+        bool need = e < total;
+        int64_t row = 0;
+        if (need) {
+            if (listed) {
+                row = cand_i[(size_t)qi * SR_CAP + e];
+                const float lo = __builtin_fmaf(-2.0f, cand_ip[(size_t)qi * SR_CAP + e], (myqq + dd[row]) * kminus);
+                need = lo <= thr2;
+            } else {
+                row = e;
+            }
+        }
+        float d = INFINITY;
+        if (need) {
+            // the whole row is requested before the dependent fmaf chain starts (every lane reads a different row)
+            f32x4 xr[SR_D / 4];
+            const f32x4 *rp = reinterpret_cast<const f32x4 *>(db) + row * (SR_D / 4);
+#pragma unroll
+            for (int c4 = 0; c4 < SR_D / 4; ++c4) xr[c4] = rp[c4];
+            const float ddr = dd[row];
+            float ip = 0.0f;
+#pragma unroll
+            for (int c4 = 0; c4 < SR_D / 4; ++c4) {
+                ip = __builtin_fmaf(xr[c4][0], sq[4 * c4 + 0], ip);
+                ip = __builtin_fmaf(xr[c4][1], sq[4 * c4 + 1], ip);
+                ip = __builtin_fmaf(xr[c4][2], sq[4 * c4 + 2], ip);
+                ip = __builtin_fmaf(xr[c4][3], sq[4 * c4 + 3], ip);
+            }
+            d = (myqq + ddr) - 2.0f * ip;
+            d = d < 0.0f ? 0.0f : d;
+        }
+        top.push(need, d, (int)row, k, lane);
+    }
+    if (top.pc > 0) top.fold(k, lane);
+    block_merge_tops(top, wtop_d, wtop_i, wave, lane, td, ti);
+    if (wave == 0 && lane < k) {
+        out_d[(size_t)qi * k + lane] = td;
+        out_i[(size_t)qi * k + lane] = ti == SR_EMPTY ? (int64_t)-1 : id_base + (int64_t)ti;
     }
 }
 
@@ -962,7 +1016,8 @@ extern "C" size_t grafp_knn_search_pre_workspace(int64_t n, int nq, int d, int k
     using namespace grafp;
     if (n <= 0 || nq <= 0 || d != SR_D || k < 1) return 0;
     return align256((size_t)nq * sizeof(float)) * 2 + align256((size_t)nq * sizeof(int)) +
-           align256((size_t)nq * SR_GROUPS * sizeof(int)) + align256((size_t)nq * SR_CAP * sizeof(int));
+           align256((size_t)nq * SR_GROUPS * sizeof(int)) + align256((size_t)nq * SR_CAP * sizeof(int)) +
+           align256((size_t)nq * SR_CAP * sizeof(float));
 }
 
 extern "C" int grafp_knn_search_l2_pre(const float *db, const void *db_bf16, const float *db_sqnorm, int64_t n,
@@ -998,7 +1053,8 @@ extern "C" int grafp_knn_search_l2_pre(const float *db, const void *db_bf16, con
     float *thr = (float *)w;                w += align256((size_t)nq * sizeof(float));
     int *cnt = (int *)w;                    w += align256((size_t)nq * sizeof(int));
     int *gmin = (int *)w;                   w += align256((size_t)nq * SR_GROUPS * sizeof(int));
-    int *cand_i = (int *)w;
+    int *cand_i = (int *)w;                 w += align256((size_t)nq * SR_CAP * sizeof(int));
+    float *cand_ip = (float *)w;
     const int64_t ng = (int64_t)nq * SR_GROUPS;
     hipLaunchKernelGGL(search_init_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, s, q, nq, qq, gmin, cnt);
     const size_t lds = (size_t)SB_TR * SB_LS + SB_TR * sizeof(float);
@@ -1009,14 +1065,15 @@ extern "C" int grafp_knn_search_l2_pre(const float *db, const void *db_bf16, con
                        (const float *)qq, nq, b_rps, gmin);                                                         \
     hipLaunchKernelGGL(search_thr_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, (const int *)gmin, nq, k, thr);      \
     hipLaunchKernelGGL(search_scan_bf16_kernel<QW>, grid, dim3(256), lds, s, dbh, db_sqnorm, n, q,                  \
-                       (const float *)qq, nq, rps, (const float *)thr, cnt, cand_i)
+                       (const float *)qq, nq, rps, (const float *)thr, cnt, cand_i, cand_ip)
     if (qw == 1) { SB_LAUNCH(1); }
     else if (qw == 2) { SB_LAUNCH(2); }
     else { SB_LAUNCH(4); }
 #undef SB_LAUNCH
     GRAFP_CHECK_LAUNCH("search_bound_bf16_kernel / search_scan_bf16_kernel");
     hipLaunchKernelGGL(search_select_exact_kernel, dim3(nq), dim3(256), 0, s, db, db_sqnorm, n, q, (const float *)qq, nq,
-                       k, id_base, (const float *)thr, (const int *)cnt, (const int *)cand_i, out_dist, out_ids);
+                       k, id_base, (const float *)thr, (const int *)cnt, (const int *)cand_i, (const float *)cand_ip,
+                       out_dist, out_ids);
     GRAFP_CHECK_LAUNCH("search_select_exact_kernel");
     return GRAFP_OK;
 }
