@@ -107,6 +107,15 @@ int grafp_knn_normalize_strided(const void *x, int dtype, int64_t stride_b, int6
 int grafp_knn_graph_f32(const float *x, int B, int C, int N, int k, int normalize, int64_t *idx, void *ws,
                         size_t ws_bytes, grafp_stream_t stream);
 
+/* The same graph (bit-identical indices) through a bf16 pre-filter: Gram tiles on the bf16 matrix cores with a
+ * rigorous rounding margin select 4-8 candidates per node, whose exact f32 distances (same arithmetic order) decide.
+ * Shapes: C % 64 == 0, N % 128 == 0, N <= 65536, k <= 4 (grafp_knn_pre_supported); x is any (b, c) strided view with
+ * N contiguous, f32 or bf16; idx is (B,N,k) int64 or int32 (idx_is_i32). */
+int grafp_knn_pre_supported(int C, int N, int k);
+size_t grafp_knn_pre_workspace(int B, int C, int N);
+int grafp_knn_graph_pre(const void *x, int dtype, int64_t stride_b, int64_t stride_c, int B, int C, int N, int k,
+                        int normalize, void *idx, int idx_is_i32, void *ws, size_t ws_bytes, grafp_stream_t stream);
+
 /* ---- K6-K7: edge gather + max-relative aggregation -------------------------------------------
  * Replaces batched_index_select x2 (encoder/gcn_lib/torch_nn.py:79-98) + max over k of (x_j - x_i)
  * + channel interleave (torch_vertex.py:21-32):

@@ -56,6 +56,34 @@ def test_knn_graph_matches_reference_goldens(dev, C, N):
     assert np.array_equal(got[ok], g[f"int_{C}_{N}"].astype(np.int64)[ok])
 
 
+@pytest.mark.parametrize("C,N,B", [(64, 1024, 2), (128, 512, 2), (256, 256, 3), (512, 128, 2), (64, 128, 5)])
+def test_knn_graph_prefilter_equals_f32_path(dev, C, N, B):
+    """knn_pre.hip (bf16 pre-filter + exact rescoring) against knn_graph.hip (all exact f32) and the C oracle: normal
+    features, clusters of near-duplicates (many survivors -> the exact fallback of a lane), exact duplicates (ties ->
+    lowest index) and un-normalised integer features (loose bounds -> fallback everywhere)."""
+    from grafp_amd import ops
+    from oracle import native
+    x = hash_normalish(f"gpu:knnpre.{C}.{N}", (B, C, N)).astype(np.float32)
+    x[0, :, 40:100] = x[0, :, 40:41] + 1e-3 * hash_normalish(f"gpu:knnpre.c.{C}.{N}", (C, 60))   # a tight cluster
+    x[1, :, 10:50] = x[1, :, 10:11]                                                              # exact duplicates
+    for normalize, xx in ((True, x), (False, hash_ints(f"gpu:knnpre.i.{C}.{N}", (B, C, N), -4, 4).astype(np.float32))):
+        xt = t(xx).to(dev)
+        a = ops.knn_graph(xt, 3, normalize=normalize, prefilter=False)
+        b = ops.knn_graph(xt, 3, normalize=normalize, prefilter=True)
+        assert torch.equal(a, b)
+        assert np.array_equal(b.cpu().numpy(), native.knn_graph(xx, 3, normalize=normalize))
+        b32 = ops.knn_graph(xt, 3, normalize=normalize, index_dtype=torch.int32)
+        assert torch.equal(b32.to(torch.int64), b)
+    xc = t(x).to(dev).permute(1, 0, 2).contiguous()                      # (C, B, N) layout, bf16 activations
+    for dt in (torch.float32, torch.bfloat16):
+        a = ops.knn_graph(xc.to(dt), 3, layout="cbn", prefilter=False)
+        b = ops.knn_graph(xc.to(dt), 3, layout="cbn", prefilter=True)
+        assert torch.equal(a, b)
+    for k in (1, 2, 4):
+        xt = t(x).to(dev)
+        assert torch.equal(ops.knn_graph(xt, k, prefilter=False), ops.knn_graph(xt, k, prefilter=True))
+
+
 def test_knn_graph_full_batch_properties(dev):
     """BASELINE config-2 size (B=256, stage 0): size-independent properties + a sampled exact check."""
     from grafp_amd import ops
