@@ -133,6 +133,154 @@ __global__ __launch_bounds__(PK_THREADS) void peak_bwd_kernel(const float *__res
     }
 }
 
+// ---- fast path for the model's shape: F = 8 filters, 7x7 taps, W = 32 ----------------------------------------------
+// The generic kernels above read two LDS operands per multiply-add (tap weight + pixel) and are LDS-bound.  Here a
+// thread owns 4 horizontally adjacent output pixels x all 8 filters (32 accumulators): per (plane, tap row) it reads 10
+// pixels once and the 8 weights of a tap with two broadcast ds_read_b128 -> 224 multiply-adds per 24 LDS reads.
+// Same summation order per output as the generic kernel (bias, then taps in (plane, ky, kx) order).
+constexpr int PK8_F = 8, PK8_K = 7, PK8_W = 32;
+
+__global__ __launch_bounds__(PK_THREADS) void peak_fwd8_kernel(const float *__restrict__ spec, int H,
+                                                               const float *__restrict__ weight,
+                                                               const float *__restrict__ bias, int sh, int Ho,
+                                                               const float *__restrict__ t_ramp,
+                                                               const float *__restrict__ f_ramp,
+                                                               float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int W = PK8_W, K = PK8_K, F = PK8_F, ph = K / 2, pw = K / 2, WP = W + 2 * pw, NT = 3 * K * K;
+    const int HP = H + 2 * ph;
+    float *swT = reinterpret_cast<float *>(smem);      // [tap][8], 16-byte aligned rows
+    float *img = swT + NT * F;
+    float *scratch = img + 3 * HP * WP;
+    const int tid = threadIdx.x, b = blockIdx.x;
+    for (int i = tid; i < NT * F; i += PK_THREADS) {
+        const int f = i / NT, tap = i - f * NT;        // weight[f][tap]
+        swT[tap * F + f] = weight[i];
+    }
+    build_image(img, scratch, spec + (size_t)b * H * W, H, W, ph, pw, t_ramp, f_ramp, tid);
+    float *ob = out + (size_t)b * F * Ho * W;
+    for (int g = tid; g < Ho * (W / 4); g += PK_THREADS) {
+        const int y = g / (W / 4), x0 = (g - y * (W / 4)) * 4;
+        float acc[F][4];
+#pragma unroll
+        for (int f = 0; f < F; ++f)
+#pragma unroll
+            for (int px = 0; px < 4; ++px) acc[f][px] = bias[f];
+        for (int ci = 0; ci < 3; ++ci)
+            for (int ky = 0; ky < K; ++ky) {
+                const float *row = img + ci * HP * WP + (y * sh + ky) * WP + x0;
+                float in[K + 3];
+#pragma unroll
+                for (int e = 0; e < K + 3; ++e) in[e] = row[e];
+                const f32x4 *w4 = reinterpret_cast<const f32x4 *>(swT + (ci * K + ky) * K * F);
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) {
+                    const f32x4 wa = w4[2 * kx], wb = w4[2 * kx + 1];
+#pragma unroll
+                    for (int px = 0; px < 4; ++px) {
+#pragma unroll
+                        for (int f = 0; f < 4; ++f) {
+                            acc[f][px] = __builtin_fmaf(wa[f], in[kx + px], acc[f][px]);
+                            acc[4 + f][px] = __builtin_fmaf(wb[f], in[kx + px], acc[4 + f][px]);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            f32x4 o;
+#pragma unroll
+            for (int px = 0; px < 4; ++px) o[px] = fmaxf(acc[f][px], 0.0f);
+            *reinterpret_cast<f32x4 *>(ob + (size_t)f * Ho * W + y * W + x0) = o;
+        }
+    }
+}
+
+// Weight gradient: thread = one (plane, tap row) x one slice of the output positions; per position it reads the 8
+// masked gradients and 7 pixels and updates 8 x 7 accumulators.  Accumulators persist over the clips of the
+// workgroup; one LDS reduction over the slices and one atomic per weight per workgroup at the end.
+constexpr int PK8_COMBOS = 3 * PK8_K;                       // 21
+constexpr int PK8_SLICES = PK_THREADS / PK8_COMBOS;         // 12
+
+__global__ __launch_bounds__(PK_THREADS) void peak_bwd8_kernel(const float *__restrict__ spec, int B, int H, int sh,
+                                                               int Ho, const float *__restrict__ t_ramp,
+                                                               const float *__restrict__ f_ramp,
+                                                               const float *__restrict__ out,
+                                                               const float *__restrict__ gout,
+                                                               float *__restrict__ dweight,
+                                                               float *__restrict__ dbias) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int W = PK8_W, K = PK8_K, F = PK8_F, ph = K / 2, pw = K / 2, WP = W + 2 * pw;
+    const int HP = H + 2 * ph, nPos = Ho * W;
+    float *img = reinterpret_cast<float *>(smem);
+    float *sg = img + 3 * HP * WP;                 // masked grad [F][nPos]
+    float *scratch = sg + F * nPos;                // [4]
+    float *part = scratch + 4;                     // [SLICES][COMBOS][F*K + F] partial sums (reduction at the end)
+    const int tid = threadIdx.x;
+    const int combo = tid % PK8_COMBOS, slice = tid / PK8_COMBOS;
+    const bool active = slice < PK8_SLICES;
+    const int ci = combo / K, ky = combo - ci * K;
+    const int per = (nPos + PK8_SLICES - 1) / PK8_SLICES;
+    const int p0 = slice * per, p1 = (p0 + per < nPos) ? p0 + per : nPos;
+    float acc[F][K], bsum[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+        bsum[f] = 0.0f;
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) acc[f][kx] = 0.0f;
+    }
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        __syncthreads();
+        build_image(img, scratch, spec + (size_t)b * H * W, H, W, ph, pw, t_ramp, f_ramp, tid);
+        const float *ob = out + (size_t)b * F * nPos, *gb = gout + (size_t)b * F * nPos;
+        for (int i = tid; i < F * nPos; i += PK_THREADS) sg[i] = ob[i] > 0.0f ? gb[i] : 0.0f;
+        __syncthreads();
+        if (active) {
+            const float *plane = img + ci * HP * WP + ky * WP;
+            for (int p = p0; p < p1; ++p) {
+                const int y = p / W, x = p - y * W;
+                const float *row = plane + (y * sh) * WP + x;
+                float in[K], g8[F];
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) in[kx] = row[kx];
+#pragma unroll
+                for (int f = 0; f < F; ++f) g8[f] = sg[f * nPos + p];
+#pragma unroll
+                for (int f = 0; f < F; ++f) {
+                    bsum[f] += g8[f];
+#pragma unroll
+                    for (int kx = 0; kx < K; ++kx) acc[f][kx] = __builtin_fmaf(g8[f], in[kx], acc[f][kx]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    constexpr int PER_T = F * K + F;               // 64 values per thread
+    if (active) {
+        float *mine = part + (size_t)(slice * PK8_COMBOS + combo) * PER_T;
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) mine[f * K + kx] = acc[f][kx];
+            mine[F * K + f] = bsum[f];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < PK8_COMBOS * F * K + F; i += PK_THREADS) {
+        float s2 = 0.0f;
+        if (i < PK8_COMBOS * F * K) {
+            const int cb = i / (F * K), r = i - cb * (F * K);        // r = f * K + kx
+            for (int sl = 0; sl < PK8_SLICES; ++sl) s2 += part[(size_t)(sl * PK8_COMBOS + cb) * PER_T + r];
+            const int f = r / K, kx = r - f * K, c2 = cb / K, ky2 = cb - c2 * K;
+            atomicAdd(&dweight[((f * 3 + c2) * K + ky2) * K + kx], s2);
+        } else {
+            const int f = i - PK8_COMBOS * F * K;                    // bias: the slices of combo 0 cover every position once
+            for (int sl = 0; sl < PK8_SLICES; ++sl) s2 += part[(size_t)(sl * PK8_COMBOS) * PER_T + F * K + f];
+            atomicAdd(&dbias[f], s2);
+        }
+    }
+}
+
 }  // namespace grafp
 
 extern "C" int grafp_peak_extract_fwd_f32(const float *spec, int B, int H, int W, const float *weight,
@@ -146,6 +294,13 @@ extern "C" int grafp_peak_extract_fwd_f32(const float *spec, int B, int H, int W
     const int ph = KH / 2, pw = KW / 2, Ho = (H + 2 * ph - KH) / stride_h + 1;
     const size_t lds = ((size_t)3 * (H + 2 * ph) * (W + 2 * pw) + (size_t)F * 3 * KH * KW + 4) * sizeof(float);
     GRAFP_REQUIRE(lds <= 160 * 1024, "peak_extract_fwd: needs %zu B of LDS (> 160 KiB)", lds);
+    if (F == PK8_F && KH == PK8_K && KW == PK8_K && W == PK8_W) {
+        (void)hipFuncSetAttribute((const void *)peak_fwd8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(peak_fwd8_kernel, dim3(B), dim3(PK_THREADS), lds, (hipStream_t)stream, spec, H, weight, bias,
+                           stride_h, Ho, t_ramp, f_ramp, out);
+        GRAFP_CHECK_LAUNCH("peak_fwd8_kernel");
+        return GRAFP_OK;
+    }
     (void)hipFuncSetAttribute((const void *)peak_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(peak_fwd_kernel, dim3(B), dim3(PK_THREADS), lds, (hipStream_t)stream, spec, H, W, weight, bias, F,
                        KH, KW, stride_h, Ho, t_ramp, f_ramp, out);
@@ -165,8 +320,20 @@ extern "C" int grafp_peak_extract_bwd_f32(const float *spec, int B, int H, int W
     const size_t lds = ((size_t)3 * (H + 2 * ph) * (W + 2 * pw) + (size_t)F * Ho * W + (size_t)F * 3 * KH * KW + F + 4) *
                        sizeof(float);
     GRAFP_REQUIRE(lds <= 160 * 1024, "peak_extract_bwd: needs %zu B of LDS (> 160 KiB)", lds);
-    (void)hipFuncSetAttribute((const void *)peak_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const int blocks = B < 256 ? B : 256;
+    if (F == PK8_F && KH == PK8_K && KW == PK8_K && W == PK8_W) {
+        const size_t lds8 = ((size_t)3 * (H + 2 * ph) * (W + 2 * pw) + (size_t)F * Ho * W + 4 +
+                             (size_t)PK8_SLICES * PK8_COMBOS * (F * KW + F)) * sizeof(float);
+        if (lds8 <= 160 * 1024) {
+            (void)hipFuncSetAttribute((const void *)peak_bwd8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds8);
+            hipLaunchKernelGGL(peak_bwd8_kernel, dim3(blocks), dim3(PK_THREADS), lds8, (hipStream_t)stream, spec, B, H,
+                               stride_h, Ho, t_ramp, f_ramp, out, grad_out, dweight, dbias);
+            GRAFP_CHECK_LAUNCH("peak_bwd8_kernel");
+            return GRAFP_OK;
+        }
+    }
+    (void)hipFuncSetAttribute((const void *)peak_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(peak_bwd_kernel, dim3(blocks), dim3(PK_THREADS), lds, (hipStream_t)stream, spec, B, H, W, F, KH,
                        KW, stride_h, Ho, t_ramp, f_ramp, out, grad_out, dweight, dbias);
     GRAFP_CHECK_LAUNCH("peak_bwd_kernel");
