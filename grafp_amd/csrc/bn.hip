@@ -273,7 +273,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_dx_kernel(const T *__restri
                                                                const float *__restrict__ save_invstd, int act,
                                                                float slope, int training,
                                                                const float *__restrict__ part, T *__restrict__ dx,
-                                                               float *__restrict__ dgamma, float *__restrict__ dbeta) {
+                                                               float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                                               float *__restrict__ dpre_bias) {
     const int c = blockIdx.y, s = blockIdx.x, tid = threadIdx.x;
     const int S = gridDim.x, grp = s / Sg, sl = s - grp * Sg;
     const T *row = x + (size_t)c * M, *grow = dz + (size_t)c * M;
@@ -293,6 +294,9 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_dx_kernel(const T *__restri
         }
         dgamma[c] = tdx;
         dbeta[c] = td;
+        // gradient of a bias added BEFORE the normalisation: cancels exactly under batch statistics; with running
+        // statistics (eval) dx = ga*invstd*dy, so it is ga*invstd*sum(dy)
+        if (dpre_bias) dpre_bias[c] = training ? 0.0f : ga * invstd * td;
     }
     // train: dx = ga*invstd * (dy - mean_g(dy) - xhat * mean_g(dy*xhat)) within the group; eval: dx = ga*invstd*dy
     const float k = ga * invstd;
@@ -395,8 +399,8 @@ extern "C" int grafp_bn_fwd(const void *x, int dtype, int C, int64_t M, int grou
 
 extern "C" int grafp_bn_bwd(const void *x, const void *dz, int dtype, int C, int64_t M, int groups, const float *pre_bias,
                             const float *gamma, const float *beta, const float *save_mean, const float *save_invstd,
-                            int act, float slope, int training, void *dx, float *dgamma, float *dbeta, void *ws,
-                            size_t ws_bytes, grafp_stream_t stream) {
+                            int act, float slope, int training, void *dx, float *dgamma, float *dbeta,
+                            float *dpre_bias, void *ws, size_t ws_bytes, grafp_stream_t stream) {
     using namespace grafp;
     GRAFP_REQUIRE(x && dz && gamma && beta && save_mean && save_invstd && dx && dgamma && dbeta, "bn_bwd: null pointer");
     GRAFP_REQUIRE(C > 0 && M > 0 && C <= 65535, "bn_bwd: bad shape C=%d M=%lld", C, (long long)M);
@@ -419,7 +423,7 @@ extern "C" int grafp_bn_bwd(const void *x, const void *dz, int dtype, int C, int
                            M, Mg, p.chunk, p.Sg, G, pre_bias, gamma, beta, save_mean, save_invstd, act, slope, part);  \
         hipLaunchKernelGGL((bn_bwd_dx_kernel<T, VEC>), grid, dim3(BN_THREADS), 0, s, (const T *)x, (const T *)dz, M,   \
                            Mg, p.chunk, p.Sg, G, pre_bias, gamma, beta, save_mean, save_invstd, act, slope, training, part,    \
-                           (T *)dx, dgamma, dbeta);                                                                    \
+                           (T *)dx, dgamma, dbeta, dpre_bias);                                                         \
     } while (0)
     if (dtype == GRAFP_F32) {
         if (bn_vec_ok<float>(x, dz, dx, nullptr, Mg)) BN_BWD(float, true); else BN_BWD(float, false);

@@ -338,17 +338,17 @@ class _BnAct(torch.autograd.Function):
         C, M, act, slope, training, has_pb, has_res, groups = ctx.cfg
         dz = dz.detach().to(x.dtype).contiguous()
         dx = torch.empty_like(x)
+        # separate tensors (not views of one buffer): autograd adopts a fresh whole tensor as .grad without a copy
         dgamma = torch.empty((C,), dtype=torch.float32, device=x.device)
         dbeta = torch.empty((C,), dtype=torch.float32, device=x.device)
+        # d(pre_bias), written by the kernel: zero under batch statistics, ga*invstd*sum(dy) in eval mode
+        dpb = torch.empty((C,), dtype=torch.float32, device=x.device) if has_pb else None
         nbytes = lib.grafp_bn_workspace(C, M)
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
         with _timed("bn_bwd", (C, M, x.element_size())):
             check(lib.grafp_bn_bwd(_p(x), _p(dz), _DT[x.dtype], C, M, groups, _p(pb) if has_pb else None, _p(g32), _p(b32),
                                    _p(mean), _p(invstd), act, slope, int(training), _p(dx), _p(dgamma), _p(dbeta),
-                                   _p(ws), nbytes, _stream()), "bn_bwd")
-        dpb = None
-        if has_pb:      # cancels exactly under batch statistics; a plain bias in eval mode
-            dpb = torch.zeros_like(dgamma) if training else dx.reshape(C, -1).float().sum(dim=1)
+                                   _p(dpb) if has_pb else None, _p(ws), nbytes, _stream()), "bn_bwd")
         return dx, dgamma, dbeta, dpb, (dz if has_res else None), None, None, None, None, None, None, None, None
 
 
@@ -365,11 +365,24 @@ def bn_act(x, gamma, beta, running_mean, running_var, training, momentum=0.1, ep
 # ------------------------------------------------------------------------------------------------
 # K9  1x1 convolution on (C, M) rows: library GEMMs forward / input-gradient, hand-written weight gradient
 # ------------------------------------------------------------------------------------------------
-def _block_diag_weight(w, groups):
-    """(Cout, Cin/g) grouped weight -> dense block-diagonal (Cout, Cin): for the small groups of the max-relative
-    conv one dense GEMM (memory-bound either way) beats a 4-batch GEMM of 32x32 problems."""
+_BD_MASKS = {}
+
+
+def _block_diag_weight(w, groups, dtype=None):
+    """(Cout, Cin/g) grouped weight -> dense block-diagonal (Cout, Cin) in `dtype`: for the small groups of the
+    max-relative conv one dense GEMM (memory-bound either way) beats a 4-batch GEMM of 32x32 problems.  ONE
+    elementwise launch (broadcast product with a cached 0/1 mask, cast included) instead of the fill + one copy per
+    block + cast of torch.block_diag."""
     cout, cin_g = w.shape
-    return torch.block_diag(*w.reshape(groups, cout // groups, cin_g).unbind(0))
+    dtype = dtype or w.dtype
+    key = (groups, w.device, w.dtype)
+    mask = _BD_MASKS.get(key)
+    if mask is None:
+        mask = torch.eye(groups, device=w.device, dtype=w.dtype).reshape(groups, 1, groups, 1)
+        _BD_MASKS[key] = mask
+    out = torch.empty((groups, cout // groups, groups, cin_g), dtype=dtype, device=w.device)
+    torch.mul(w.reshape(groups, cout // groups, 1, cin_g), mask, out=out)
+    return out.reshape(cout, groups * cin_g)
 
 
 class _Conv1x1(torch.autograd.Function):
@@ -377,8 +390,7 @@ class _Conv1x1(torch.autograd.Function):
     def forward(ctx, x, w, groups):
         """x (Cin, M) f32/bf16 rows, w (Cout, Cin/groups) parameter view -> (Cout, M) in x's dtype."""
         x = x.detach()
-        wl = w.detach().to(x.dtype)
-        dense = _block_diag_weight(wl, groups) if groups > 1 else wl
+        dense = _block_diag_weight(w.detach(), groups, x.dtype) if groups > 1 else w.detach().to(x.dtype)
         y = torch.mm(dense, x)
         ctx.save_for_backward(x, dense)
         ctx.groups, ctx.wshape = groups, tuple(w.shape)

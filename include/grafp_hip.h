@@ -162,8 +162,8 @@ int grafp_bn_fwd(const void *x, int dtype, int C, int64_t M, int groups, const f
 int grafp_bn_bwd(const void *x, const void *dz, int dtype, int C, int64_t M, int groups, const float *pre_bias,
                  const float *gamma,
                  const float *beta, const float *save_mean, const float *save_invstd, int act, float slope,
-                 int training, void *dx, float *dgamma, float *dbeta, void *ws, size_t ws_bytes,
-                 grafp_stream_t stream);
+                 int training, void *dx, float *dgamma, float *dbeta, float *dpre_bias /* (C) or NULL */, void *ws,
+                 size_t ws_bytes, grafp_stream_t stream);
 
 /* ---- K9 backward: weight gradient of a 1x1 convolution on the (C, M) layout ------------------------------
  * dW[o][c] = sum_m grad_out[o][m] * x[c][m] for every 1x1 Conv2d of the encoder (torch_vertex.py:152-162,
