@@ -42,6 +42,8 @@ SIGNATURES = {
     "grafp_mrconv_bwd_strided": (_I, [_P, _I, _L, _L, _P, _P, _L, _L, _I, _I, _I, _I, _P, _P]),
     "grafp_mrconv_fwd_strided_i32": (_I, [_P, _I, _L, _L, _P, _I, _I, _I, _I, _P, _L, _L, _P]),
     "grafp_mrconv_bwd_strided_i32": (_I, [_P, _I, _L, _L, _P, _P, _L, _L, _I, _I, _I, _I, _P, _P]),
+    "grafp_stride2_taps_fwd": (_I, [_P, _I, _L, _I, _P, _P]),
+    "grafp_stride2_taps_bwd": (_I, [_P, _I, _L, _I, _P, _P]),
     "grafp_bn_workspace": (_Z, [_I, _L]),
     "grafp_bn_fwd": (_I, [_P, _I, _I, _L, _I, _P, _P, _P, _P, _I, _F, _F, _F, _I, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "grafp_bn_bwd": (_I, [_P, _P, _I, _I, _L, _I, _P, _P, _P, _P, _P, _I, _F, _I, _P, _P, _P, _P, _P, _Z, _P]),

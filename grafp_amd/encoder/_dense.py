@@ -74,8 +74,7 @@ def conv3_stride2(conv, x):
     cin, B, N = x.shape
     cout = conv.out_channels
     n_out = (N - 1) // 2 + 1
-    xp = F.pad(x, (1, 1))
-    taps = torch.cat([xp[:, :, t:t + 2 * n_out - 1:2] for t in range(3)], dim=0)       # (3Cin, B, n_out)
+    taps = ops.stride2_taps(x)                                                          # (3, Cin, B, n_out)
     w = conv.weight[:, :, :, 1].permute(0, 2, 1).reshape(cout, 3 * cin)                 # [o][t*Cin + c]
     return ops.conv1x1_rows(taps.reshape(3 * cin, B * n_out), w).reshape(cout, B, n_out)
 

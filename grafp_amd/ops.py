@@ -365,6 +365,39 @@ def bn_act(x, gamma, beta, running_mean, running_var, training, momentum=0.1, ep
 # ------------------------------------------------------------------------------------------------
 # K9  1x1 convolution on (C, M) rows: library GEMMs forward / input-gradient, hand-written weight gradient
 # ------------------------------------------------------------------------------------------------
+class _Stride2Taps(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _require_gpu(x)
+        x = x.detach().contiguous()
+        if x.dtype not in _DT:
+            x = x.float()
+        N = x.shape[-1]
+        rows = x.numel() // N
+        n_out = (N - 1) // 2 + 1
+        out = torch.empty((3,) + tuple(x.shape[:-1]) + (n_out,), dtype=x.dtype, device=x.device)
+        check(lib.grafp_stride2_taps_fwd(_p(x), _DT[x.dtype], rows, N, _p(out), _stream()), "stride2_taps_fwd")
+        ctx.shape = tuple(x.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        shape = ctx.shape
+        N = shape[-1]
+        g = g.detach().contiguous()
+        if g.dtype not in _DT:
+            g = g.float()
+        dx = torch.empty(shape, dtype=g.dtype, device=g.device)
+        check(lib.grafp_stride2_taps_bwd(_p(g), _DT[g.dtype], dx.numel() // N, N, _p(dx), _stream()), "stride2_taps_bwd")
+        return dx
+
+
+def stride2_taps(x):
+    """x (..., N) -> (3, ..., n_out): out[t][...][j] = x[...][2j + t - 1] (zero outside), the operand of the 3-tap
+    stride-2 node convolution of Downsample as one gather (and one scatter-free transpose in backward)."""
+    return _Stride2Taps.apply(x)
+
+
 _BD_MASKS = {}
 
 

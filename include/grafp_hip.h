@@ -194,6 +194,12 @@ int grafp_ntxent_fwd_bwd_f32(const float *zi_all, const float *zj_all, int B_all
                              int n_local, float tau, float *loss_partial, float *dzi, float *dzj, void *ws,
                              size_t ws_bytes, grafp_stream_t stream);
 
+/* ---- K10 glue: taps of the stride-2 node convolution of Downsample (graph_encoder.py:16-28) -------------
+ *   x (rows, N) f32/bf16 contiguous rows (rows = C*B)  ->  out (3, rows, n_out), n_out = (N-1)/2 + 1,
+ *   out[t][r][j] = x[r][2j + t - 1], zero outside [0, N); _bwd is its transpose (grad_out (3, rows, n_out) -> dx). */
+int grafp_stride2_taps_fwd(const void *x, int dtype, int64_t rows, int N, void *out, grafp_stream_t stream);
+int grafp_stride2_taps_bwd(const void *grad_out, int dtype, int64_t rows, int N, void *dx, grafp_stream_t stream);
+
 /* ---- K13: brute-force fingerprint search ------------------------------------------------------
  * Replaces faiss.IndexFlatL2 add/search as used at eval.py:54,212-213,269-270: exact squared-L2
  * top-k, ascending, ids = row index + id_base, ties -> lowest id, id -1 / dist +inf when fewer than

@@ -588,3 +588,27 @@ def test_seq_rerank_bit_exact_vs_c_oracle(dev, n, nq_rows, k, lens):
                                   torch.from_numpy(item_row).to(dev), torch.from_numpy(item_len).to(dev), top=10)
     assert np.array_equal(got_i.cpu().numpy(), want_i)
     assert np.array_equal(got_s.cpu().numpy(), want_s)
+
+
+@pytest.mark.parametrize("shape", [(5, 3, 64), (8, 2, 101), (2, 4, 1)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_stride2_taps_vs_pad_slice_cat(dev, shape, dtype):
+    """ops.stride2_taps == F.pad + three strided slices (what the stride-2 3x1 convolution of Downsample reads),
+    forward exactly and backward exactly in f32 / to bf16 rounding."""
+    import torch.nn.functional as F
+    from grafp_amd import ops
+    x = t(hash_normalish(f"gpu:taps.{shape}", shape)).to(dev).to(dtype)
+    N = shape[-1]
+    n_out = (N - 1) // 2 + 1
+    xr = x.clone().float().requires_grad_(True)
+    xp = F.pad(xr, (1, 1))
+    want = torch.stack([xp[..., t0:t0 + 2 * n_out - 1:2] for t0 in range(3)], dim=0)
+    xg = x.clone().requires_grad_(True)
+    got = ops.stride2_taps(xg)
+    assert got.shape == want.shape and got.dtype == dtype
+    assert torch.equal(got.float(), want.detach().to(dtype).float())
+    g = t(hash_normalish(f"gpu:taps.g.{shape}", tuple(want.shape))).to(dev)
+    want.backward(g.to(dtype).float())
+    got.backward(g.to(dtype))
+    tol = 0.0 if dtype == torch.float32 else 1e-2
+    assert torch.allclose(xg.grad.float(), xr.grad, rtol=tol, atol=tol)
