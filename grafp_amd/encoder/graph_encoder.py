@@ -83,6 +83,7 @@ class GraphEncoder(nn.Module):
         self.dilation, self.dropout = dilation, dropout
         self.num_blocks = sum(self.blocks)
         self.conv = "mr"                      # the reference ignores its `conv` argument (:123)
+        self._lowp = None                     # cached low-precision copies of the 1x1 conv weights (ops.lowp_weights)
         n_nodes = cfg["n_mels"] * cfg["n_frames"] // cfg["peak_stride"]
 
         self.stem = nn.Sequential(nn.Conv2d(in_channels, self.channels[0], kernel_size=1, bias=False),
@@ -117,6 +118,13 @@ class GraphEncoder(nn.Module):
         statistics per view (the reference runs the views one after the other), everything else is per clip."""
         x = to_cbn(x)
         g = int(views)
+        if torch.is_autocast_enabled() and x.is_cuda:      # all 1x1 conv weights to the autocast dtype in one launch
+            if self._lowp is None:
+                self._lowp = ops.lowp_weights([m for m in self.modules()
+                                               if isinstance(m, nn.Conv2d) and m.kernel_size == (1, 1)])
+            self._lowp.refresh(torch.get_autocast_dtype("cuda"))
+        elif self._lowp is not None:
+            self._lowp.clear()
         with deferred_counters():
             x = bn_act(self.stem[1], conv1x1(self.stem[0], x), act=ops.ACT_LEAKY, slope=self.stem[2].negative_slope,
                        groups=g)

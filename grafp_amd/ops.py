@@ -420,10 +420,16 @@ def _block_diag_weight(w, groups, dtype=None):
 
 class _Conv1x1(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, groups):
-        """x (Cin, M) f32/bf16 rows, w (Cout, Cin/groups) parameter view -> (Cout, M) in x's dtype."""
+    def forward(ctx, x, w, groups, w_lowp=None):
+        """x (Cin, M) f32/bf16 rows, w (Cout, Cin/groups) parameter view -> (Cout, M) in x's dtype.
+        w_lowp: optional copy of w already in x's dtype (see lowp_weights), saves the per-call cast launch."""
         x = x.detach()
-        dense = _block_diag_weight(w.detach(), groups, x.dtype) if groups > 1 else w.detach().to(x.dtype)
+        if groups > 1:
+            dense = _block_diag_weight(w.detach(), groups, x.dtype)
+        elif w_lowp is not None and w_lowp.dtype == x.dtype and w_lowp.numel() == w.numel():
+            dense = w_lowp.detach().reshape(w.shape)
+        else:
+            dense = w.detach().to(x.dtype)
         y = torch.mm(dense, x)
         ctx.save_for_backward(x, dense)
         ctx.groups, ctx.wshape = groups, tuple(w.shape)
@@ -451,16 +457,43 @@ class _Conv1x1(torch.autograd.Function):
             else:
                 dw = torch.bmm(g.reshape(groups, cout // groups, M), x.reshape(groups, cin_g, M).transpose(1, 2))
                 dw = dw.reshape(cout, cin_g).float()
-        return dx, dw, None
+        return dx, dw, None, None
 
 
-def conv1x1_rows(x, w, groups=1):
+def conv1x1_rows(x, w, groups=1, w_lowp=None):
     """y = W x over (C, M) rows (x contiguous 2-D).  Under autocast f32 inputs are lowered to the autocast dtype
     (the rest of a block already flows in it); the weight gradient of bf16 operands is the hand-written split-K
     kernel (grafp_conv1x1_wgrad_bf16), everything else a plain library GEMM."""
     if torch.is_autocast_enabled() and x.is_cuda and x.dtype == torch.float32:
         x = x.to(torch.get_autocast_gpu_dtype())
-    return _Conv1x1.apply(x.contiguous(), w, groups)
+    return _Conv1x1.apply(x.contiguous(), w, groups, w_lowp)
+
+
+class lowp_weights:
+    """Lowers the weights of many 1x1 convolutions to the autocast dtype with ONE multi-tensor copy per forward pass
+    (instead of one cast launch per layer).  `refresh()` before the layers run; conv._w_lowp is then picked up by
+    encoder/_dense.conv1x1.  The buffers are overwritten by the next refresh(): fine as long as the weights do not
+    change between a forward pass and its backward pass."""
+
+    def __init__(self, convs):
+        self.convs = [c for c in convs if c.groups == 1]
+        self._bufs, self._dtype = None, None
+
+    def refresh(self, dtype):
+        ws = [c.weight for c in self.convs]
+        if not ws or not ws[0].is_cuda:
+            return
+        if self._bufs is None or self._dtype != dtype or self._bufs[0].device != ws[0].device:
+            self._bufs = [torch.empty(w.shape, dtype=dtype, device=w.device) for w in ws]
+            self._dtype = dtype
+        with torch.no_grad():
+            torch._foreach_copy_(self._bufs, ws)
+        for c, b in zip(self.convs, self._bufs):
+            c._w_lowp = b
+
+    def clear(self):
+        for c in self.convs:
+            c._w_lowp = None
 
 
 # ------------------------------------------------------------------------------------------------

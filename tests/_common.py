@@ -110,12 +110,12 @@ class CpuOps:
         from grafp_amd import ops
         from oracle import model as om
         self._ops = ops
-        self._saved = (ops.knn_graph, ops.max_relative, ops.peak_extract, ops.bn_act)
+        self._saved = (ops.knn_graph, ops.max_relative, ops.peak_extract, ops.bn_act, ops.stride2_taps)
 
         def bcn(x, layout):
             return x if layout == "bcn" else x.permute(1, 0, 2)
 
-        def knn(x, k, normalize=True, layout="bcn", index_dtype=torch.int64):
+        def knn(x, k, normalize=True, layout="bcn", index_dtype=torch.int64, prefilter=None):
             if x.dim() == 4:
                 x = x.squeeze(-1)
             return om.knn_graph_torch(bcn(x, layout).float(), k).to(index_dtype)
@@ -137,12 +137,16 @@ class CpuOps:
                            for seg in y.chunk(groups, dim=2)], dim=2).reshape(x.shape)
             y = F.relu(y) if act == 1 else (F.leaky_relu(y, slope) if act == 2 else y)
             return y if residual is None else y + residual
-        ops.knn_graph, ops.max_relative, ops.peak_extract, ops.bn_act = knn, maxrel, peak, bn_act
+        def taps(x):       # pad + three strided slices: what Conv2d(3, stride 2, padding 1) reads along N
+            n_out = (x.shape[-1] - 1) // 2 + 1
+            xp = F.pad(x, (1, 1))
+            return torch.stack([xp[..., t0:t0 + 2 * n_out - 1:2] for t0 in range(3)], dim=0)
+        ops.knn_graph, ops.max_relative, ops.peak_extract, ops.bn_act, ops.stride2_taps = knn, maxrel, peak, bn_act, taps
         return self
 
     def __exit__(self, *exc):
         o = self._ops
-        o.knn_graph, o.max_relative, o.peak_extract, o.bn_act = self._saved
+        o.knn_graph, o.max_relative, o.peak_extract, o.bn_act, o.stride2_taps = self._saved
 
 
 def reference_graphs(sd, xi, xj, train):
