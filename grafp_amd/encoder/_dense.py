@@ -39,8 +39,7 @@ def conv1x1(conv, x):
     for the grouped conv of the max-relative block)."""
     cin, B, N = x.shape
     cout, g = conv.out_channels, conv.groups
-    return ops.conv1x1_rows(x.reshape(cin, B * N), conv.weight.reshape(cout, cin // g), g,
-                            getattr(conv, "_w_lowp", None)).reshape(cout, B, N)
+    return ops.conv1x1_rows(x.reshape(cin, B * N), conv.weight, g, getattr(conv, "_w_lowp", None)).reshape(cout, B, N)
 
 
 # num_batches_tracked of every BatchNorm touched inside a `deferred_counters()` block advance with ONE multi-tensor

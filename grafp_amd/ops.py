@@ -424,15 +424,18 @@ class _Conv1x1(torch.autograd.Function):
         """x (Cin, M) f32/bf16 rows, w (Cout, Cin/groups) parameter view -> (Cout, M) in x's dtype.
         w_lowp: optional copy of w already in x's dtype (see lowp_weights), saves the per-call cast launch."""
         x = x.detach()
+        # w may be the 4-D Conv2d parameter itself (Cout, Cin/g, 1, 1): taking it un-reshaped keeps a view node out of
+        # the graph, so the weight gradient returned below is adopted as .grad without a copy
+        w2 = w.detach().reshape(w.shape[0], -1)
         if groups > 1:
-            dense = _block_diag_weight(w.detach(), groups, x.dtype)
+            dense = _block_diag_weight(w2, groups, x.dtype)
         elif w_lowp is not None and w_lowp.dtype == x.dtype and w_lowp.numel() == w.numel():
-            dense = w_lowp.detach().reshape(w.shape)
+            dense = w_lowp.detach().reshape(w2.shape)
         else:
-            dense = w.detach().to(x.dtype)
+            dense = w2.to(x.dtype)
         y = torch.mm(dense, x)
         ctx.save_for_backward(x, dense)
-        ctx.groups, ctx.wshape = groups, tuple(w.shape)
+        ctx.groups, ctx.wshape, ctx.wfull = groups, tuple(w2.shape), tuple(w.shape)
         return y
 
     @staticmethod
@@ -457,7 +460,7 @@ class _Conv1x1(torch.autograd.Function):
             else:
                 dw = torch.bmm(g.reshape(groups, cout // groups, M), x.reshape(groups, cin_g, M).transpose(1, 2))
                 dw = dw.reshape(cout, cin_g).float()
-        return dx, dw, None, None
+        return dx, (None if dw is None else dw.reshape(ctx.wfull)), None, None
 
 
 def conv1x1_rows(x, w, groups=1, w_lowp=None):
