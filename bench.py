@@ -11,6 +11,7 @@ all-reduce -> Adam.  Inputs are synthetic 1 s clips already resident in HBM (SUR
 are randomly initialised (the architecture and shapes are config/grafp.yaml's).  Rank 0 prints ONE JSON line.
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -303,6 +304,23 @@ def main():
                                                            "L2 vs the oracle with the k-NN edges held equal"}
             del t32
         if world == 1 and not args.no_retrieval:
+            # BASELINE config 3/4, generation side: fingerprinting throughput of the forward pass alone (eval mode,
+            # log-mel already computed), as generate.py / test_fp.py drive it, 1024 one-second segments per call
+            model.eval()
+            segs = trainer.augment(x_i, x_j)[0].repeat(4, 1, 1)[:1024]
+            fp = {}
+            for tag, amp_dt in (("f32", None), ("bf16", torch.bfloat16)):
+                ctx = torch.autocast("cuda", dtype=amp_dt) if amp_dt is not None else contextlib.nullcontext()
+                with torch.no_grad(), ctx:
+                    model.embed(segs)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(3):
+                        model.embed(segs)
+                    torch.cuda.synchronize()
+                fp[f"segments_per_s_{tag}"] = round(3 * segs.shape[0] / (time.perf_counter() - t0), 1)
+            line["fingerprinting"] = fp
+            model.train()
             line["retrieval"] = retrieval_probe(device, cpu_check=not args.no_cpu_baseline)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, args.cpu_baseline_seconds)

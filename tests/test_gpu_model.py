@@ -288,3 +288,21 @@ def test_db_writers(dev, tmp_path):
         assert (np.linalg.norm(got - want, axis=1) / np.linalg.norm(want, axis=1)).max() <= 5e-3
     np.testing.assert_allclose(np.asarray(q), np.asarray(d), rtol=1e-5, atol=1e-6)     # identity augmentation
     np.testing.assert_allclose(np.linalg.norm(want, axis=1), 1.0, rtol=1e-5)
+    # train mode (what the reference's scripts run in): one model call per track chunk, BatchNorm on that call's
+    # statistics -- the writers must reproduce exactly that batching
+    model.train()
+    create_dummy_db(tracks, augment=aug, model=model, output_root_dir=str(tmp_path), fname="dummy_train", verbose=False)
+    dt, _ = load_memmap_data(str(tmp_path), "dummy_train", display=False)
+    with torch.no_grad():
+        want_t = torch.cat([model.embed(aug(t.to(dev), None)[0])[1] for t in tracks]).cpu().numpy()
+    np.testing.assert_allclose(np.asarray(dt), want_t, rtol=1e-5, atol=1e-6)
+    assert np.abs(want_t - want).max() > 1e-4                                          # the two modes do differ
+    model.eval()
+    # opt-in packing of several tracks per model call (eval mode): same fingerprints up to GEMM rounding / near-tie flips
+    create_db(tracks, model, aug, str(tmp_path), concat=False, max_segments=1024)
+    parts = np.load(tmp_path / "fingerprints.npy", allow_pickle=True)
+    assert len(parts) == len(tracks) and sum(len(p) for p in parts) == n_seg
+    packed = np.concatenate(list(parts), axis=0)
+    with torch.no_grad():        # the train-mode pass above advanced the running statistics: fresh eval reference
+        want_e = torch.cat([model.embed(aug(t.to(dev), None)[0])[1] for t in tracks]).cpu().numpy()
+    assert (np.linalg.norm(packed - want_e, axis=1) / np.linalg.norm(want_e, axis=1)).max() <= 5e-3
