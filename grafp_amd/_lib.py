@@ -60,6 +60,7 @@ SIGNATURES = {
     "grafp_knn_search_l2_pre": (_I, [_P, _P, _P, _L, _P, _I, _I, _I, _L, _P, _P, _P, _Z, _P]),
     "grafp_merge_topk": (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),
     "grafp_seq_rerank_f32": (_I, [_P, _L, _P, _L, _P, _I, _P, _P, _I, _I, _I, _P, _P, _P]),
+    "grafp_seq_rerank_shard_f32": (_I, [_P, _L, _L, _L, _L, _L, _P, _L, _P, _I, _P, _P, _I, _I, _I, _P, _P, _P]),
 }
 
 

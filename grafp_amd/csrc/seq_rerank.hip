@@ -54,8 +54,12 @@ __device__ __forceinline__ float ord_f32(unsigned int o) {
     return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
 }
 
+// Sharded use: `recon` holds global rows [row_base, row_base + n_rows) of an n-row index; only candidates whose start id
+// lies in [id_lo, id_hi) are scored here (the shard that owns the start row, which also holds a halo of the next
+// shard's first rows so that whole sequences are local); the per-shard top lists are merged by score afterwards.
 __global__ __launch_bounds__(256) void seq_rerank_kernel(const float *__restrict__ recon, int64_t n,
-                                                         const float *__restrict__ q_rows,
+                                                         int64_t row_base, int64_t n_rows, int64_t id_lo,
+                                                         int64_t id_hi, const float *__restrict__ q_rows,
                                                          const int64_t *__restrict__ ids, int k,
                                                          const int64_t *__restrict__ item_row,
                                                          const int *__restrict__ item_len, int max_len, int top,
@@ -84,7 +88,7 @@ __global__ __launch_bounds__(256) void seq_rerank_kernel(const float *__restrict
             const int t = e / k;
             const int64_t id = ids[(r0 + t) * k + (e - t * k)];
             const int64_t c = id - t;                         // eval.py:273-274
-            if (id >= 0 && c >= 0) key = (unsigned long long)c;
+            if (id >= 0 && c >= 0 && c >= id_lo && c < id_hi) key = (unsigned long long)c;
         }
         keys[e] = key;
     }
@@ -109,10 +113,12 @@ __global__ __launch_bounds__(256) void seq_rerank_kernel(const float *__restrict
     for (int c = hw; c < ncand; c += 8) {
         const int cid = cand[c];
         const int64_t left = n - (int64_t)cid;
-        const int m = left < ql ? (int)left : ql;
+        int m = left < ql ? (int)left : ql;
+        const int64_t have = row_base + n_rows - (int64_t)cid;        // rows of this sequence present locally
+        if (have < m) m = have > 0 ? (int)have : 0;                   // (never with a halo of max_len - 1 rows)
         float acc = 0.0f;
         for (int t = 0; t < m; ++t) {
-            const float4 r = rc4[((int64_t)cid + t) * (RR_D / 4) + l];
+            const float4 r = rc4[((int64_t)cid - row_base + t) * (RR_D / 4) + l];
             const float4 qv = sq4[t * (RR_D / 4) + l];
             acc = __builtin_fmaf(qv.x, r.x, acc);
             acc = __builtin_fmaf(qv.y, r.y, acc);
@@ -136,23 +142,35 @@ __global__ __launch_bounds__(256) void seq_rerank_kernel(const float *__restrict
 
 }  // namespace grafp
 
-extern "C" int grafp_seq_rerank_f32(const float *index_rows, int64_t n, const float *q_rows, int64_t n_qrows,
-                                    const int64_t *topk_ids, int k, const int64_t *item_row, const int *item_len,
-                                    int n_items, int max_len, int top, int64_t *out_ids, float *out_scores,
-                                    grafp_stream_t stream) {
+extern "C" int grafp_seq_rerank_shard_f32(const float *index_rows, int64_t n_rows, int64_t row_base, int64_t n,
+                                          int64_t id_lo, int64_t id_hi, const float *q_rows, int64_t n_qrows,
+                                          const int64_t *topk_ids, int k, const int64_t *item_row,
+                                          const int *item_len, int n_items, int max_len, int top, int64_t *out_ids,
+                                          float *out_scores, grafp_stream_t stream) {
     using namespace grafp;
     GRAFP_REQUIRE(index_rows && q_rows && topk_ids && item_row && item_len && out_ids && out_scores,
                   "seq_rerank: null pointer");
     GRAFP_REQUIRE(n >= 1 && n < 0x7fffffffll && n_qrows >= 1 && n_items >= 0, "seq_rerank: bad n=%lld n_qrows=%lld",
                   (long long)n, (long long)n_qrows);
+    GRAFP_REQUIRE(n_rows >= 1 && row_base >= 0 && row_base + n_rows <= n && id_lo >= row_base && id_lo <= id_hi &&
+                  id_hi <= row_base + n_rows, "seq_rerank: bad shard rows [%lld, +%lld) ids [%lld, %lld) of %lld",
+                  (long long)row_base, (long long)n_rows, (long long)id_lo, (long long)id_hi, (long long)n);
     GRAFP_REQUIRE(k >= 1 && max_len >= 1 && max_len <= RR_MAX_LEN && (int64_t)max_len * k <= RR_MAX_CAND,
                   "seq_rerank: max_len=%d k=%d exceed %d segments / %d candidates per item", max_len, k, RR_MAX_LEN,
                   RR_MAX_CAND);
     GRAFP_REQUIRE(top >= 1 && top <= 64, "seq_rerank: top=%d not in [1, 64]", top);
     GRAFP_REQUIRE((((uintptr_t)index_rows | (uintptr_t)q_rows) & 15) == 0, "seq_rerank: rows must be 16-byte aligned");
     if (n_items == 0) return GRAFP_OK;
-    hipLaunchKernelGGL(seq_rerank_kernel, dim3(n_items), dim3(256), 0, (hipStream_t)stream, index_rows, n, q_rows,
-                       topk_ids, k, item_row, item_len, max_len, top, out_ids, out_scores);
+    hipLaunchKernelGGL(seq_rerank_kernel, dim3(n_items), dim3(256), 0, (hipStream_t)stream, index_rows, n, row_base,
+                       n_rows, id_lo, id_hi, q_rows, topk_ids, k, item_row, item_len, max_len, top, out_ids, out_scores);
     GRAFP_CHECK_LAUNCH("seq_rerank_kernel");
     return GRAFP_OK;
+}
+
+extern "C" int grafp_seq_rerank_f32(const float *index_rows, int64_t n, const float *q_rows, int64_t n_qrows,
+                                    const int64_t *topk_ids, int k, const int64_t *item_row, const int *item_len,
+                                    int n_items, int max_len, int top, int64_t *out_ids, float *out_scores,
+                                    grafp_stream_t stream) {
+    return grafp_seq_rerank_shard_f32(index_rows, n, 0, n, 0, n, q_rows, n_qrows, topk_ids, k, item_row, item_len,
+                                      n_items, max_len, top, out_ids, out_scores, stream);
 }

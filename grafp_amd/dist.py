@@ -18,6 +18,7 @@ on CPU with the gloo backend (tests/test_dist_cpu.py) without any CPU fallback i
 """
 import os
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -182,15 +183,19 @@ class ShardedFlatL2Index:
     search(q, k): local top-k (ids offset by the shard start) -> all-gather of (nq, k) dist+ids -> merge.
     `local_index_factory(id_base)` and `merge_fn(part_d, part_i)` default to the HIP implementations."""
 
-    def __init__(self, d=128, group=None, local_index_factory=None, merge_fn=None):
+    def __init__(self, d=128, group=None, local_index_factory=None, merge_fn=None, halo=63):
         self.d, self.group = d, group
         self.rank, self.world = rank_of(group), world_size(group)
         self._factory, self._merge = local_index_factory, merge_fn
         self.local = None
         self.ntotal = 0
+        self.halo = int(halo)          # rows of the NEXT shard kept after the own rows: sequences stay local (rerank)
+        self.lo = self.hi = 0
+        self._halo_rows = None
 
     def add_global(self, x):
-        """Every rank passes the SAME full (n, d) array (host or memmap); each keeps only its rows."""
+        """Every rank passes the SAME full (n, d) array (host or memmap); each keeps only its rows (searched) plus
+        `halo` rows of the next shard (read by the sequence rerank only).  One call per index."""
         n = len(x)
         lo, hi = shard_range(n, self.rank, self.world)
         if self._factory is None:
@@ -198,7 +203,43 @@ class ShardedFlatL2Index:
             self._factory = lambda id_base: FlatL2Index(self.d, id_base=id_base)
         self.local = self._factory(lo + self.ntotal)
         self.local.add(x[lo:hi])
+        self.lo, self.hi = lo + self.ntotal, hi + self.ntotal
+        self._halo_rows = x[hi:min(n, hi + self.halo)]
         self.ntotal += n
+
+    def rerank(self, q_rows, topk_ids, item_row, item_len, top=10):
+        """Sequence-level rerank (eval.py:262-290) over the sharded index: every rank scores the candidates whose start
+        row it owns (its rows + halo make those sequences local), then one all-gather of the (n_items, top) lists
+        and a merge by (score descending, id ascending).  q_rows / topk_ids are the replicated query segments and the
+        merged GLOBAL search results; returns (ids, scores) like ops.seq_rerank."""
+        from . import ops
+        dev = self.local.device
+        rows = self.local.rows()
+        if self._halo_rows is not None and len(self._halo_rows):
+            halo = torch.as_tensor(np.ascontiguousarray(self._halo_rows)).to(dev, dtype=torch.float32)
+            rows = torch.cat([rows, halo], dim=0)
+        as_t = lambda a, dt: torch.as_tensor(a).to(dev, dtype=dt)
+        item_len_t = as_t(item_len, torch.int32)
+        if int(item_len_t.max().item()) - 1 > self.halo and self.world > 1:
+            raise ValueError(f"sequences of {int(item_len_t.max().item())} segments need halo >= that minus one")
+        ids, sc = ops.seq_rerank(rows, as_t(q_rows, torch.float32), as_t(topk_ids, torch.int64),
+                                 as_t(item_row, torch.int64), item_len_t, top=top,
+                                 shard=(self.lo, self.ntotal, self.lo, self.hi))
+        if self.world == 1:
+            return ids, sc
+        n_items = ids.shape[0]
+        gi = torch.empty((self.world * n_items, top), dtype=ids.dtype, device=dev)
+        gs = torch.empty((self.world * n_items, top), dtype=sc.dtype, device=dev)
+        dist.all_gather_into_tensor(gi, ids.contiguous(), group=self.group)
+        dist.all_gather_into_tensor(gs, sc.contiguous(), group=self.group)
+        gi = gi.reshape(self.world, n_items, top).permute(1, 0, 2).reshape(n_items, -1)
+        gs = gs.reshape(self.world, n_items, top).permute(1, 0, 2).reshape(n_items, -1)
+        # (score descending, id ascending); empty slots (id -1, score -inf) sink to the end
+        key_id = torch.where(gi < 0, torch.full_like(gi, torch.iinfo(torch.int64).max), gi)
+        o1 = torch.argsort(key_id, dim=1, stable=True)
+        gs1, gi1 = torch.gather(gs, 1, o1), torch.gather(gi, 1, o1)
+        o2 = torch.argsort(gs1, dim=1, descending=True, stable=True)
+        return torch.gather(gi1, 1, o2)[:, :top].contiguous(), torch.gather(gs1, 1, o2)[:, :top].contiguous()
 
     def search(self, q, k):
         """numpy in -> numpy out, tensors in -> tensors out (like FlatL2Index.search).  The local search, the

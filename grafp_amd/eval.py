@@ -62,9 +62,12 @@ def sequence_rerank(q, I, recon, sl):
 
 
 def eval_faiss(emb_dir, emb_dummy_dir=None, index_type="ivfpq", nogpu=False, max_train=1e7, test_ids="icassp",
-               test_seq_len="1 3 5 9 11 19", k_probe=20, n_centroids=64):
+               test_seq_len="1 3 5 9 11 19", k_probe=20, n_centroids=64, sharded=False):
     """Segment/sequence-level search experiment; returns hit rates (4, n_lengths) in percent:
-    rows = top1 exact, top1 near, top3 exact, top10 exact.  Side-effect files as in the reference."""
+    rows = top1 exact, top1 near, top3 exact, top10 exact.  Side-effect files as in the reference.
+    sharded=True (an extension; every rank of the initialised process group calls it with the same arguments): the
+    index rows are split over the ranks (dist.ShardedFlatL2Index: local search + all-gather + merge, local rerank of
+    the owned candidates + merge); every rank returns the same table, rank 0 writes the files."""
     if isinstance(test_seq_len, str):
         test_seq_len = np.asarray(list(map(int, test_seq_len.split())))
     test_seq_len = np.asarray(test_seq_len)
@@ -74,10 +77,17 @@ def eval_faiss(emb_dir, emb_dummy_dir=None, index_type="ivfpq", nogpu=False, max
     dummy_db, dummy_db_shape = load_memmap_data(emb_dummy_dir, "dummy_db")
     n_dummy = int(dummy_db_shape[0])
 
-    index = get_index(index_type, dummy_db, dummy_db.shape, (not nogpu), max_train, n_centroids=n_centroids)
     t0 = time.time()
-    index.add(np.asarray(dummy_db)); print(f"{len(dummy_db)} items from dummy DB")
-    index.add(np.asarray(db)); print(f"{len(db)} items from reference DB")
+    if sharded:
+        from . import dist as gdist
+        max_sl_ = int(max(test_seq_len))
+        index = gdist.ShardedFlatL2Index(int(dummy_db.shape[1]), halo=max(max_sl_ - 1, 0))
+        index.add_global(np.concatenate([np.asarray(dummy_db), np.asarray(db)], axis=0))   # dummy rows first (:212-213)
+        index.device = index.local.device
+    else:
+        index = get_index(index_type, dummy_db, dummy_db.shape, (not nogpu), max_train, n_centroids=n_centroids)
+        index.add(np.asarray(dummy_db)); print(f"{len(dummy_db)} items from dummy DB")
+        index.add(np.asarray(db)); print(f"{len(db)} items from reference DB")
     print(f"Added total {index.ntotal} items to DB. {time.time() - t0:>4.2f} sec.")
     # the reference extends dummy_db.mm on disk to get a reconstruction table; here the resident index is the table
 
@@ -116,8 +126,11 @@ def eval_faiss(emb_dir, emb_dummy_dir=None, index_type="ivfpq", nogpu=False, max
     live = item_len > 0
     pred = np.full((n_test * n_len, 10), -1, dtype=np.int64)
     if live.any():
-        ids, _ = ops.seq_rerank(index.rows(), q_dev, I_all, torch.from_numpy(item_row[live]).to(dev),
-                                torch.from_numpy(item_len[live]).to(dev), top=10)
+        if sharded:
+            ids, _ = index.rerank(q_dev, I_all, item_row[live], item_len[live], top=10)
+        else:
+            ids, _ = ops.seq_rerank(index.rows(), q_dev, I_all, torch.from_numpy(item_row[live]).to(dev),
+                                    torch.from_numpy(item_len[live]).to(dev), top=10)
         pred[live] = ids.cpu().numpy()
     print(f"Reranked {int(live.sum()):,} (test id, length) items in {time.time() - t0:>4.2f} sec.")
     pred = pred.reshape(n_test, n_len, 10)
@@ -130,6 +143,10 @@ def eval_faiss(emb_dir, emb_dummy_dir=None, index_type="ivfpq", nogpu=False, max
     flags[3] = (pred == gt[:, :, None]).any(axis=2)
 
     hit_rates = 100.0 * flags.mean(axis=1)
+    if sharded:
+        from . import dist as gdist
+        if gdist.rank_of() != 0:
+            return hit_rates
     result_dir = emb_dir + f"/{uuid.uuid4().hex[:8]}"
     os.makedirs(result_dir, exist_ok=True)
     np.save(f"{result_dir}/hit_rates.npy", hit_rates)

@@ -240,6 +240,14 @@ int grafp_seq_rerank_f32(const float *index_rows, int64_t n, const float *q_rows
                          const int64_t *topk_ids, int k, const int64_t *item_row, const int *item_len, int n_items,
                          int max_len, int top, int64_t *out_ids, float *out_scores, grafp_stream_t stream);
 
+/* Sharded form: index_rows holds global rows [row_base, row_base + n_rows) of an n-row index (a contiguous shard plus
+ * a halo of the next shard's first max_len - 1 rows); only candidates with start id in [id_lo, id_hi) are scored.
+ * The per-shard (out_ids, out_scores) lists are merged by (score descending, id ascending). */
+int grafp_seq_rerank_shard_f32(const float *index_rows, int64_t n_rows, int64_t row_base, int64_t n, int64_t id_lo,
+                               int64_t id_hi, const float *q_rows, int64_t n_qrows, const int64_t *topk_ids, int k,
+                               const int64_t *item_row, const int *item_len, int n_items, int max_len, int top,
+                               int64_t *out_ids, float *out_scores, grafp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -47,8 +47,22 @@ def main():
     index = gdist.ShardedFlatL2Index(128)
     index.add_global(db.numpy())
     D, I = index.search(q.numpy(), 10)
+    # sharded sequence rerank: planted 11-segment runs, one of them straddling the shard boundary (rows 2495..2505)
+    starts = torch.tensor([40, 2495, 3100, 4989])
+    qs = torch.cat([db[s0:s0 + 11] for s0 in starts.tolist()])
+    qs = torch.nn.functional.normalize(qs + 0.05 * torch.randn(qs.shape, generator=gen), dim=1)
+    _, Iq = index.search(qs.numpy(), 10)
+    item_row = torch.arange(4).repeat_interleave(3) * 11
+    item_len = torch.tensor([1, 5, 11] * 4, dtype=torch.int32)
+    rid, rsc = index.rerank(qs, torch.as_tensor(Iq), item_row, item_len, top=10)
+    rates = None
+    if len(sys.argv) > 3:                       # eval_faiss over the sharded index on the files of sys.argv[3]
+        from grafp_amd.eval import eval_faiss
+        rates = eval_faiss(sys.argv[3], index_type="l2", test_ids=os.path.join(sys.argv[3], "ids.npy"),
+                           test_seq_len="1 3 5 9", k_probe=20, sharded=True)
     torch.save({"loss_share": float(loss), "grads": grads, "grad_norm": total, "z_i": z_i.detach().cpu(),
-                "D": torch.as_tensor(D).cpu(), "I": torch.as_tensor(I).cpu()}, f"{out}.{rank}.pt")
+                "D": torch.as_tensor(D).cpu(), "I": torch.as_tensor(I).cpu(), "rid": rid.cpu(), "rsc": rsc.cpu(),
+                "rates": rates}, f"{out}.{rank}.pt")
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -15,13 +15,14 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _launch(world, out, B):
+def _launch(world, out, B, extra=()):
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT="29653", GRAFP_LOCAL_DEVICE="0", GRAFP_DIST_BACKEND="gloo",
                    HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_dist_gpu_worker.py"), out, str(B)], env=env,
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_dist_gpu_worker.py"), out, str(B), *extra],
+                                      env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     for p in procs:
         log, _ = p.communicate(timeout=600)
@@ -35,8 +36,19 @@ def test_two_ranks_match_one_process(tmp_path):
     from grafp_amd.util import load_config
     B = 8
     out = str(tmp_path / "w2")
-    _launch(2, out, B)
-    got = [torch.load(f"{out}.{r}.pt") for r in range(2)]
+    from _common import eval_case, golden, write_eval_case
+    case = eval_case()
+    evdir = tmp_path / "ev"
+    evdir.mkdir()
+    write_eval_case(str(evdir), case)
+    import numpy as np
+    np.save(evdir / "ids.npy", case["test_ids"])
+    _launch(2, out, B, extra=(str(evdir),))
+    got = [torch.load(f"{out}.{r}.pt", weights_only=False) for r in range(2)]
+    # eval_faiss over the two-rank sharded index == the table the reference's own eval_faiss produced
+    g = golden("eval_faiss.npz")
+    for r in range(2):
+        np.testing.assert_array_equal(got[r]["rates"], g["hit_rates"])
 
     device = torch.device("cuda:0")
     cfg = load_config()
@@ -77,6 +89,17 @@ def test_two_ranks_match_one_process(tmp_path):
     D, I = ops.search_l2(dbd, ops.row_sqnorm(dbd), q.to(device), 10)
     for r in range(2):
         assert torch.equal(got[r]["I"], I.cpu()) and torch.equal(got[r]["D"], D.cpu())
+    # sharded sequence rerank (rows + halo per rank, per-shard top lists merged by score) == unsharded rerank
+    starts = torch.tensor([40, 2495, 3100, 4989])
+    qs = torch.cat([db[s0:s0 + 11] for s0 in starts.tolist()])
+    qs = torch.nn.functional.normalize(qs + 0.05 * torch.randn(qs.shape, generator=gen), dim=1).to(device)
+    _, Iq = ops.search_l2(dbd, ops.row_sqnorm(dbd), qs, 10)
+    item_row = (torch.arange(4).repeat_interleave(3) * 11).to(device)
+    item_len = torch.tensor([1, 5, 11] * 4, dtype=torch.int32, device=device)
+    wid, wsc = ops.seq_rerank(dbd, qs, Iq, item_row, item_len, top=10)
+    for r in range(2):
+        assert torch.equal(got[r]["rid"], wid.cpu()) and torch.equal(got[r]["rsc"], wsc.cpu())
+    assert (wid[:, 0].cpu().reshape(4, 3) == starts[:, None]).all()          # planted runs found, across the boundary
 
 
 def test_bench_two_ranks_one_gpu(tmp_path):
