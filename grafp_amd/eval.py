@@ -62,12 +62,25 @@ def sequence_rerank(q, I, recon, sl):
 
 
 def eval_faiss(emb_dir, emb_dummy_dir=None, index_type="ivfpq", nogpu=False, max_train=1e7, test_ids="icassp",
-               test_seq_len="1 3 5 9 11 19", k_probe=20, n_centroids=64, sharded=False):
+               test_seq_len="1 3 5 9 11 19", k_probe=20, n_centroids=64):
     """Segment/sequence-level search experiment; returns hit rates (4, n_lengths) in percent:
-    rows = top1 exact, top1 near, top3 exact, top10 exact.  Side-effect files as in the reference.
-    sharded=True (an extension; every rank of the initialised process group calls it with the same arguments): the
-    index rows are split over the ranks (dist.ShardedFlatL2Index: local search + all-gather + merge, local rerank of
-    the owned candidates + merge); every rank returns the same table, rank 0 writes the files."""
+    rows = top1 exact, top1 near, top3 exact, top10 exact.  Side-effect files as in the reference
+    (same signature as eval.py:170-178)."""
+    return _eval_faiss(emb_dir, emb_dummy_dir, index_type, nogpu, max_train, test_ids, test_seq_len, k_probe,
+                       n_centroids, sharded=False)
+
+
+def eval_faiss_sharded(emb_dir, emb_dummy_dir=None, index_type="ivfpq", nogpu=False, max_train=1e7, test_ids="icassp",
+                       test_seq_len="1 3 5 9 11 19", k_probe=20, n_centroids=64):
+    """eval_faiss over an index whose rows are split across the ranks of the initialised process group (every rank
+    calls it with the same arguments): dist.ShardedFlatL2Index does the local search + all-gather + merge and the
+    local rerank of the owned candidates + merge.  Every rank returns the same table; rank 0 writes the files."""
+    return _eval_faiss(emb_dir, emb_dummy_dir, index_type, nogpu, max_train, test_ids, test_seq_len, k_probe,
+                       n_centroids, sharded=True)
+
+
+def _eval_faiss(emb_dir, emb_dummy_dir, index_type, nogpu, max_train, test_ids, test_seq_len, k_probe, n_centroids,
+                sharded):
     if isinstance(test_seq_len, str):
         test_seq_len = np.asarray(list(map(int, test_seq_len.split())))
     test_seq_len = np.asarray(test_seq_len)

@@ -57,9 +57,9 @@ def main():
     rid, rsc = index.rerank(qs, torch.as_tensor(Iq), item_row, item_len, top=10)
     rates = None
     if len(sys.argv) > 3:                       # eval_faiss over the sharded index on the files of sys.argv[3]
-        from grafp_amd.eval import eval_faiss
-        rates = eval_faiss(sys.argv[3], index_type="l2", test_ids=os.path.join(sys.argv[3], "ids.npy"),
-                           test_seq_len="1 3 5 9", k_probe=20, sharded=True)
+        from grafp_amd.eval import eval_faiss_sharded
+        rates = eval_faiss_sharded(sys.argv[3], index_type="l2", test_ids=os.path.join(sys.argv[3], "ids.npy"),
+                                   test_seq_len="1 3 5 9", k_probe=20)
     torch.save({"loss_share": float(loss), "grads": grads, "grad_norm": total, "z_i": z_i.detach().cpu(),
                 "D": torch.as_tensor(D).cpu(), "I": torch.as_tensor(I).cpu(), "rid": rid.cpu(), "rsc": rsc.cpu(),
                 "rates": rates}, f"{out}.{rank}.pt")
