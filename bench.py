@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-retrieval", action="store_true")
     ap.add_argument("--no-f32-probe", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="skip the HIP-graph replay of the step")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=25.0)
     return ap.parse_args()
 
@@ -288,6 +289,22 @@ def main():
             "roofline": roof,
             "kernels": kernels,
         }
+        if world == 1 and not args.no_graph:
+            # the same step replayed from ONE HIP graph (Trainer.step_graph): ~700 launches become one graph launch.
+            # Reported beside `value` (which stays the eager step, the path every N runs) rather than instead of it.
+            try:
+                trainer.step_graph(x_i, x_j)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    trainer.step_graph(x_i, x_j)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / args.steps
+                line["hip_graph"] = {"value": round(B / dt, 2), "unit": "clips/s", "ms_per_step": round(dt * 1e3, 3),
+                                     "steps": args.steps, "note": "whole step (augment, forward, loss, backward, Adam) "
+                                                                  "captured once, replayed per step; single process"}
+            except Exception as exc:      # noqa: BLE001 -- report, do not fail the bench line
+                line["hip_graph"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
         if world == 1 and args.dtype == "bf16" and not args.no_f32_probe:
             # the same step with f32 GEMMs: the mode that meets the 1e-3 embedding bar; the
             # bf16 headline above is the throughput mode

@@ -29,7 +29,10 @@ class Trainer:
         self.augment = GPUTransformNeuralfp(cfg, None, None, train=True)
         # train.py:174 (same Adam, defaults); on the GPU the update of all 271 parameter tensors is one fused launch
         # with device-side step counters instead of ~35 multi-tensor launches and 271 host-side counter bumps
-        self.opt = torch.optim.Adam(model.parameters(), lr=lr or cfg["lr"], fused=torch.device(device).type == "cuda")
+        on_gpu = torch.device(device).type == "cuda"
+        # capturable: the step counters live on the device, so the whole step can be recorded into a HIP graph
+        self.opt = torch.optim.Adam(model.parameters(), lr=lr or cfg["lr"], fused=on_gpu, capturable=on_gpu)
+        self._graph = None                     # (hipGraph, static x_i, static x_j, static loss) once captured
         self.sched = torch.optim.lr_scheduler.CosineAnnealingLR(self.opt, T_max=cfg["T_max"], eta_min=cfg["min_lr"])
         self.sync = gdist.GradSync(model.parameters(), group=group, n_buckets=n_buckets)
 
@@ -55,6 +58,35 @@ class Trainer:
         self.sync.finish()
         self.opt.step()
         return loss.detach()
+
+    def step_graph(self, x_i, x_j):
+        """Same step, replayed from a HIP graph (single process only: the collectives of the data-parallel path are
+        not captured).  The first call runs three eager steps on a side stream (allocator and library warm-up, as
+        torch.cuda.graphs asks), records the fourth and replays it; later calls copy the batch into the static input buffers and
+        replay ~700 launches as one graph launch.  Shapes must not change between calls."""
+        if self.world > 1:
+            raise RuntimeError("step_graph: single-process only (use step() under data parallelism)")
+        if self._graph is None:
+            sx_i, sx_j = x_i.clone(), x_j.clone()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    self.step(sx_i, sx_j)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                loss = self.step(sx_i, sx_j)
+            self._graph = (graph, sx_i, sx_j, loss)
+            graph.replay()                     # capture only records: this runs the step on the batch
+            return loss.clone()
+        graph, sx_i, sx_j, loss = self._graph
+        if sx_i.shape != x_i.shape or sx_j.shape != x_j.shape:
+            raise ValueError("step_graph: batch shape changed since capture")
+        sx_i.copy_(x_i)
+        sx_j.copy_(x_j)
+        graph.replay()
+        return loss.clone()
 
     def checkpoint(self, epoch, loss_log, hit_rate_log, hit_rates=None):
         """The dict layout of train.py:212-220."""

@@ -612,3 +612,31 @@ def test_stride2_taps_vs_pad_slice_cat(dev, shape, dtype):
     got.backward(g.to(dtype))
     tol = 0.0 if dtype == torch.float32 else 1e-2
     assert torch.allclose(xg.grad.float(), xr.grad, rtol=tol, atol=tol)
+
+
+def test_c_abi_entries_are_graph_capturable(dev):
+    """The C entries only enqueue kernels on the stream they are given (no allocation, no synchronisation): a search
+    and a k-NN graph build captured into a HIP graph replay correctly on new input contents."""
+    from grafp_amd import ops
+    db, q, _ = _planted(20000, 41, "graph")
+    dbt, qt = t(db).to(dev), t(q).to(dev)
+    sq, dbh = ops.row_sqnorm(dbt), ops.rows_to_bf16(dbt)
+    x = t(hash_normalish("gpu:graph.knn", (4, 64, 256))).to(dev)
+    want_d, want_i = ops.search_l2(dbt, sq, qt, 20, db_bf16=dbh)
+    want_g = ops.knn_graph(x, 3)
+    q_static, x_static = torch.zeros_like(qt), torch.zeros_like(x)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                       # warm-up on the capture stream (allocator, module loading)
+        ops.search_l2(dbt, sq, q_static, 20, db_bf16=dbh)
+        ops.knn_graph(x_static, 3)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out_d, out_i = ops.search_l2(dbt, sq, q_static, 20, db_bf16=dbh)
+        out_g = ops.knn_graph(x_static, 3)
+    q_static.copy_(qt)
+    x_static.copy_(x)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out_i, want_i) and torch.equal(out_d, want_d) and torch.equal(out_g, want_g)

@@ -306,3 +306,51 @@ def test_db_writers(dev, tmp_path):
     with torch.no_grad():        # the train-mode pass above advanced the running statistics: fresh eval reference
         want_e = torch.cat([model.embed(aug(t.to(dev), None)[0])[1] for t in tracks]).cpu().numpy()
     assert (np.linalg.norm(packed - want_e, axis=1) / np.linalg.norm(want_e, axis=1)).max() <= 5e-3
+
+
+def test_trainer_step_graph_equals_eager(dev):
+    """Trainer.step_graph (whole step replayed from one HIP graph): from the SAME weights and optimizer state, a
+    replayed step returns the loss an eager forward pass computes on the new batch and leaves the parameters where
+    an eager step leaves them."""
+    from grafp_amd.simclr.ntxent import ntxent_loss
+    from grafp_amd.train import Trainer, build_model, synthetic_batch
+    from grafp_amd.util import load_config
+    cfg = load_config()
+    cfg["bsz_train"] = 16
+    torch.manual_seed(7)
+    model = build_model(cfg, device=dev)
+    tr = Trainer(cfg, model, dev, amp_dtype=None)
+    tr.step_graph(*synthetic_batch(16, 50, dev))                  # 3 eager warm-up steps, capture, first replay
+
+    def snapshot():
+        return ([p.detach().clone() for p in model.parameters()], [b.detach().clone() for b in model.buffers()],
+                [{k: v.detach().clone() for k, v in st.items() if torch.is_tensor(v)} for st in tr.opt.state.values()])
+
+    def restore(snap):                                            # in place: the graph holds these addresses
+        with torch.no_grad():
+            for p, v in zip(model.parameters(), snap[0]):
+                p.copy_(v)
+            for b, v in zip(model.buffers(), snap[1]):
+                b.copy_(v)
+            for st, sv in zip(tr.opt.state.values(), snap[2]):
+                for k, v in sv.items():
+                    st[k].copy_(v)
+
+    for seed in (51, 52):
+        xi, xj = synthetic_batch(16, seed, dev)
+        snap = snapshot()
+        with torch.no_grad():                                     # eager forward loss at these weights
+            X_i, X_j = tr.augment(xi, xj)
+            _, _, z_i, z_j = model(X_i, X_j)
+            want_loss = float(ntxent_loss(z_i, z_j, cfg))
+        restore(snap)                                             # (the forward advanced the running statistics)
+        loss_e = float(tr.step(xi, xj))
+        p_e = torch.cat([p.detach().flatten() for p in model.parameters()]).clone()
+        restore(snap)
+        loss_g = float(tr.step_graph(xi, xj))
+        p_g = torch.cat([p.detach().flatten() for p in model.parameters()]).clone()
+        p_0 = torch.cat([v.flatten() for v in snap[0]])
+        assert abs(loss_e - want_loss) <= 1e-5 * max(1.0, abs(want_loss))
+        assert abs(loss_g - want_loss) <= 1e-5 * max(1.0, abs(want_loss))
+        d_e, d_g = p_e - p_0, p_g - p_0
+        assert float(d_e.norm()) > 0 and float((d_g - d_e).norm() / d_e.norm()) < 0.05     # atomics: not bit-equal
