@@ -1036,7 +1036,9 @@ extern "C" int grafp_knn_search_l2_pre(const float *db, const void *db_bf16, con
         return GRAFP_ERR_WORKSPACE;
     }
     hipStream_t s = (hipStream_t)stream;
-    const int qw = nq <= 32 ? 1 : 4, rw = 4 / qw;     // (the 2x2 shape measured 3.5x slower than 4x1 at nq = 41)
+    // measured crossovers (1M x 128): the 1x4 shape only pays for a handful of queries (nq=16: 136 vs 127 us, nq=32:
+    // 168 vs 143 us for the 2x2 shape)
+    const int qw = nq <= 8 ? 1 : (nq <= 64 ? 2 : 4), rw = 4 / qw;
     const int qgroups = (nq + 32 * qw - 1) / (32 * qw);
     int splits, b_splits;
     int64_t rps, b_rps;
