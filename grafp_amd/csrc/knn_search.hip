@@ -35,6 +35,10 @@ constexpr int SR_LS = 129;       // LDS row stride of the database tile (ds_read
 constexpr int SR_EMPTY = 0x7fffffff;
 constexpr int SR_GROUPS = 64;    // disjoint sample groups per query in the pre-pass
 constexpr int SR_CAP = 4096;     // candidate slots per query (typical fill: a few hundred)
+constexpr int SR_NSUB = 16;      // pre-filter path: the slots are SR_NSUB sub-lists with their own counters, picked by the
+                                 // row slice of the appending workgroup -- hundreds of increments on ONE counter serialise
+                                 // in L2 (a small batch spent 40 us of a 90 us scan there)
+constexpr int SR_SUBCAP = SR_CAP / SR_NSUB;
 
 // Order LDS traffic between the lanes of ONE wave: wait for this wave's LDS operations only (lgkmcnt) -- a full
 // fence would also drain vmcnt, i.e. stall on the database prefetch that is deliberately left in flight.
@@ -251,8 +255,8 @@ __global__ __launch_bounds__(256) void search_init_kernel(const float *__restric
                                                           int *__restrict__ gmin, int *__restrict__ cnt) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < (int64_t)nq * SR_GROUPS) gmin[i] = 0x7f800000;  // +inf
+    if (i < (int64_t)nq * SR_NSUB) cnt[i] = 0;          // (the f32 path only uses the first nq)
     if (i < nq) {
-        cnt[i] = 0;
         const float *row = q + i * SR_D;
         float s = 0.0f;
         for (int c = 0; c < SR_D; ++c) s = __builtin_fmaf(row[c], row[c], s);   // same chain as row_sqnorm_kernel
@@ -623,11 +627,12 @@ __global__ __launch_bounds__(256, 3) void search_scan_bf16_kernel(const unsigned
     // keep iff d~ - SLACK (qq + dd) <= bound  <=>  <q^,x^> >= A_q + H_row
     const float kminus = 1.0f - SB_SLACK;
     const float a_q = qvalid ? 0.5f * (qq[qi] * kminus - thr[qi]) : INFINITY;
-    auto append = [&](int qg, int row, float ip) {            // to the global per-query list
-        const int pos = atomicAdd(&cnt[qg], 1);
-        if (pos < SR_CAP) {                                   // beyond: cnt > SR_CAP -> exact rescan
-            cand_i[(size_t)qg * SR_CAP + pos] = row;
-            cand_ip[(size_t)qg * SR_CAP + pos] = ip;          // <q^,x^>: lets the select kernel bound d from both sides
+    const int sub = blockIdx.x & (SR_NSUB - 1);
+    auto append = [&](int qg, int row, float ip) {            // to sub-list `sub` of the query's candidate list
+        const int pos = atomicAdd(&cnt[qg * SR_NSUB + sub], 1);
+        if (pos < SR_SUBCAP) {                                // beyond: the select kernel sees the count and rescans
+            cand_i[(size_t)qg * SR_CAP + sub * SR_SUBCAP + pos] = row;
+            cand_ip[(size_t)qg * SR_CAP + sub * SR_SUBCAP + pos] = ip;   // <q^,x^>: bounds d from both sides later
         }
     };
     auto drain = [&]() {                                      // all threads; callers provide the barriers around it
@@ -725,10 +730,28 @@ __global__ __launch_bounds__(256) void search_select_exact_kernel(const float *_
     __shared__ float s_thr2;
     const int qi = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     if (tid < SR_D) sq[tid] = q[(size_t)qi * SR_D + tid];
+    __shared__ int s_off[SR_NSUB + 1];
     const float myqq = qq[qi];
-    const int c = cnt[qi];
-    const bool listed = c <= SR_CAP;                       // else: exact rescan of every row (pathological ties)
+    if (tid == 0) {                                        // sub-list fills -> offsets of a flat candidate index
+        int acc_n = 0, over = 0;
+        for (int s2 = 0; s2 < SR_NSUB; ++s2) {
+            const int cs = cnt[qi * SR_NSUB + s2];
+            over |= cs > SR_SUBCAP;
+            s_off[s2] = acc_n;
+            acc_n += cs < SR_SUBCAP ? cs : SR_SUBCAP;
+        }
+        s_off[SR_NSUB] = over ? -1 : acc_n;
+    }
+    __syncthreads();
+    const int c = s_off[SR_NSUB];
+    const bool listed = c >= 0;                            // else: a sub-list overflowed -> exact rescan of every row
     const int64_t total = listed ? (int64_t)c : n;
+    auto slot_of = [&](int e) {                            // flat candidate index -> slot in the query's list
+        int s2 = 0;
+#pragma unroll
+        for (int b2 = SR_NSUB / 2; b2 > 0; b2 >>= 1) s2 += (e >= s_off[s2 + b2]) ? b2 : 0;
+        return s2 * SR_SUBCAP + (e - s_off[s2]);
+    };
     float thr2 = thr[qi];
     WaveTop top;
     float td;
@@ -741,9 +764,10 @@ __global__ __launch_bounds__(256) void search_select_exact_kernel(const float *_
             float hi = INFINITY;
             int row = 0;
             if (valid) {
-                row = cand_i[(size_t)qi * SR_CAP + e];
+                const int sl = slot_of(e);
+                row = cand_i[(size_t)qi * SR_CAP + sl];
                 const float t = myqq + dd[row];
-                hi = __builtin_fmaf(-2.0f, cand_ip[(size_t)qi * SR_CAP + e], t * (1.0f + SB_SLACK));
+                hi = __builtin_fmaf(-2.0f, cand_ip[(size_t)qi * SR_CAP + sl], t * (1.0f + SB_SLACK));
                 hi = hi < 0.0f ? 0.0f : hi;
             }
             top.push(valid, hi, row, k, lane);
@@ -764,8 +788,9 @@ __global__ __launch_bounds__(256) void search_select_exact_kernel(const float *_
         int64_t row = 0;
         if (need) {
             if (listed) {
-                row = cand_i[(size_t)qi * SR_CAP + e];
-                const float lo = __builtin_fmaf(-2.0f, cand_ip[(size_t)qi * SR_CAP + e], (myqq + dd[row]) * kminus);
+                const int sl = slot_of((int)e);
+                row = cand_i[(size_t)qi * SR_CAP + sl];
+                const float lo = __builtin_fmaf(-2.0f, cand_ip[(size_t)qi * SR_CAP + sl], (myqq + dd[row]) * kminus);
                 need = lo <= thr2;
             } else {
                 row = e;
@@ -947,7 +972,7 @@ extern "C" int grafp_row_sqnorm_f32(const float *m, int64_t n, int d, float *out
 extern "C" size_t grafp_knn_search_workspace(int64_t n, int nq, int d, int k) {
     using namespace grafp;
     if (n <= 0 || nq <= 0 || d != SR_D || k < 1) return 0;
-    return align256((size_t)nq * sizeof(float)) * 2 + align256((size_t)nq * sizeof(int)) +
+    return align256((size_t)nq * sizeof(float)) * 2 + align256((size_t)nq * SR_NSUB * sizeof(int)) +
            align256((size_t)nq * SR_GROUPS * sizeof(int)) + align256((size_t)nq * SR_CAP * sizeof(float)) +
            align256((size_t)nq * SR_CAP * sizeof(int));
 }
@@ -971,7 +996,7 @@ extern "C" int grafp_knn_search_l2_f32(const float *db, const float *db_sqnorm, 
     char *w = (char *)ws;
     float *qq = (float *)w;                 w += align256((size_t)nq * sizeof(float));
     float *thr = (float *)w;                w += align256((size_t)nq * sizeof(float));
-    int *cnt = (int *)w;                    w += align256((size_t)nq * sizeof(int));
+    int *cnt = (int *)w;                    w += align256((size_t)nq * SR_NSUB * sizeof(int));
     int *gmin = (int *)w;                   w += align256((size_t)nq * SR_GROUPS * sizeof(int));
     float *cand_d = (float *)w;             w += align256((size_t)nq * SR_CAP * sizeof(float));
     int *cand_i = (int *)w;
@@ -1015,7 +1040,7 @@ extern "C" int grafp_f32_to_bf16(const float *src, int64_t n_elems, void *dst, g
 extern "C" size_t grafp_knn_search_pre_workspace(int64_t n, int nq, int d, int k) {
     using namespace grafp;
     if (n <= 0 || nq <= 0 || d != SR_D || k < 1) return 0;
-    return align256((size_t)nq * sizeof(float)) * 2 + align256((size_t)nq * sizeof(int)) +
+    return align256((size_t)nq * sizeof(float)) * 2 + align256((size_t)nq * SR_NSUB * sizeof(int)) +
            align256((size_t)nq * SR_GROUPS * sizeof(int)) + align256((size_t)nq * SR_CAP * sizeof(int)) +
            align256((size_t)nq * SR_CAP * sizeof(float));
 }
@@ -1053,7 +1078,7 @@ extern "C" int grafp_knn_search_l2_pre(const float *db, const void *db_bf16, con
     char *w = (char *)ws;
     float *qq = (float *)w;                 w += align256((size_t)nq * sizeof(float));
     float *thr = (float *)w;                w += align256((size_t)nq * sizeof(float));
-    int *cnt = (int *)w;                    w += align256((size_t)nq * sizeof(int));
+    int *cnt = (int *)w;                    w += align256((size_t)nq * SR_NSUB * sizeof(int));
     int *gmin = (int *)w;                   w += align256((size_t)nq * SR_GROUPS * sizeof(int));
     int *cand_i = (int *)w;                 w += align256((size_t)nq * SR_CAP * sizeof(int));
     float *cand_ip = (float *)w;
