@@ -122,6 +122,82 @@ __global__ __launch_bounds__(MR_THREADS) void mrconv_fwd_kernel(const T *__restr
     }
 }
 
+// Persistent 4-wide variant (N % 4 == 0, 4-element aligned strides/pointers -- every shape of the encoder): a
+// workgroup stages the clip's edges ONCE and then walks several channel slabs of the clip, with the rows of the next
+// slab already in flight (registers) while the current one is gathered out of LDS.  The one-slab-per-workgroup
+// kernel above re-staged the 12 N bytes of edges for every 4 channel rows and exposed every load to latency.
+constexpr int MRP_ITEMS = 4;                      // 4-element pieces per thread per slab: slab = 4096 elements
+constexpr int MRP_SLAB = MRP_ITEMS * MR_THREADS * 4;
+
+template <typename T, typename I>
+__global__ __launch_bounds__(MR_THREADS) void mrconv_fwd_p_kernel(const T *__restrict__ x, int64_t x_sb, int64_t x_sc,
+                                                                  const I *__restrict__ idx, T *__restrict__ out,
+                                                                  int64_t o_sb, int64_t o_sc, int C, int N, int K,
+                                                                  int CC) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    float *rows = reinterpret_cast<float *>(smem);                 // [CC*N] (<= MRP_SLAB floats)
+    int *sidx = reinterpret_cast<int *>(rows + MRP_SLAB);          // [K][N]
+    const int nslab = (C + CC - 1) / CC;
+    const T *xb = x + (size_t)b * x_sb;
+    T *ob = out + (size_t)b * o_sb;
+    // this thread's pieces inside a slab: (channel offset, node) of piece it
+    int pc[MRP_ITEMS], pn[MRP_ITEMS];
+    {
+        MR_WALK(4, tid, N, c, n);
+#pragma unroll
+        for (int it = 0; it < MRP_ITEMS; ++it) {
+            pc[it] = c;
+            pn[it] = n;
+            MR_NEXT(4, N, c, n);
+        }
+    }
+    float pv[MRP_ITEMS][4];
+    auto fetch = [&](int slab) {
+        const int c0 = slab * CC, cc = min(CC, C - c0);
+#pragma unroll
+        for (int it = 0; it < MRP_ITEMS; ++it)
+            if (pc[it] < cc) mr_ld4(xb + (size_t)(c0 + pc[it]) * x_sc + pn[it], pv[it]);
+    };
+    int slab = blockIdx.x;
+    if (slab < nslab) fetch(slab);
+    stage_idx<I>(sidx, idx + (size_t)b * N * K, N, K, tid);
+    for (; slab < nslab; slab += gridDim.x) {
+        const int c0 = slab * CC, cc = min(CC, C - c0);
+        __syncthreads();                       // previous slab fully consumed (and sidx staged, first time round)
+#pragma unroll
+        for (int it = 0; it < MRP_ITEMS; ++it)
+            if (pc[it] < cc) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rows[pc[it] * N + pn[it] + e] = pv[it][e];
+            }
+        __syncthreads();
+        float xi[MRP_ITEMS][4];
+#pragma unroll
+        for (int it = 0; it < MRP_ITEMS; ++it)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xi[it][e] = pv[it][e];
+        if (slab + gridDim.x < nslab) fetch(slab + gridDim.x);      // next slab in flight during the gather
+#pragma unroll
+        for (int it = 0; it < MRP_ITEMS; ++it) {
+            if (pc[it] < cc) {
+                const float *row = rows + pc[it] * N;
+                float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                for (int k = 0; k < K; ++k) {
+                    const int4 j4 = *reinterpret_cast<const int4 *>(sidx + k * N + pn[it]);
+                    m[0] = fmaxf(m[0], row[j4.x] - xi[it][0]);
+                    m[1] = fmaxf(m[1], row[j4.y] - xi[it][1]);
+                    m[2] = fmaxf(m[2], row[j4.z] - xi[it][2]);
+                    m[3] = fmaxf(m[3], row[j4.w] - xi[it][3]);
+                }
+                T *o = ob + (size_t)(2 * (c0 + pc[it])) * o_sc + pn[it];
+                mr_st4(o, xi[it]);
+                mr_st4(o + o_sc, m);
+            }
+        }
+    }
+}
+
 // BWD_ITEMS * 256 * V elements per workgroup: the odd-channel gradients stay in registers between the
 // accumulator initialisation and the scatter phase.
 // Measured: small slabs (ITEMS = 2: 2048 elements, ~36 KB of LDS, 4 workgroups per CU) beat 8192-element ones by
@@ -205,6 +281,100 @@ __global__ __launch_bounds__(MR_THREADS) void mrconv_bwd_kernel(const T *__restr
     }
 }
 
+// Persistent 4-wide backward (same conditions as mrconv_fwd_p_kernel): edges staged once per workgroup, slabs of
+// 2048 elements (2 pieces per thread), the next slab's x / g_even / g_odd in flight while the current one scatters.
+constexpr int MRB_ITEMS = 2;
+constexpr int MRB_SLAB = MRB_ITEMS * MR_THREADS * 4;
+
+template <typename T, typename I>
+__global__ __launch_bounds__(MR_THREADS) void mrconv_bwd_p_kernel(const T *__restrict__ x, int64_t x_sb, int64_t x_sc,
+                                                                  const I *__restrict__ idx,
+                                                                  const T *__restrict__ gout, int64_t g_sb,
+                                                                  int64_t g_sc, T *__restrict__ dx, int C, int N, int K,
+                                                                  int CC) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    float *rows = reinterpret_cast<float *>(smem);                 // [CC*N] x
+    float *acc = rows + MRB_SLAB;                                  // [CC*N] gradient accumulator
+    int *sidx = reinterpret_cast<int *>(acc + MRB_SLAB);           // [K][N]
+    const int nslab = (C + CC - 1) / CC;
+    const T *xb = x + (size_t)b * x_sb;
+    const T *gb = gout + (size_t)b * g_sb;
+    T *db = dx + (size_t)b * x_sb;
+    int pc[MRB_ITEMS], pn[MRB_ITEMS];
+    {
+        MR_WALK(4, tid, N, c, n);
+#pragma unroll
+        for (int it = 0; it < MRB_ITEMS; ++it) {
+            pc[it] = c;
+            pn[it] = n;
+            MR_NEXT(4, N, c, n);
+        }
+    }
+    float pv[MRB_ITEMS][4], pe[MRB_ITEMS][4], po[MRB_ITEMS][4];     // x, g_even, g_odd of the slab in flight
+    auto fetch = [&](int slab) {
+        const int c0 = slab * CC, cc = min(CC, C - c0);
+#pragma unroll
+        for (int it = 0; it < MRB_ITEMS; ++it)
+            if (pc[it] < cc) {
+                const int c = c0 + pc[it];
+                mr_ld4(xb + (size_t)c * x_sc + pn[it], pv[it]);
+                mr_ld4(gb + (size_t)(2 * c) * g_sc + pn[it], pe[it]);
+                mr_ld4(gb + (size_t)(2 * c + 1) * g_sc + pn[it], po[it]);
+            }
+    };
+    int slab = blockIdx.x;
+    if (slab < nslab) fetch(slab);
+    stage_idx<I>(sidx, idx + (size_t)b * N * K, N, K, tid);
+    for (; slab < nslab; slab += gridDim.x) {
+        const int c0 = slab * CC, cc = min(CC, C - c0);
+        __syncthreads();                       // previous slab written out (and sidx staged, first time round)
+        float xi[MRB_ITEMS][4], godd[MRB_ITEMS][4];
+#pragma unroll
+        for (int it = 0; it < MRB_ITEMS; ++it)
+            if (pc[it] < cc) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    rows[pc[it] * N + pn[it] + e] = pv[it][e];
+                    acc[pc[it] * N + pn[it] + e] = pe[it][e] - po[it][e];   // identity branch minus the centre terms
+                    xi[it][e] = pv[it][e];
+                    godd[it][e] = po[it][e];
+                }
+            }
+        __syncthreads();
+        if (slab + gridDim.x < nslab) fetch(slab + gridDim.x);
+        // route g_odd[c][m] to the arg-max neighbour of m (first maximum)
+#pragma unroll
+        for (int it = 0; it < MRB_ITEMS; ++it) {
+            if (pc[it] < cc) {
+                const float *row = rows + pc[it] * N;
+                float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                int bj[4];
+                for (int k = 0; k < K; ++k) {
+                    const int4 j4 = *reinterpret_cast<const int4 *>(sidx + k * N + pn[it]);
+                    const int jj[4] = {j4.x, j4.y, j4.z, j4.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = row[jj[e]] - xi[it][e];
+                        if (k == 0 || v > best[e]) { best[e] = v; bj[e] = jj[e]; }
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) atomicAdd(&acc[pc[it] * N + bj[e]], godd[it][e]);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < MRB_ITEMS; ++it)
+            if (pc[it] < cc) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[pc[it] * N + pn[it] + e];
+                mr_st4(db + (size_t)(c0 + pc[it]) * x_sc + pn[it], v);
+            }
+    }
+}
+
 static int pick_cc(int C, int N, int target_elems) {
     int cc = target_elems / N;
     if (cc < 1) cc = 1;
@@ -230,6 +400,27 @@ static int mrconv_fwd_impl(const void *x, int dtype, int64_t x_sb, int64_t x_sc,
     const size_t es = dtype == GRAFP_F32 ? 4 : 2;
     const bool v4 = (N % 4 == 0) && (x_sb % 4 == 0) && (x_sc % 4 == 0) && (o_sb % 4 == 0) && (o_sc % 4 == 0) &&
                     ((uintptr_t)x % (4 * es) == 0) && ((uintptr_t)out % (4 * es) == 0);
+    if (v4 && N <= MRP_SLAB) {
+        // persistent variant: whole channel rows per slab, a few slabs per workgroup
+        const int ccp = MRP_SLAB / N < C ? MRP_SLAB / N : C;
+        const int nslab = (C + ccp - 1) / ccp;
+        int per_clip = nslab < 4 ? nslab : 4;                       // workgroups per clip
+        while ((int64_t)per_clip * B < 1024 && per_clip < nslab) ++per_clip;
+        const size_t ldsp = ((size_t)MRP_SLAB + (size_t)K * N) * 4;
+        if (ldsp <= 160 * 1024) {
+            const dim3 gridp(per_clip, B);
+#define MR_FWDP(T, I)                                                                                                  \
+    (void)hipFuncSetAttribute((const void *)mrconv_fwd_p_kernel<T, I>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                              (int)ldsp);                                                                              \
+    hipLaunchKernelGGL((mrconv_fwd_p_kernel<T, I>), gridp, dim3(MR_THREADS), ldsp, (hipStream_t)stream, (const T *)x,  \
+                       x_sb, x_sc, (const I *)idx, (T *)out, o_sb, o_sc, C, N, K, ccp)
+            if (dtype == GRAFP_F32) { if (idx32) { MR_FWDP(float, int32_t); } else { MR_FWDP(float, int64_t); } }
+            else { if (idx32) { MR_FWDP(unsigned short, int32_t); } else { MR_FWDP(unsigned short, int64_t); } }
+#undef MR_FWDP
+            GRAFP_CHECK_LAUNCH("mrconv_fwd_p_kernel");
+            return GRAFP_OK;
+        }
+    }
 #define MR_FWD_I(T, V, I)                                                                                              \
     (void)hipFuncSetAttribute((const void *)mrconv_fwd_kernel<T, V, I>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
                               (int)lds);                                                                               \
@@ -255,6 +446,26 @@ static int mrconv_bwd_impl(const void *x, int dtype, int64_t x_sb, int64_t x_sc,
     const size_t es = dtype == GRAFP_F32 ? 4 : 2;
     const bool v4 = (N % 4 == 0) && (x_sb % 4 == 0) && (x_sc % 4 == 0) && (g_sb % 4 == 0) && (g_sc % 4 == 0) &&
                     ((uintptr_t)x % (4 * es) == 0) && ((uintptr_t)grad_out % (4 * es) == 0) && ((uintptr_t)dx % (4 * es) == 0);
+    if (v4 && N <= MRB_SLAB) {
+        const int ccp = MRB_SLAB / N < C ? MRB_SLAB / N : C;
+        const int nslab = (C + ccp - 1) / ccp;
+        int per_clip = nslab < 4 ? nslab : 4;
+        while ((int64_t)per_clip * B < 1024 && per_clip < nslab) ++per_clip;
+        const size_t ldsp = ((size_t)2 * MRB_SLAB + (size_t)K * N) * 4;
+        if (ldsp <= 160 * 1024) {
+            const dim3 gridp(per_clip, B);
+#define MR_BWDP(T, I)                                                                                                  \
+    (void)hipFuncSetAttribute((const void *)mrconv_bwd_p_kernel<T, I>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                              (int)ldsp);                                                                              \
+    hipLaunchKernelGGL((mrconv_bwd_p_kernel<T, I>), gridp, dim3(MR_THREADS), ldsp, (hipStream_t)stream, (const T *)x,  \
+                       x_sb, x_sc, (const I *)idx, (const T *)grad_out, g_sb, g_sc, (T *)dx, C, N, K, ccp)
+            if (dtype == GRAFP_F32) { if (idx32) { MR_BWDP(float, int32_t); } else { MR_BWDP(float, int64_t); } }
+            else { if (idx32) { MR_BWDP(unsigned short, int32_t); } else { MR_BWDP(unsigned short, int64_t); } }
+#undef MR_BWDP
+            GRAFP_CHECK_LAUNCH("mrconv_bwd_p_kernel");
+            return GRAFP_OK;
+        }
+    }
     // a workgroup covers exactly ITEMS * 256 * V elements (whole channel rows)
     const int per_item = MR_THREADS * (v4 ? 4 : 1);
     const int items = N <= 2 * per_item ? 2 : 8;
