@@ -29,6 +29,8 @@ template <> struct BnIO<float> {
     __device__ static void store(float *p, const float (&v)[4]) {
         *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
     }
+    using Raw = float4;
+    __device__ static void unpack(const float4 &t, float (&v)[4]) { v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
     __device__ static float ld1(const float *p) { return *p; }
     __device__ static void st1(float *p, float v) { *p = v; }
 };
@@ -55,10 +57,20 @@ template <> struct BnIO<unsigned short> {
         for (int i = 0; i < 4; ++i) w[i] = (unsigned)f2bf(v[2 * i]) | ((unsigned)f2bf(v[2 * i + 1]) << 16);
         *reinterpret_cast<uint4 *>(p) = make_uint4(w[0], w[1], w[2], w[3]);
     }
+    using Raw = uint4;
+    __device__ static void unpack(const uint4 &t, float (&v)[8]) {
+        const unsigned w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[2 * i] = __uint_as_float(w[i] << 16);
+            v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+        }
+    }
     __device__ static float ld1(const unsigned short *p) { return __uint_as_float(((unsigned)*p) << 16); }
     __device__ static void st1(unsigned short *p, float v) { *p = f2bf(v); }
 };
 
+template <int THREADS = 256>
 __device__ __forceinline__ float2 block_sum2(float a, float b, float2 *scratch, int tid) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -69,7 +81,7 @@ __device__ __forceinline__ float2 block_sum2(float a, float b, float2 *scratch, 
     if ((tid & 63) == 0) scratch[tid >> 6] = make_float2(a, b);
     __syncthreads();
     float2 r = scratch[0];
-    for (int w = 1; w < BN_THREADS / 64; ++w) {
+    for (int w = 1; w < THREADS / 64; ++w) {
         r.x += scratch[w].x;
         r.y += scratch[w].y;
     }
@@ -326,6 +338,271 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_dx_kernel(const T *__restri
     }
 }
 
+// ---- single-pass variants: the chunk stays in registers across a row-wide rendezvous --------------------------
+// The two-kernel forms above read X twice (forward) or X and dZ twice (backward).  Here a workgroup keeps its chunk
+// (eight 16-byte vectors per thread, bf16 left packed) in VGPRs, publishes its partial sums, waits until all S workgroups of ITS ROW have
+// published (the S workgroups of a row have consecutive block ids and are dispatched together -- the
+// forward-progress assumption of a decoupled look-back scan), reduces the partials in the fixed order the two-kernel
+// form uses, and finishes from registers: forward 3 -> 2 passes over HBM, backward 5 -> 3.
+// `sync` = one counter line per row followed by S 8-byte slots per row, ALL ONES on entry and again on exit.
+// Cross-XCD visibility: slots and counters move with agent-scope relaxed atomics, i.e. sc1 write-through stores and
+// L2-bypassing loads (the per-XCD L2s are not coherent for plain accesses); no L2 writeback/invalidate.  The wait
+// is bounded: a lost rendezvous traps instead of hanging the device.
+constexpr int BN1_ITEMS = 8;                           // 16-byte vectors per thread, kept RAW (bf16 stays packed): 32 VGPRs
+constexpr int BN1_THREADS = 256;
+constexpr int BN1_MIN_CHUNK = BN1_THREADS * BN1_ITEMS * 4;   // elements per workgroup: 8192 f32 / 16384 bf16
+constexpr int BN1_MAX_S = 256;                         // workgroups per row
+constexpr int BN1_SYNC_STRIDE = 64;                    // ints between row counters: one 256-byte line each, so the
+                                                       // polls and arrivals of different rows never share a channel queue
+
+constexpr unsigned BN1_EMPTY = 0xffffffffu;            // "not published yet" (a NaN pattern real sums are steered away from)
+
+// Publishes this workgroup's partial pair into slot s of its row and waits until every slot of the row is filled.
+// No read-modify-write sits on the critical path: a slot is ONE 8-byte write-through store, the wait is wave 0 polling
+// the row's S slots with L2-bypassing loads (the successful poll already holds the data).  Returns with sp[0..S) set.
+__device__ __forceinline__ void bn1_publish_and_wait(float a, float b, unsigned long long *slots_row, int s, int S,
+                                                     float2 *sp, int tid) {
+    if (tid == 0) {
+        unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+        if (ua == BN1_EMPTY) ua = 0xfffffffeu;          // still a NaN, but not the marker
+        __hip_atomic_store(slots_row + s, (unsigned long long)ua | ((unsigned long long)ub << 32), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid < 64) {
+        int spins = 0;
+        for (;;) {
+            bool ok = true;
+            for (int i = tid; i < S; i += 64) {
+                const unsigned long long v = __hip_atomic_load(slots_row + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned)v == BN1_EMPTY) ok = false;
+                else sp[i] = make_float2(__uint_as_float((unsigned)v), __uint_as_float((unsigned)(v >> 32)));
+            }
+            if (__all(ok)) break;
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1 << 22)) __builtin_trap();
+        }
+    }
+    __syncthreads();
+}
+
+// After a workgroup has its copy of the partials it checks out of the row (fire and forget: the returned count is
+// only looked at when the workgroup is done); the last one out empties the slots and re-arms the counter, so the
+// whole `sync` buffer is all-ones again when the kernel ends.
+__device__ __forceinline__ int bn1_checkout(int *counter) {
+    return __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void bn1_rearm(int old, int S, int *counter, unsigned long long *slots_row) {
+    if (old == S - 2) {                                  // counter starts at -1: the S-th checkout sees S - 2
+        for (int i = 0; i < S; ++i)
+            __hip_atomic_store(slots_row + i, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(counter, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(BN1_THREADS) void bn_fwd1_kernel(const T *__restrict__ x, int64_t M, int64_t Mg, int Sg,
+                                                             int G, const float *__restrict__ pre_bias,
+                                                             const float *__restrict__ gamma,
+                                                             const float *__restrict__ beta,
+                                                             const T *__restrict__ residual, int act, float slope,
+                                                             float eps, float momentum,
+                                                             float *__restrict__ running_mean,
+                                                             float *__restrict__ running_var,
+                                                             int *__restrict__ sync, T *__restrict__ out,
+                                                             float *__restrict__ save_mean,
+                                                             float *__restrict__ save_invstd) {
+    constexpr int W = BnIO<T>::W, ITEMS = BN1_ITEMS, CHUNK = BN1_THREADS * ITEMS * W;
+    __shared__ float2 scratch[BN1_THREADS / 64];
+    __shared__ float2 sp[BN1_MAX_S];
+    const int c = blockIdx.y, s = blockIdx.x, tid = threadIdx.x;
+    const int S = gridDim.x, grp = s / Sg, sl = s - grp * Sg;
+    const T *row = x + (size_t)c * M;
+    const float pb = pre_bias ? pre_bias[c] : 0.0f;
+    const float shift = BnIO<T>::ld1(row + (int64_t)grp * Mg) + pb;
+    const int64_t gend = (int64_t)(grp + 1) * Mg;
+    const int64_t lo = (int64_t)grp * Mg + (int64_t)sl * CHUNK;
+    const int64_t hi = (lo + CHUNK < gend) ? lo + CHUNK : gend;
+    typename BnIO<T>::Raw raw[ITEMS];
+    float a = 0.0f, q = 0.0f;
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const int64_t m = lo + ((int64_t)it * BN1_THREADS + tid) * W;
+        if (m < hi) raw[it] = *reinterpret_cast<const typename BnIO<T>::Raw *>(row + m);
+    }
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const int64_t m = lo + ((int64_t)it * BN1_THREADS + tid) * W;
+        if (m < hi) {
+            float v[W];
+            BnIO<T>::unpack(raw[it], v);
+#pragma unroll
+            for (int i = 0; i < W; ++i) {
+                const float d = (v[i] + pb) - shift;
+                a += d;
+                q = __builtin_fmaf(d, d, q);
+            }
+        }
+    }
+    const float2 r = block_sum2<BN1_THREADS>(a, q, scratch, tid);
+    unsigned long long *slots_row = reinterpret_cast<unsigned long long *>(sync + (size_t)gridDim.y * BN1_SYNC_STRIDE) + (size_t)c * S;
+    int *counter = sync + (size_t)c * BN1_SYNC_STRIDE;
+    bn1_publish_and_wait(r.x, r.y, slots_row, s, S, sp, tid);
+    int checkout = 0;
+    if (tid == 0) checkout = bn1_checkout(counter);
+    a = 0.0f, q = 0.0f;
+    for (int i = grp * Sg; i < (grp + 1) * Sg; ++i) {
+        a += sp[i].x;
+        q += sp[i].y;
+    }
+    const float dm = a / (float)Mg;
+    const float var = fmaxf(q / (float)Mg - dm * dm, 0.0f);
+    const float mean = shift + dm;
+    const float invstd = 1.0f / sqrtf(var + eps);
+    if (sl == 0 && tid == 0) {
+        save_mean[c * G + grp] = mean;
+        save_invstd[c * G + grp] = invstd;
+    }
+    if (s == 0 && tid == 0 && running_mean) {
+        float rm = running_mean[c], rv = running_var[c];
+        for (int g2 = 0; g2 < G; ++g2) {
+            float a2 = 0.0f, q2 = 0.0f;
+            for (int i = g2 * Sg; i < (g2 + 1) * Sg; ++i) {
+                a2 += sp[i].x;
+                q2 += sp[i].y;
+            }
+            const float sh2 = BnIO<T>::ld1(row + (int64_t)g2 * Mg) + pb;
+            const float dm2 = a2 / (float)Mg;
+            const float var2 = fmaxf(q2 / (float)Mg - dm2 * dm2, 0.0f);
+            const float unbiased = Mg > 1 ? var2 * ((float)Mg / (float)(Mg - 1)) : var2;
+            rm = (1.0f - momentum) * rm + momentum * (sh2 + dm2);
+            rv = (1.0f - momentum) * rv + momentum * unbiased;
+        }
+        running_mean[c] = rm;
+        running_var[c] = rv;
+    }
+    const float g = gamma[c] * invstd;
+    const float off = beta[c] + (pb - mean) * g;
+    const T *rrow = residual ? residual + (size_t)c * M : nullptr;
+    T *orow = out + (size_t)c * M;
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const int64_t m = lo + ((int64_t)it * BN1_THREADS + tid) * W;
+        if (m < hi) {
+            float v[W], rr[W];
+            BnIO<T>::unpack(raw[it], v);
+            if (rrow) BnIO<T>::load(rrow + m, rr);
+#pragma unroll
+            for (int i = 0; i < W; ++i) {
+                v[i] = act_fwd(__builtin_fmaf(v[i], g, off), act, slope);
+                if (rrow) v[i] += rr[i];
+            }
+            BnIO<T>::store(orow + m, v);
+        }
+    }
+    if (tid == 0) bn1_rearm(checkout, S, counter, slots_row);
+}
+
+template <typename T>
+__global__ __launch_bounds__(BN1_THREADS) void bn_bwd1_kernel(const T *__restrict__ x, const T *__restrict__ dz,
+                                                             int64_t M, int64_t Mg, int Sg, int G,
+                                                             const float *__restrict__ pre_bias,
+                                                             const float *__restrict__ gamma,
+                                                             const float *__restrict__ beta,
+                                                             const float *__restrict__ save_mean,
+                                                             const float *__restrict__ save_invstd, int act,
+                                                             float slope,
+                                                             int *__restrict__ sync, T *__restrict__ dx,
+                                                             float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                                             float *__restrict__ dpre_bias) {
+    constexpr int W = BnIO<T>::W, ITEMS = BN1_ITEMS, CHUNK = BN1_THREADS * ITEMS * W;
+    __shared__ float2 scratch[BN1_THREADS / 64];
+    __shared__ float2 sp[BN1_MAX_S];
+    const int c = blockIdx.y, s = blockIdx.x, tid = threadIdx.x;
+    const int S = gridDim.x, grp = s / Sg, sl = s - grp * Sg;
+    const T *row = x + (size_t)c * M, *grow = dz + (size_t)c * M;
+    T *orow = dx + (size_t)c * M;
+    const float pb = pre_bias ? pre_bias[c] : 0.0f;
+    const float mean = save_mean[c * G + grp], invstd = save_invstd[c * G + grp], ga = gamma[c], be = beta[c];
+    const int64_t gend = (int64_t)(grp + 1) * Mg;
+    const int64_t lo = (int64_t)grp * Mg + (int64_t)sl * CHUNK;
+    const int64_t hi = (lo + CHUNK < gend) ? lo + CHUNK : gend;
+    typename BnIO<T>::Raw rx[ITEMS], rd[ITEMS];
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const int64_t m = lo + ((int64_t)it * BN1_THREADS + tid) * W;
+        if (m < hi) {
+            rx[it] = *reinterpret_cast<const typename BnIO<T>::Raw *>(row + m);
+            rd[it] = *reinterpret_cast<const typename BnIO<T>::Raw *>(grow + m);
+        }
+    }
+    float sd = 0.0f, sdx = 0.0f;
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const int64_t m = lo + ((int64_t)it * BN1_THREADS + tid) * W;
+        if (m < hi) {
+            float v[W], d[W];
+            BnIO<T>::unpack(rx[it], v);
+            BnIO<T>::unpack(rd[it], d);
+#pragma unroll
+            for (int i = 0; i < W; ++i) {
+                const float xh = ((v[i] + pb) - mean) * invstd;
+                const float dy = d[i] * act_grad(__builtin_fmaf(xh, ga, be), act, slope);
+                sd += dy;
+                sdx = __builtin_fmaf(dy, xh, sdx);
+            }
+        }
+    }
+    const float2 r = block_sum2<BN1_THREADS>(sd, sdx, scratch, tid);
+    unsigned long long *slots_row = reinterpret_cast<unsigned long long *>(sync + (size_t)gridDim.y * BN1_SYNC_STRIDE) + (size_t)c * S;
+    int *counter = sync + (size_t)c * BN1_SYNC_STRIDE;
+    bn1_publish_and_wait(r.x, r.y, slots_row, s, S, sp, tid);
+    int checkout = 0;
+    if (tid == 0) checkout = bn1_checkout(counter);
+    sd = 0.0f, sdx = 0.0f;
+    for (int i = grp * Sg; i < (grp + 1) * Sg; ++i) {
+        sd += sp[i].x;
+        sdx += sp[i].y;
+    }
+    if (s == 0 && tid == 0) {
+        float td = 0.0f, tdx = 0.0f;
+        for (int i = 0; i < S; ++i) {
+            td += sp[i].x;
+            tdx += sp[i].y;
+        }
+        dgamma[c] = tdx;
+        dbeta[c] = td;
+        if (dpre_bias) dpre_bias[c] = 0.0f;          // training mode only: cancels in the normalisation
+    }
+    const float k = ga * invstd;
+    const float m1 = sd / (float)Mg, m2 = sdx / (float)Mg;
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const int64_t m = lo + ((int64_t)it * BN1_THREADS + tid) * W;
+        if (m < hi) {
+            float v[W], d[W];
+            BnIO<T>::unpack(rx[it], v);
+            BnIO<T>::unpack(rd[it], d);
+#pragma unroll
+            for (int i = 0; i < W; ++i) {
+                const float xh = ((v[i] + pb) - mean) * invstd;
+                const float dy = d[i] * act_grad(__builtin_fmaf(xh, ga, be), act, slope);
+                v[i] = k * ((dy - m1) - xh * m2);
+            }
+            BnIO<T>::store(orow + m, v);
+        }
+    }
+    if (tid == 0) bn1_rearm(checkout, S, counter, slots_row);
+}
+
+// single-pass plan: Sg chunks per group, or 0 when the shape does not qualify
+static int bn1_plan(int64_t Mg, int G, int W) {
+    if (Mg % W) return 0;
+    const int64_t chunk = (int64_t)BN1_THREADS * BN1_ITEMS * W;
+    const int64_t Sg = (Mg + chunk - 1) / chunk;
+    if (Sg * G > BN1_MAX_S) return 0;
+    return (int)Sg;
+}
+
 struct BnPlan {
     int Sg;
     int64_t chunk;
@@ -354,13 +631,21 @@ static bool bn_vec_ok(const void *a, const void *b, const void *c, const void *d
 
 extern "C" size_t grafp_bn_workspace(int C, int64_t M) {
     if (C <= 0 || M <= 0) return 0;
-    return ((size_t)4096 + (size_t)C * 8) * 2 * sizeof(float);      // >= C * G * Sg partial pairs for any G <= 8
+    const size_t two_pass = (size_t)4096 + (size_t)C * 8;          // >= C * G * Sg partial pairs for any G <= 8
+    return two_pass * 2 * sizeof(float);
 }
 
-extern "C" int grafp_bn_fwd(const void *x, int dtype, int C, int64_t M, int groups, const float *pre_bias, const float *gamma,
-                            const float *beta, const void *residual, int act, float slope, float eps, float momentum,
-                            int training, float *running_mean, float *running_var, void *out, float *save_mean,
-                            float *save_invstd, void *ws, size_t ws_bytes, grafp_stream_t stream) {
+extern "C" size_t grafp_bn_sync_bytes(int C, int64_t M) {
+    if (C <= 0 || M <= 0) return 0;
+    // a counter line per row + at most (M / chunk + groups) <= M / chunk + 8 slots per row
+    return (size_t)C * grafp::BN1_SYNC_STRIDE * sizeof(int) + (size_t)C * ((size_t)(M / grafp::BN1_MIN_CHUNK) + 8) * 8;
+}
+
+extern "C" int grafp_bn_fwd_1pass(const void *x, int dtype, int C, int64_t M, int groups, const float *pre_bias,
+                                  const float *gamma, const float *beta, const void *residual, int act, float slope,
+                                  float eps, float momentum, int training, float *running_mean, float *running_var,
+                                  void *out, float *save_mean, float *save_invstd, void *ws, size_t ws_bytes,
+                                  int32_t *sync, grafp_stream_t stream) {
     using namespace grafp;
     GRAFP_REQUIRE(x && gamma && beta && out && save_mean && save_invstd, "bn_fwd: null pointer");
     GRAFP_REQUIRE(C > 0 && M > 0 && C <= 65535, "bn_fwd: bad shape C=%d M=%lld", C, (long long)M);
@@ -376,6 +661,25 @@ extern "C" int grafp_bn_fwd(const void *x, int dtype, int C, int64_t M, int grou
     }
     hipStream_t s = (hipStream_t)stream;
     float *part = (float *)ws;
+    if (sync && training) {
+        const bool f32 = dtype == GRAFP_F32;
+        const bool ok = f32 ? bn_vec_ok<float>(x, out, residual, nullptr, Mg) : bn_vec_ok<unsigned short>(x, out, residual, nullptr, Mg);
+        const int Sg = ok ? bn1_plan(Mg, G, f32 ? 4 : 8) : 0;
+        if (Sg > 0) {
+            const dim3 grid(Sg * G, C);
+            if (f32)
+                hipLaunchKernelGGL((bn_fwd1_kernel<float>), grid, dim3(BN1_THREADS), 0, s, (const float *)x, M, Mg, Sg, G,
+                                   pre_bias, gamma, beta, (const float *)residual, act, slope, eps, momentum,
+                                   running_mean, running_var, (int *)sync, (float *)out, save_mean, save_invstd);
+            else
+                hipLaunchKernelGGL((bn_fwd1_kernel<unsigned short>), grid, dim3(BN1_THREADS), 0, s,
+                                   (const unsigned short *)x, M, Mg, Sg, G, pre_bias, gamma, beta,
+                                   (const unsigned short *)residual, act, slope, eps, momentum, running_mean,
+                                   running_var, (int *)sync, (unsigned short *)out, save_mean, save_invstd);
+            GRAFP_CHECK_LAUNCH("bn_fwd1_kernel");
+            return GRAFP_OK;
+        }
+    }
 #define BN_FWD(T, VEC)                                                                                                 \
     do {                                                                                                               \
         const BnPlan p = bn_plan(C, Mg, G, VEC ? BnIO<T>::W : 1);                                                      \
@@ -397,10 +701,19 @@ extern "C" int grafp_bn_fwd(const void *x, int dtype, int C, int64_t M, int grou
     return GRAFP_OK;
 }
 
-extern "C" int grafp_bn_bwd(const void *x, const void *dz, int dtype, int C, int64_t M, int groups, const float *pre_bias,
-                            const float *gamma, const float *beta, const float *save_mean, const float *save_invstd,
-                            int act, float slope, int training, void *dx, float *dgamma, float *dbeta,
-                            float *dpre_bias, void *ws, size_t ws_bytes, grafp_stream_t stream) {
+extern "C" int grafp_bn_fwd(const void *x, int dtype, int C, int64_t M, int groups, const float *pre_bias, const float *gamma,
+                            const float *beta, const void *residual, int act, float slope, float eps, float momentum,
+                            int training, float *running_mean, float *running_var, void *out, float *save_mean,
+                            float *save_invstd, void *ws, size_t ws_bytes, grafp_stream_t stream) {
+    return grafp_bn_fwd_1pass(x, dtype, C, M, groups, pre_bias, gamma, beta, residual, act, slope, eps, momentum, training,
+                              running_mean, running_var, out, save_mean, save_invstd, ws, ws_bytes, nullptr, stream);
+}
+
+extern "C" int grafp_bn_bwd_1pass(const void *x, const void *dz, int dtype, int C, int64_t M, int groups,
+                                  const float *pre_bias, const float *gamma, const float *beta, const float *save_mean,
+                                  const float *save_invstd, int act, float slope, int training, void *dx,
+                                  float *dgamma, float *dbeta, float *dpre_bias, void *ws, size_t ws_bytes,
+                                  int32_t *sync, grafp_stream_t stream) {
     using namespace grafp;
     GRAFP_REQUIRE(x && dz && gamma && beta && save_mean && save_invstd && dx && dgamma && dbeta, "bn_bwd: null pointer");
     GRAFP_REQUIRE(C > 0 && M > 0 && C <= 65535, "bn_bwd: bad shape C=%d M=%lld", C, (long long)M);
@@ -415,6 +728,25 @@ extern "C" int grafp_bn_bwd(const void *x, const void *dz, int dtype, int C, int
     }
     hipStream_t s = (hipStream_t)stream;
     float *part = (float *)ws;
+    if (sync && training) {
+        const bool f32 = dtype == GRAFP_F32;
+        const bool ok = f32 ? bn_vec_ok<float>(x, dz, dx, nullptr, Mg) : bn_vec_ok<unsigned short>(x, dz, dx, nullptr, Mg);
+        const int Sg = ok ? bn1_plan(Mg, G, f32 ? 4 : 8) : 0;
+        if (Sg > 0) {
+            const dim3 grid(Sg * G, C);
+            if (f32)
+                hipLaunchKernelGGL((bn_bwd1_kernel<float>), grid, dim3(BN1_THREADS), 0, s, (const float *)x,
+                                   (const float *)dz, M, Mg, Sg, G, pre_bias, gamma, beta, save_mean, save_invstd, act,
+                                   slope, (int *)sync, (float *)dx, dgamma, dbeta, dpre_bias);
+            else
+                hipLaunchKernelGGL((bn_bwd1_kernel<unsigned short>), grid, dim3(BN1_THREADS), 0, s,
+                                   (const unsigned short *)x, (const unsigned short *)dz, M, Mg, Sg, G, pre_bias, gamma,
+                                   beta, save_mean, save_invstd, act, slope, (int *)sync, (unsigned short *)dx,
+                                   dgamma, dbeta, dpre_bias);
+            GRAFP_CHECK_LAUNCH("bn_bwd1_kernel");
+            return GRAFP_OK;
+        }
+    }
 #define BN_BWD(T, VEC)                                                                                                 \
     do {                                                                                                               \
         const BnPlan p = bn_plan(C, Mg, G, VEC ? BnIO<T>::W : 1);                                                      \
@@ -433,4 +765,12 @@ extern "C" int grafp_bn_bwd(const void *x, const void *dz, int dtype, int C, int
 #undef BN_BWD
     GRAFP_CHECK_LAUNCH("bn_bwd_reduce_kernel / bn_bwd_dx_kernel");
     return GRAFP_OK;
+}
+
+extern "C" int grafp_bn_bwd(const void *x, const void *dz, int dtype, int C, int64_t M, int groups, const float *pre_bias,
+                            const float *gamma, const float *beta, const float *save_mean, const float *save_invstd,
+                            int act, float slope, int training, void *dx, float *dgamma, float *dbeta,
+                            float *dpre_bias, void *ws, size_t ws_bytes, grafp_stream_t stream) {
+    return grafp_bn_bwd_1pass(x, dz, dtype, C, M, groups, pre_bias, gamma, beta, save_mean, save_invstd, act, slope,
+                              training, dx, dgamma, dbeta, dpre_bias, ws, ws_bytes, nullptr, stream);
 }

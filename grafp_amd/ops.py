@@ -7,6 +7,7 @@ raise immediately.
 import contextlib
 import ctypes
 import math
+import os
 
 import numpy as np
 import torch
@@ -306,6 +307,24 @@ def max_relative(x, idx, layout="bcn"):
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 
 
+_BN_SYNC = {}
+
+
+def _bn_sync(device, C, M):
+    """The rendezvous buffer of the single-pass BatchNorm kernels: filled with ones once per (device, stream); every
+    call leaves it that way (include/grafp_hip.h, grafp_bn_fwd_1pass).  GRAFP_BN_TWO_PASS=1 selects the two-pass
+    kernels (None)."""
+    if os.environ.get("GRAFP_BN_TWO_PASS", "0") == "1":
+        return None
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    buf = _BN_SYNC.get(key)
+    need = int(lib.grafp_bn_sync_bytes(C, M))
+    if buf is None or buf.numel() * 8 < need:
+        buf = torch.full((max(1 << 18, (need + 7) // 8),), -1, dtype=torch.int64, device=device)
+        _BN_SYNC[key] = buf
+    return buf
+
+
 class _BnAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, pre_bias, residual, running_mean, running_var, training, momentum, eps, act,
@@ -325,9 +344,10 @@ class _BnAct(torch.autograd.Function):
         nbytes = lib.grafp_bn_workspace(C, M)
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
         with _timed("bn_fwd", (C, M, x.element_size())):
-            check(lib.grafp_bn_fwd(_p(x), _DT[x.dtype], C, M, groups, _p(pb), _p(g32), _p(b32), _p(res), act, float(slope),
-                                   float(eps), float(momentum), int(bool(training)), _p(running_mean), _p(running_var),
-                                   _p(out), _p(mean), _p(invstd), _p(ws), nbytes, _stream()), "bn_fwd")
+            check(lib.grafp_bn_fwd_1pass(_p(x), _DT[x.dtype], C, M, groups, _p(pb), _p(g32), _p(b32), _p(res), act,
+                                         float(slope), float(eps), float(momentum), int(bool(training)),
+                                         _p(running_mean), _p(running_var), _p(out), _p(mean), _p(invstd), _p(ws),
+                                         nbytes, _p(_bn_sync(x.device, C, M)), _stream()), "bn_fwd")
         ctx.save_for_backward(x, g32, b32, pb if pb is not None else mean.new_empty(0), mean, invstd)
         ctx.cfg = (C, M, act, float(slope), bool(training), pre_bias is not None, residual is not None, groups)
         return out
@@ -346,9 +366,10 @@ class _BnAct(torch.autograd.Function):
         nbytes = lib.grafp_bn_workspace(C, M)
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
         with _timed("bn_bwd", (C, M, x.element_size())):
-            check(lib.grafp_bn_bwd(_p(x), _p(dz), _DT[x.dtype], C, M, groups, _p(pb) if has_pb else None, _p(g32), _p(b32),
-                                   _p(mean), _p(invstd), act, slope, int(training), _p(dx), _p(dgamma), _p(dbeta),
-                                   _p(dpb) if has_pb else None, _p(ws), nbytes, _stream()), "bn_bwd")
+            check(lib.grafp_bn_bwd_1pass(_p(x), _p(dz), _DT[x.dtype], C, M, groups, _p(pb) if has_pb else None, _p(g32),
+                                         _p(b32), _p(mean), _p(invstd), act, slope, int(training), _p(dx), _p(dgamma),
+                                         _p(dbeta), _p(dpb) if has_pb else None, _p(ws), nbytes,
+                                         _p(_bn_sync(x.device, C, M)), _stream()), "bn_bwd")
         return dx, dgamma, dbeta, dpb, (dz if has_res else None), None, None, None, None, None, None, None, None
 
 

@@ -164,6 +164,24 @@ int grafp_bn_bwd(const void *x, const void *dz, int dtype, int C, int64_t M, int
                  const float *beta, const float *save_mean, const float *save_invstd, int act, float slope,
                  int training, void *dx, float *dgamma, float *dbeta, float *dpre_bias /* (C) or NULL */, void *ws,
                  size_t ws_bytes, grafp_stream_t stream);
+/* Single-pass forms of the two entries above (same arguments, results and reference call sites, plus `sync`):
+ * in training mode each workgroup keeps its chunk of a row (8192 f32 / 16384 bf16 elements) in registers across a row-wide rendezvous,
+ * so x (and dz) cross HBM once instead of twice -- forward 3 -> 2 passes, backward 5 -> 3.
+ *   sync  grafp_bn_sync_bytes(C, M) bytes, 8-byte aligned, ALL ONES (0xff) on entry; the call leaves it all ones
+ *         again (so one buffer, filled once, serves every call enqueued on the same stream).  NULL, eval mode, rows
+ *         that are not 16-byte aligned multiples of the vector width, or more than 256 chunks per row select the
+ *         two-pass kernels. */
+size_t grafp_bn_sync_bytes(int C, int64_t M);
+int grafp_bn_fwd_1pass(const void *x, int dtype, int C, int64_t M, int groups, const float *pre_bias,
+                       const float *gamma, const float *beta, const void *residual, int act, float slope, float eps,
+                       float momentum, int training, float *running_mean, float *running_var, void *out,
+                       float *save_mean, float *save_invstd, void *ws, size_t ws_bytes, int32_t *sync,
+                       grafp_stream_t stream);
+int grafp_bn_bwd_1pass(const void *x, const void *dz, int dtype, int C, int64_t M, int groups, const float *pre_bias,
+                       const float *gamma, const float *beta, const float *save_mean, const float *save_invstd,
+                       int act, float slope, int training, void *dx, float *dgamma, float *dbeta,
+                       float *dpre_bias /* (C) or NULL */, void *ws, size_t ws_bytes, int32_t *sync,
+                       grafp_stream_t stream);
 
 /* ---- K9 backward: weight gradient of a 1x1 convolution on the (C, M) layout ------------------------------
  * dW[o][c] = sum_m grad_out[o][m] * x[c][m] for every 1x1 Conv2d of the encoder (torch_vertex.py:152-162,
