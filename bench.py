@@ -72,8 +72,9 @@ def summarise_kernels(timed, esize=4):
             by = sum(mrconv_bytes(m, esize) for _, _, m in ev)
             row.update(bound="hbm", achieved=round(by / (tot * 1e-3) / 1e9, 1), unit="GB/s", peak=PEAK_HBM_GBS)
         elif name in ("bn_fwd", "bn_bwd"):
-            # fwd: stats read + apply read + write (+ residual read, not counted); bwd: 2 x (x, dz) reads + dx write
-            per = 3.0 if name == "bn_fwd" else 5.0
+            # algorithmic passes: fwd reads x, writes z (+ residual read, not counted); bwd reads x and dz, writes dx
+            # (what the single-pass kernels move; the two-pass forms re-read and are charged the same)
+            per = 2.0 if name == "bn_fwd" else 3.0
             by = sum(per * C * M * e for _, _, (C, M, e) in ev)
             row.update(bound="hbm", achieved=round(by / (tot * 1e-3) / 1e9, 1), unit="GB/s", peak=PEAK_HBM_GBS)
         elif name == "conv1x1_wgrad":
