@@ -510,6 +510,40 @@ def test_bn_act_bf16(dev):
     assert xg.grad.dtype == torch.bfloat16 and torch.isfinite(xg.grad.float()).all()
 
 
+@pytest.mark.parametrize("C,M,G,dt", [(64, 2 * 131072, 2, "bf16"), (24, 3 * 40000, 3, "f32"), (256, 65536, 2, "bf16"),
+                                      (8, 2 * 16384 + 16, 1, "bf16"), (5, 8192 * 300, 1, "f32")])
+def test_bn_single_pass_equals_two_pass(dev, monkeypatch, C, M, G, dt):
+    """The single-pass training kernels (chunk held in registers across the row rendezvous; rows of many chunks,
+    ragged last chunk, 3 groups, f32 and bf16) against the two-pass kernels: outputs/gradients equal up to the
+    different partial-sum chunking (1e-6 relative on the statistics), and the rendezvous buffer is all-ones again
+    after every call.  The last case exceeds 256 chunks per row and must fall back by itself."""
+    from grafp_amd import ops
+    dtype = torch.float32 if dt == "f32" else torch.bfloat16
+    gen = torch.Generator(device=dev).manual_seed(C * 7 + G)
+    x = (torch.randn(C, M, device=dev, generator=gen) * 1.5 + 4.0 * torch.randn(C, 1, device=dev, generator=gen)).to(dtype)
+    res = torch.randn(C, M, device=dev, generator=gen).to(dtype)
+    gz = torch.randn(C, M, device=dev, generator=gen).to(dtype)
+    gamma = 1.0 + 0.2 * torch.randn(C, device=dev, generator=gen); beta = 0.3 * torch.randn(C, device=dev, generator=gen)
+    pb = 0.5 * torch.randn(C, device=dev, generator=gen)
+
+    def run(two_pass):
+        monkeypatch.setenv("GRAFP_BN_TWO_PASS", "1" if two_pass else "0")
+        xg = x.clone().requires_grad_(True); gg = gamma.clone().requires_grad_(True); bg = beta.clone().requires_grad_(True)
+        rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        out = ops.bn_act(xg, gg, bg, rm, rv, True, 0.1, 1e-5, pb, res, 2, 0.2, G)
+        out.backward(gz)
+        return [v.detach().float() for v in (out, xg.grad, gg.grad, bg.grad, rm, rv)]
+    one, two = run(False), run(True)
+    torch.cuda.synchronize()
+    for buf in ops._BN_SYNC.values():
+        assert bool((buf == -1).all()), "rendezvous buffer not re-armed"
+    ulp = 2 ** -7 if dt == "bf16" else 2e-6
+    for a, b, name in zip(one, two, ("out", "dx", "dgamma", "dbeta", "running_mean", "running_var")):
+        scale = float(b.abs().max()) + 1e-12
+        err = float((a - b).abs().max()) / scale
+        assert err <= (ulp if name in ("out", "dx") else 2e-5), (name, err)
+
+
 @pytest.mark.parametrize("cout,cin,groups,M", [(64, 64, 1, 8192), (256, 64, 1, 4096), (64, 128, 1, 3000), (128, 128, 4, 8192),
                                                 (512, 128, 1, 2048), (40, 24, 1, 777), (96, 192, 4, 1000)])
 def test_conv1x1_wgrad_bf16(dev, cout, cin, groups, M):
