@@ -22,11 +22,13 @@ def build_model(cfg, k=3, device=None):
 
 
 class Trainer:
-    def __init__(self, cfg, model, device, amp_dtype=None, group=None, lr=None, n_buckets=4):
+    def __init__(self, cfg, model, device, amp_dtype=None, group=None, lr=None, n_buckets=4, ir_dir=None,
+                 noise_dir=None, aug_seed=None):
         self.cfg, self.model, self.device, self.group = cfg, model, device, group
         self.amp_dtype = amp_dtype
         self.world = gdist.world_size(group)
-        self.augment = GPUTransformNeuralfp(cfg, None, None, train=True)
+        # ir_dir / noise_dir: recordings for the batched device-side augmentation of the second view (train.py:150-151)
+        self.augment = GPUTransformNeuralfp(dict(cfg, aug_seed=aug_seed), ir_dir, noise_dir, train=True).to(device)
         # train.py:174 (same Adam, defaults); on the GPU the update of all 271 parameter tensors is one fused launch
         # with device-side step counters instead of ~35 multi-tensor launches and 271 host-side counter bumps
         on_gpu = torch.device(device).type == "cuda"

@@ -47,6 +47,10 @@ def lib():
         L.oracle_seq_rerank.argtypes = [f32p, ctypes.c_int64, f32p, i64p, ctypes.c_int, i64p, i32p, ctypes.c_int,
                                         ctypes.c_int, i64p, f32p]
         L.oracle_seq_rerank.restype = ctypes.c_int
+        L.oracle_ir_convolve.argtypes = [f32p, ctypes.c_int, ctypes.c_int, f32p, ctypes.c_int64, i32p, i32p, f32p]
+        L.oracle_ir_convolve.restype = None
+        L.oracle_mix_snr.argtypes = [f32p, ctypes.c_int, ctypes.c_int, f32p, ctypes.c_int64, i32p, i32p, i32p, f32p, f32p]
+        L.oracle_mix_snr.restype = None
         _LIB = L
     return _LIB
 
@@ -115,3 +119,38 @@ def seq_rerank(index_rows, q_rows, topk_ids, item_row, item_len, top=10):
     if rc != 0:
         raise ValueError(f"oracle_seq_rerank failed ({rc})")
     return oi, os_
+
+
+def _i32(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a, a.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+
+
+def ir_convolve(x, ir_bank, ir_len, ir_index=None):
+    """x (B,T), ir_bank (n_ir,Lmax), ir_len (n_ir), ir_index (B) or None -> (B,T); csrc/augment.c (one fmaf chain per
+    output, taps ascending; full convolution truncated to T)."""
+    x, xp = _f32(x)
+    bank, bp = _f32(ir_bank)
+    ln, lp = _i32(ir_len)
+    B, T = x.shape
+    out = np.empty_like(x)
+    if ir_index is None:
+        ip = None
+    else:
+        ix, ip = _i32(ir_index)
+    lib().oracle_ir_convolve(xp, B, T, bp, bank.shape[1], lp, ip, out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+    return out
+
+
+def mix_snr(x, noise_bank, noise_len, noise_index, noise_offset, snr_db):
+    """AddBackgroundNoise restated (csrc/augment.c): x + rms(x)/10^(snr/20) * n/(rms(n)+1e-8), n read circularly."""
+    x, xp = _f32(x)
+    bank, bp = _f32(noise_bank)
+    ln, lp = _i32(noise_len)
+    ni, nip = _i32(noise_index)
+    no, nop = _i32(noise_offset)
+    sn, sp = _f32(snr_db)
+    B, T = x.shape
+    out = np.empty_like(x)
+    lib().oracle_mix_snr(xp, B, T, bp, bank.shape[1], lp, nip, nop, sp, out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+    return out

@@ -674,3 +674,77 @@ def test_c_abi_entries_are_graph_capturable(dev):
     graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(out_i, want_i) and torch.equal(out_d, want_d) and torch.equal(out_g, want_g)
+
+
+@pytest.mark.parametrize("B,T,L", [(3, 16000, 16000), (2, 5000, 700), (1, 40000, 3001), (4, 2048, 9), (2, 777, 2000)])
+def test_ir_convolve_bit_exact_vs_oracle(dev, B, T, L):
+    """ApplyImpulseResponse on the device: every output is the oracle's fmaf chain (taps ascending) -> equal bits;
+    skipped signals (index -1) are copies; responses longer than the signal, ragged lengths, multi-tile signals."""
+    from grafp_amd import ops
+    from oracle import native as on
+    rng = np.random.default_rng(B * 1000 + L)
+    x = rng.standard_normal((B, T)).astype(np.float32)
+    bank = np.zeros((3, L), np.float32)
+    lens = np.array([L, max(1, L // 3), 1], np.int32)
+    for i in range(3):
+        bank[i, :lens[i]] = rng.standard_normal(lens[i]) * np.exp(-np.arange(lens[i]) / (0.2 * L + 1))
+    idx = np.array([(0, -1, 1, 2)[b % 4] for b in range(B)], np.int32)
+    want = on.ir_convolve(x, bank, lens, idx)
+    got = ops.ir_convolve(torch.from_numpy(x).to(dev), torch.from_numpy(bank).to(dev), torch.from_numpy(lens),
+                          torch.from_numpy(idx)).cpu().numpy()
+    assert np.array_equal(got, want)          # (== treats +0 and -0 alike: zero-padded taps may flip a zero's sign)
+    ref = np.convolve(x[0].astype(np.float64), bank[idx[0], :lens[idx[0]]].astype(np.float64))[:T]
+    np.testing.assert_allclose(got[0], ref, rtol=0, atol=3e-5 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("B,T", [(5, 16000), (1, 100000), (3, 4097)])
+def test_mix_snr_vs_oracle(dev, B, T):
+    """AddBackgroundNoise on the device vs the oracle (double sums): 2e-6 of the signal's peak; the realised SNR
+    is the requested one; skipped signals are copies."""
+    from grafp_amd import ops
+    from oracle import native as on
+    rng = np.random.default_rng(T)
+    x = rng.standard_normal((B, T)).astype(np.float32) * 0.1
+    noise = rng.standard_normal((3, 30000)).astype(np.float32)
+    nlen = np.array([30000, 12345, 100], np.int32)
+    nidx = np.array([(0, 1, -1, 2, 1)[b % 5] for b in range(B)], np.int32)
+    off = np.array([(7, 12344, 0, 99, 5000)[b % 5] for b in range(B)], np.int32)
+    snr = np.array([(0.0, 5.0, 10.0, 20.0, 3.3)[b % 5] for b in range(B)], np.float32)
+    want = on.mix_snr(x, noise, nlen, nidx, off, snr)
+    got = ops.mix_snr(torch.from_numpy(x).to(dev), torch.from_numpy(noise).to(dev), torch.from_numpy(nlen),
+                      torch.from_numpy(nidx), torch.from_numpy(off), torch.from_numpy(snr)).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-6 * np.abs(want).max())
+    for b in range(B):
+        if nidx[b] < 0:
+            assert np.array_equal(got[b], x[b])
+        else:
+            added = got[b].astype(np.float64) - x[b]
+            got_snr = 20 * np.log10(np.sqrt((x[b].astype(np.float64) ** 2).mean()) / np.sqrt((added ** 2).mean()))
+            assert abs(got_snr - snr[b]) < 2e-3
+
+
+def test_device_augmentation_in_the_transform(dev):
+    """GPUTransformNeuralfp with recordings: the train branch augments the second view on the device (both
+    transforms, per-clip draws, reproducible from the seed), probabilities 0 leave the view untouched, the
+    validation branch augments the whole track before segmentation."""
+    from grafp_amd.modules.transformations import GPUTransformNeuralfp
+    from grafp_amd.util import load_config
+    from grafp_amd import ops
+    cfg = dict(load_config())
+    rng = np.random.default_rng(0)
+    irs = (rng.standard_normal((4, 4000)) * np.exp(-np.arange(4000) / 600.0)).astype(np.float32)
+    noise = rng.standard_normal((3, 50000)).astype(np.float32)
+    x = torch.from_numpy(rng.standard_normal((6, 16000)).astype(np.float32) * 0.1).to(dev)
+    t1 = GPUTransformNeuralfp(dict(cfg, aug_seed=11), irs, noise, train=True).to(dev)
+    t2 = GPUTransformNeuralfp(dict(cfg, aug_seed=11), irs, noise, train=True).to(dev)
+    a, b = t1.train_transform(x), t2.train_transform(x)
+    assert torch.equal(a, b) and not torch.equal(a, x) and torch.isfinite(a).all()
+    Xi, Xj = t1(x, x)
+    assert Xi.shape == Xj.shape == (6, cfg["n_mels"], cfg["n_frames"]) and not torch.equal(Xi, Xj)
+    assert torch.equal(Xi, ops.logmel(x, cfg["fs"], cfg["n_fft"], cfg["win_len"], cfg["hop_len"], cfg["n_mels"]))
+    off = GPUTransformNeuralfp(dict(cfg, ir_prob=0.0, noise_prob=0.0), irs, noise, train=True).to(dev)
+    assert torch.equal(off.train_transform(x), x)
+    val = GPUTransformNeuralfp(dict(cfg, aug_seed=3), irs, noise, train=False).to(dev)
+    track = x.reshape(-1)
+    S_i, S_j = val(track.unsqueeze(0), track.unsqueeze(0))
+    assert S_i.shape == S_j.shape and S_i.shape[0] > 1 and not torch.equal(S_i, S_j)

@@ -182,11 +182,33 @@ def test_config_and_util():
     assert util.override(3, None) == 3 and util.override(3, 5) == 5
 
 
-def test_augmentation_is_refused_loudly():
-    from grafp_amd.modules.transformations import GPUTransformNeuralfp
+def test_augmentation_banks_and_cpu_branch(tmp_path):
+    """Recordings are decoded once into zero-padded banks (.npy and PCM .wav, directory / list / array sources);
+    a wrong sample rate is refused; without a GPU the transforms themselves refuse to run (no CPU fallback); the
+    DataLoader-worker branch (cpu=True) stays an identity crop."""
+    import wave
+    from grafp_amd.modules.transformations import GPUTransformNeuralfp, load_bank
     from grafp_amd.util import load_config
-    with pytest.raises(NotImplementedError):
-        GPUTransformNeuralfp(load_config(), "/some/ir", None)
-    t = GPUTransformNeuralfp(load_config(), None, None, cpu=True)
+    cfg = load_config()
+    a = (np.sin(np.arange(300) * 0.1) * 0.5).astype(np.float32)
+    np.save(tmp_path / "a.npy", a)
+    pcm = (np.clip(np.cos(np.arange(500) * 0.05), -1, 1) * 32767).astype("<i2")
+    for name, fs in (("b.wav", cfg["fs"]), ("bad.wav", 8000)):
+        with wave.open(str(tmp_path / name), "wb") as w:
+            w.setnchannels(1); w.setsampwidth(2); w.setframerate(fs); w.writeframes(pcm.tobytes())
+    bank, lens = load_bank([str(tmp_path / "a.npy"), str(tmp_path / "b.wav")], cfg["fs"])
+    assert bank.shape == (2, 500) and lens.tolist() == [300, 500]
+    assert np.array_equal(bank[0, :300].numpy(), a) and float(bank[0, 300:].abs().max()) == 0.0
+    np.testing.assert_allclose(bank[1].numpy(), pcm.astype(np.float32) / 32768.0)
+    with pytest.raises(ValueError):
+        load_bank(str(tmp_path / "bad.wav"), cfg["fs"])
+    (tmp_path / "d").mkdir(); np.save(tmp_path / "d" / "x.npy", a)
+    assert load_bank(str(tmp_path / "d"), cfg["fs"])[1].tolist() == [300]
+    assert load_bank(np.ones((3, 7), np.float32), cfg["fs"], max_len=5)[0].shape == (3, 5)
+    t = GPUTransformNeuralfp(cfg, str(tmp_path / "d"), np.ones((2, 100), np.float32), train=True)
+    assert t.ir_bank.shape == (1, 300) and t.noise_len.tolist() == [100, 100]
+    with pytest.raises(RuntimeError):
+        t.train_transform(torch.zeros(2, 16000))           # CPU tensors: the HIP path refuses, nothing falls back
+    t = GPUTransformNeuralfp(cfg, None, None, cpu=True)
     a, b = t(torch.zeros(16000), torch.arange(16010.0))
     assert b.shape == (16000,)

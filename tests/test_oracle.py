@@ -363,3 +363,34 @@ def test_seq_rerank_c_vs_numpy_scores():
         n = min(10, len(cand))
         assert np.array_equal(pred[it, :n], cand[order][:n]) and (pred[it, n:] == -1).all()
         np.testing.assert_allclose(scores[it, :n], sc[order][:n], rtol=2e-5, atol=2e-6)
+
+
+def test_augment_oracle_matches_definitions():
+    """oracle/csrc/augment.c against float64 numpy statements of the two transforms' published definitions
+    (torch_audiomentations is not installable here: parity unpinned against the library itself): full convolution
+    truncated to the input length; background scaled to the requested SNR after RMS normalisation."""
+    from oracle import native as on
+    rng = np.random.default_rng(3)
+    B, T = 4, 3000
+    x = rng.standard_normal((B, T)).astype(np.float32)
+    bank = np.zeros((2, 900), np.float32)
+    bank[0, :900] = rng.standard_normal(900) * np.exp(-np.arange(900) / 150.0)
+    bank[1, :17] = rng.standard_normal(17)
+    lens, idx = np.array([900, 17]), np.array([0, -1, 1, 0])
+    y = on.ir_convolve(x, bank, lens, idx)
+    for b, i in enumerate(idx):
+        want = x[b] if i < 0 else np.convolve(x[b].astype(np.float64), bank[i, :lens[i]].astype(np.float64))[:T]
+        np.testing.assert_allclose(y[b], want, rtol=0, atol=2e-5 * np.abs(want).max())
+    assert np.array_equal(on.ir_convolve(x, bank, lens, None)[1], on.ir_convolve(x[1:2], bank, lens, np.array([0]))[0])
+    noise = rng.standard_normal((2, 2000)).astype(np.float32) * 3.0
+    nlen, nidx, off = np.array([2000, 777]), np.array([1, 0, -1, 1]), np.array([5, 1999, 0, 776])
+    snr = np.array([10.0, 0.0, 5.0, 20.0], np.float32)
+    z = on.mix_snr(x, noise, nlen, nidx, off, snr)
+    for b in range(B):
+        if nidx[b] < 0:
+            assert np.array_equal(z[b], x[b]); continue
+        n = noise[nidx[b], (off[b] + np.arange(T)) % nlen[nidx[b]]].astype(np.float64)
+        added = z[b].astype(np.float64) - x[b]
+        got_snr = 20 * np.log10(np.sqrt((x[b].astype(np.float64) ** 2).mean()) / np.sqrt((added ** 2).mean()))
+        assert abs(got_snr - snr[b]) < 1e-3
+        assert np.corrcoef(added, n)[0, 1] > 0.999999
