@@ -8,10 +8,11 @@
 //   AddBackgroundNoise     y = x + rms(x) / 10^(snr_db / 20) * n / (rms(n) + 1e-8)
 // Here the whole batch stays in HBM: the impulse responses and noise recordings are resident banks, every clip picks
 // a row (or none) by index, and the two transforms are three launches for the batch.
-//   * ir_convolve_kernel: direct convolution on the f32 FMA pipe.  A workgroup owns 2048 consecutive outputs of one
-//     clip, a thread two groups of 4 consecutive outputs; the impulse response is walked in 512-tap chunks staged in LDS together
-//     with the 2560 input samples they touch.  Per 8 taps a thread loads 2 x 8 new samples (the other 4 of each 12-sample
-//     window are the previous step's) and 8 taps (broadcast) and issues 64 fmaf: ~11 FMAs per LDS dword, so the
+//   * ir_convolve_kernel: direct convolution on the f32 FMA pipe.  A workgroup owns 4096 consecutive outputs of one
+//     clip, a thread 8 consecutive outputs in each half of the tile; the impulse response is walked in 512-tap chunks
+//     staged in LDS together with the input samples they touch, stored as (lower half, upper half) pairs.  Per 8 taps a
+//     thread loads 8 new sample pairs (the other 8 of its 16-pair window are the previous step's) and 8 taps (broadcast)
+//     and issues 64 packed FMAs: 5.3 FMAs per LDS dword (the LDS port allows 4 at the packed-FMA peak), so the
 //     kernel is FMA-bound (2*T*L flops per clip; 1 s clips with 1 s responses = 0.51 GFLOP per clip).  Every output
 //     is ONE fmaf chain in increasing tap order -- the order oracle/csrc/augment.c fixes -- so results are bit-equal
 //     to the oracle.  (An FFT convolution needs ~30x fewer flops at L = 16000 but two 32768-point transforms per clip
@@ -25,16 +26,24 @@
 namespace grafp {
 
 constexpr int AC_THREADS = 256;
-constexpr int AC_R = 8;                         // consecutive outputs per thread
-constexpr int AC_TT = AC_THREADS * AC_R;        // 2048 outputs per workgroup
+constexpr int AC_R = 8;                         // consecutive output PAIRS per thread
+constexpr int AC_H = AC_THREADS * AC_R;         // 2048: half a tile
+constexpr int AC_TT = 2 * AC_H;                 // 4096 outputs per workgroup
 constexpr int AC_LC = 512;                      // taps per LDS chunk
+constexpr int AC_ROWS = (AC_H + AC_LC) / 8;     // LDS rows of 8 sample pairs (+ one 16-byte pad: 20 dwords per row)
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __global__ __launch_bounds__(AC_THREADS) void ir_convolve_kernel(const float *__restrict__ x, int64_t x_stride, int T,
                                                                  const float *__restrict__ ir_bank, int64_t ir_stride,
                                                                  const int *__restrict__ ir_index,
                                                                  const int *__restrict__ ir_len,
                                                                  float *__restrict__ out, int64_t out_stride) {
-    __shared__ __attribute__((aligned(16))) float xs[AC_TT + AC_LC];
+    // xs: sample PAIRS (x[p], x[p + AC_H]) -- output o of the lower half-tile and output o of the upper half-tile
+    // meet the same taps, so one packed FMA (v_pk_fma_f32, tap broadcast) advances both chains and its operands are
+    // always an aligned register pair.  Rows of 8 pairs are padded to 80 bytes: a thread's window pieces (16 bytes,
+    // lanes 64 bytes of samples apart) then fall on distinct banks.
+    __shared__ __attribute__((aligned(16))) float xs[AC_ROWS * 20];
     __shared__ __attribute__((aligned(16))) float hs[AC_LC];
     // clips run fastest over the grid and the late (long) tiles come first: a tile's cost grows with its position
     // (causal sum), and with tiles fastest every XCD (block id mod 8) would own ONE tile position -- 8x imbalance
@@ -49,64 +58,59 @@ __global__ __launch_bounds__(AC_THREADS) void ir_convolve_kernel(const float *__
     }
     const int L = ir_len[ii];
     const float *h = ir_bank + (size_t)ii * ir_stride;
-    float acc[AC_R];
+    f32x2 acc[AC_R];
 #pragma unroll
-    for (int j = 0; j < AC_R; ++j) acc[j] = 0.0f;
+    for (int j = 0; j < AC_R; ++j) acc[j] = f32x2{0.0f, 0.0f};
     // taps beyond the last output index of this tile only meet samples before the start of the clip
     const int l_end = L < t0 + AC_TT ? L : t0 + AC_TT;
     for (int l0 = 0; l0 < l_end; l0 += AC_LC) {
         __syncthreads();
         for (int i = tid; i < AC_LC; i += AC_THREADS) hs[i] = (l0 + i < L) ? h[l0 + i] : 0.0f;
-        const int xbase = t0 - l0 - AC_LC;       // xs[i] = x[xbase + i]
-        for (int i = tid; i < AC_TT + AC_LC; i += AC_THREADS) {
-            const int p = xbase + i;
-            xs[i] = (p >= 0 && p < T) ? xb[p] : 0.0f;
+        const int xbase = t0 - l0 - AC_LC;       // pair i = (x[xbase + i], x[xbase + i + AC_H])
+        for (int i = tid; i < AC_H + AC_LC; i += AC_THREADS) {
+            const int p = xbase + i, q = p + AC_H;
+            const float a = (p >= 0 && p < T) ? xb[p] : 0.0f, c = (q >= 0 && q < T) ? xb[q] : 0.0f;
+            *reinterpret_cast<float2 *>(xs + 2 * i + 4 * (i >> 3)) = make_float2(a, c);
         }
         __syncthreads();
-        // A thread owns two groups of 4 consecutive outputs, t0 + 4*tid + j and t0 + 1024 + 4*tid + j: consecutive
-        // lanes then read consecutive 16-byte pieces of the window (conflict-free ds_read_b128; one group of 8 outputs
-        // per thread puts the lanes 32 bytes apart -- the same banks every 4th lane).  Tap l = l0 + u0 + u meets, for
-        // output index o = 4*tid + g*1024 + j of the tile, the sample xs[o - u0 - u + AC_LC] = w[j - u + 8] with the
-        // 12-sample window w[k] = xs[4*tid + g*1024 + AC_LC - u0 - 8 + k]; stepping u0 by 8 keeps w[0..3] as w[8..11].
-        const float *wp0 = xs + tid * 4 + AC_LC, *wp1 = wp0 + AC_TT / 2;
-        float hi[2][4], lo[2][8];
-        {
-            const float4 a = *reinterpret_cast<const float4 *>(wp0), c = *reinterpret_cast<const float4 *>(wp1);
-            hi[0][0] = a.x; hi[0][1] = a.y; hi[0][2] = a.z; hi[0][3] = a.w;
-            hi[1][0] = c.x; hi[1][1] = c.y; hi[1][2] = c.z; hi[1][3] = c.w;
+        // Tap l = l0 + u0 + u meets, for output pair o = 8*tid + j, the sample pair number o - u0 - u + AC_LC
+        //   = w[j - u + 8] of the 16-pair window w[k] = pair (8*tid + AC_LC - u0 - 8 + k): one LDS row per step;
+        // stepping u0 by 8 keeps w[0..7] as w[8..15].  Every output is ONE fmaf chain, taps ascending.
+        const float *wp = xs + 20 * (tid + AC_LC / 8);
+        f32x2 hi[8], lo[8];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const float4 v = *reinterpret_cast<const float4 *>(wp + 4 * m);
+            hi[2 * m] = f32x2{v.x, v.y};
+            hi[2 * m + 1] = f32x2{v.z, v.w};
         }
 #pragma unroll 2
         for (int u0 = 0; u0 < AC_LC; u0 += 8) {
+            const float *row = wp - 20 * (u0 / 8 + 1);
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                const float *wp = g ? wp1 : wp0;
-                const float4 a = *reinterpret_cast<const float4 *>(wp - u0 - 8), c = *reinterpret_cast<const float4 *>(wp - u0 - 4);
-                lo[g][0] = a.x; lo[g][1] = a.y; lo[g][2] = a.z; lo[g][3] = a.w;
-                lo[g][4] = c.x; lo[g][5] = c.y; lo[g][6] = c.z; lo[g][7] = c.w;
+            for (int m = 0; m < 4; ++m) {
+                const float4 v = *reinterpret_cast<const float4 *>(row + 4 * m);
+                lo[2 * m] = f32x2{v.x, v.y};
+                lo[2 * m + 1] = f32x2{v.z, v.w};
             }
             const float4 h0 = *reinterpret_cast<const float4 *>(hs + u0), h1 = *reinterpret_cast<const float4 *>(hs + u0 + 4);
             const float hv[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
 #pragma unroll
             for (int u = 0; u < 8; ++u)
 #pragma unroll
-                for (int g = 0; g < 2; ++g)
+                for (int j = 0; j < AC_R; ++j) {
+                    const int k = j - u + 8;      // 1..15
+                    acc[j] = __builtin_elementwise_fma(f32x2{hv[u], hv[u]}, k < 8 ? lo[k] : hi[k - 8], acc[j]);
+                }
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int k = j - u + 8;      // 1..11
-                        acc[g * 4 + j] = __builtin_fmaf(hv[u], k < 8 ? lo[g][k] : hi[g][k - 8], acc[g * 4 + j]);
-                    }
-#pragma unroll
-            for (int g = 0; g < 2; ++g)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) hi[g][k] = lo[g][k];
+            for (int k = 0; k < 8; ++k) hi[k] = lo[k];
         }
     }
+    const int t = t0 + tid * AC_R;
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        const int t = t0 + g * (AC_TT / 2) + tid * 4;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (t + j < T) ob[t + j] = acc[g * 4 + j];
+    for (int j = 0; j < AC_R; ++j) {
+        if (t + j < T) ob[t + j] = acc[j].x;
+        if (t + j + AC_H < T) ob[t + j + AC_H] = acc[j].y;
     }
 }
 
