@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--no-retrieval", action="store_true")
     ap.add_argument("--no-f32-probe", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="skip the HIP-graph replay of the step")
+    ap.add_argument("--no-augment", action="store_true", help="skip the device-side augmentation leg")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=25.0)
     return ap.parse_args()
 
@@ -340,6 +341,43 @@ def main():
             line["fingerprinting"] = fp
             model.train()
             line["retrieval"] = retrieval_probe(device, cpu_check=not args.no_cpu_baseline)
+        if world == 1 and not args.no_augment:
+            # the second view augmented on the device (impulse response + background noise for every
+            # clip: ir_prob = noise_prob = 1 as in config/grafp.yaml), synthetic banks: 8 one-second decaying-noise
+            # responses, 16 ten-second noise recordings
+            from grafp_amd import ops
+            gen = torch.Generator(device=device).manual_seed(5)
+            irs = torch.randn(8, 16000, generator=gen, device=device) * \
+                torch.exp(-torch.arange(16000, device=device, dtype=torch.float32) / 3000.0)
+            noise = torch.randn(16, 160000, generator=gen, device=device)
+            taug = Trainer(cfg, model, device, amp_dtype=amp, ir_dir=irs, noise_dir=noise, aug_seed=0)
+            tf = taug.augment
+            pick = torch.randint(0, 8, (B,), generator=gen, device=device)
+            off = torch.randint(0, 160000, (B,), generator=gen, device=device)
+            snr = 20.0 * torch.rand(B, generator=gen, device=device)
+
+            def timed(fn, reps):
+                fn()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    fn()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t0) / reps
+            dt_ir = timed(lambda: ops.ir_convolve(x_j, tf.ir_bank, tf.ir_len, pick), 5)
+            dt_mx = timed(lambda: ops.mix_snr(x_j, tf.noise_bank, tf.noise_len, pick, off, snr), 20)
+            Tn, Ln = x_j.shape[1], 16000
+            useful = 2.0 * B * (Tn * Ln - Ln * (Ln - 1) / 2.0)
+            dt_step = timed(lambda: taug.step(x_i, x_j), max(3, args.steps // 2))
+            line["augmentation"] = {
+                "ir_convolve_ms": round(dt_ir * 1e3, 3), "ir_convolve_tflops": round(useful / dt_ir / 1e12, 1),
+                "ir_convolve_peak_tflops": PEAK_F32_MATRIX_TFLOPS,
+                "mix_snr_us": round(dt_mx * 1e6, 1), "mix_snr_gbs": round(3.0 * 4 * B * Tn / dt_mx / 1e9, 1),
+                "step_ms_with_augmentation": round(dt_step * 1e3, 3),
+                "clips_per_s_with_augmentation": round(B / dt_step, 2),
+                "note": f"{B} one-second clips, one-second responses (useful flops 2*sum_t min(t+1, L)), x/noise/out "
+                        "once for the mix; step = the eager step above with both transforms on every clip of view j"}
+            del taug
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, args.cpu_baseline_seconds)
         print(json.dumps(line), flush=True)
