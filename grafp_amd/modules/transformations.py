@@ -120,14 +120,19 @@ class GPUTransformNeuralfp(nn.Module):
             x = ops.mix_snr(x, self.noise_bank, self.noise_len, torch.where(keep, pick, torch.full_like(pick, -1)), off, snr)
         return x[0] if squeeze else x
 
+    def _has_banks(self):
+        return self.ir_bank is not None or self.noise_bank is not None
+
     def train_transform(self, x):
+        if not self._has_banks():
+            return x
         return self.augment(x, self.cfg["ir_prob"], self.cfg["noise_prob"], self.cfg["tr_snr"])
 
     def val_transform(self, x):
-        return self.augment(x, 1.0, 1.0, self.cfg["val_snr"])
+        return self.augment(x, 1.0, 1.0, self.cfg["val_snr"]) if self._has_banks() else x
 
     def ablation(self, x):
-        return self.augment(x, 0.0, 1.0, self.cfg["val_snr"])
+        return self.augment(x, 0.0, 1.0, self.cfg["val_snr"]) if self._has_banks() else x
 
     def logmelspec(self, x):
         c = self.cfg
