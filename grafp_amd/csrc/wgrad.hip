@@ -149,7 +149,9 @@ struct WgradPlan {
 };
 static WgradPlan wgrad_plan(int cout_g, int cin_g, int groups, int64_t M) {
     WgradPlan p;
-    // measured crossover.  (A 256 x 128 tile with 64-column chunks -- 85 flop per operand byte instead of 64 -- was
+    // measured crossover.  (Two chunks in flight per workgroup -- a second register set -- costs the 128-tile its
+    // second workgroup per CU (320 registers) and was 30-40 % slower on the stage 2-3 shapes, 3-8 % on the 64-tile.)
+    // (A 256 x 128 tile with 64-column chunks -- 85 flop per operand byte instead of 64 -- was
     // tried and is 5-30 % slower on every FFN shape: the halved chunk doubles the barriers per MFMA.)
     p.tw = (cout_g >= 128 && cin_g >= 128 && (int64_t)cout_g * cin_g >= 65536) ? 128 : 64;
     p.tiles_o = (cout_g + p.tw - 1) / p.tw;
