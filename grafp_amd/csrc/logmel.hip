@@ -89,102 +89,6 @@ __global__ __launch_bounds__(LM_THREADS) void logmel_kernel(const float *__restr
     }
 }
 
-// Wave-per-frame-pair variant for n_fft = 4^n (256, 1024: the model's): each of the 4 waves runs its OWN complex
-// radix-4 Stockham FFT (two real frames) in its own LDS buffers -- 5 passes of 4 butterflies per lane for n_fft = 1024
-// instead of 10 radix-2 passes separated by workgroup barriers, and no workgroup barrier inside the transform at all
-// (a wave's LDS accesses execute in order; only the compiler needs the fence).  The 8 frames of the workgroup meet
-// again for the mel bands.
-template <int NFFT>
-__global__ __launch_bounds__(LM_THREADS) void logmel_wave_kernel(const float *__restrict__ wav, int64_t wav_stride, int T,
-                                                                 int hop, int n_mels, int n_frames,
-                                                                 const float *__restrict__ window,
-                                                                 const float2 *__restrict__ twiddle,
-                                                                 const float *__restrict__ fb,
-                                                                 const int *__restrict__ band_lo,
-                                                                 const int *__restrict__ band_hi, float *__restrict__ out) {
-    constexpr int NB = NFFT / 2 + 1, NW = LM_THREADS / 64, Q = NFFT / 4;
-    static_assert(NW * 2 == LM_FPB, "one frame pair per wave");
-    __shared__ float2 bufA[NW][NFFT];          // after the transform: the wave's two power spectra (2 * NB floats)
-    __shared__ float2 bufB[NW][NFFT];
-    __shared__ float2 tw[NFFT / 2];
-    __shared__ float win[NFFT];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, b = blockIdx.y;
-    const int frame0 = blockIdx.x * LM_FPB;
-    const float *x = wav + (size_t)b * wav_stride;
-    for (int i = tid; i < NFFT / 2; i += LM_THREADS) tw[i] = twiddle[i];
-    for (int i = tid; i < NFFT; i += LM_THREADS) win[i] = window[i];
-    __syncthreads();
-    const int f0 = frame0 + 2 * wave, f1 = f0 + 1;
-    float2 *src = bufA[wave], *dst = bufB[wave];
-    if (f0 < n_frames) {                         // wave-uniform
-        for (int t = lane; t < NFFT; t += 64) {
-            int p0 = f0 * hop + t - NFFT / 2, p1 = p0 + hop;
-            p0 = p0 < 0 ? -p0 : (p0 >= T ? 2 * (T - 1) - p0 : p0);
-            p1 = p1 < 0 ? -p1 : (p1 >= T ? 2 * (T - 1) - p1 : p1);
-            const float w = win[t];
-            src[t] = make_float2(x[p0] * w, f1 < n_frames ? x[p1] * w : 0.0f);
-        }
-#pragma unroll 1
-        for (int p = 1; p < NFFT; p <<= 2) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
-            const int tstep = Q / p;             // twiddle index step: exp(-2 pi i k / (4p)) = tw[k * N / (4p)]
-#pragma unroll
-            for (int r = 0; r < Q / 64; ++r) {
-                const int i = lane + 64 * r;
-                const int k = i & (p - 1);
-                const int j = ((i - k) << 2) + k;
-                const float2 u0 = src[i];
-                float2 u[3];
-#pragma unroll
-                for (int t = 1; t < 4; ++t) {
-                    const int q = t * k * tstep;                     // < 3N/4; tw holds [0, N/2): tw[q] = -tw[q - N/2]
-                    float2 w = tw[q & (NFFT / 2 - 1)];
-                    if (q >= NFFT / 2) w = make_float2(-w.x, -w.y);
-                    const float2 v = src[i + t * Q];
-                    u[t - 1] = make_float2(v.x * w.x - v.y * w.y, v.x * w.y + v.y * w.x);
-                }
-                const float2 v0 = make_float2(u0.x + u[1].x, u0.y + u[1].y), v1 = make_float2(u0.x - u[1].x, u0.y - u[1].y);
-                const float2 v2 = make_float2(u[0].x + u[2].x, u[0].y + u[2].y);
-                const float2 d = make_float2(u[0].x - u[2].x, u[0].y - u[2].y);
-                const float2 v3 = make_float2(d.y, -d.x);            // (-i) * (u1 - u3): forward transform
-                dst[j] = make_float2(v0.x + v2.x, v0.y + v2.y);
-                dst[j + p] = make_float2(v1.x + v3.x, v1.y + v3.y);
-                dst[j + 2 * p] = make_float2(v0.x - v2.x, v0.y - v2.y);
-                dst[j + 3 * p] = make_float2(v1.x - v3.x, v1.y - v3.y);
-            }
-            float2 *tmp = src; src = dst; dst = tmp;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-        // split the two real spectra into the free buffer: Xa = (Z[k] + conj Z[N-k]) / 2, Xb = (Z[k] - conj Z[N-k]) / (2i)
-        float *pw = reinterpret_cast<float *>(dst);
-        for (int k = lane; k < NB; k += 64) {
-            const float2 z = src[k], y = src[(NFFT - k) & (NFFT - 1)];
-            const float ar = 0.5f * (z.x + y.x), ai = 0.5f * (z.y - y.y);
-            const float br = 0.5f * (z.y + y.y), bi = 0.5f * (y.x - z.x);
-            pw[k] = ar * ar + ai * ai;
-            pw[NB + k] = br * br + bi * bi;
-        }
-    }
-    __syncthreads();
-    // (after an odd number of passes the spectra of wave w sit in bufA[w] or bufB[w]: same choice in every wave)
-    int passes = 0;
-    for (int p = 1; p < NFFT; p <<= 2) ++passes;
-    // mel bands of the workgroup's 8 frames: lanes run over bands so fb rows are read coalesced
-    for (int it = tid; it < LM_FPB * n_mels; it += LM_THREADS) {
-        const int fr = it / n_mels, m = it - fr * n_mels;
-        const int f = frame0 + fr;
-        if (f < n_frames) {
-            const float *pw = reinterpret_cast<const float *>((passes & 1) ? bufA[fr >> 1] : bufB[fr >> 1]) + (fr & 1) * NB;
-            float acc = 0.0f;
-            const int lo = band_lo[m], hi = band_hi[m];
-            for (int k = lo; k <= hi; ++k) acc = __builtin_fmaf(pw[k], fb[(size_t)k * n_mels + m], acc);
-            out[((size_t)b * n_mels + m) * n_frames + f] = 10.0f * log10f(fmaxf(acc, 1e-10f));
-        }
-    }
-}
-
 __global__ __launch_bounds__(256) void unfold_kernel(const float *__restrict__ spec, int n_mels, int n_frames,
                                                      int size, int step, int n_seg, float *__restrict__ seg) {
     const size_t total = (size_t)n_seg * n_mels * size;
@@ -213,18 +117,14 @@ extern "C" int grafp_logmel_f32(const float *wav, int64_t wav_stride, int B, int
 #define LM_LAUNCH(N)                                                                                                 \
     hipLaunchKernelGGL(logmel_kernel<N>, grid, dim3(LM_THREADS), 0, s, wav, wav_stride, T, hop, n_mels, n_frames,    \
                        window, tw, fb, band_lo, band_hi, out)
-#define LM_LAUNCH_WAVE(N)                                                                                            \
-    hipLaunchKernelGGL(logmel_wave_kernel<N>, grid, dim3(LM_THREADS), 0, s, wav, wav_stride, T, hop, n_mels,         \
-                       n_frames, window, tw, fb, band_lo, band_hi, out)
     switch (n_fft) {
-        case 256: LM_LAUNCH_WAVE(256); break;
+        case 256: LM_LAUNCH(256); break;
         case 512: LM_LAUNCH(512); break;
-        case 1024: LM_LAUNCH_WAVE(1024); break;
+        case 1024: LM_LAUNCH(1024); break;
         case 2048: LM_LAUNCH(2048); break;
         default: set_error("logmel: n_fft=%d not in {256,512,1024,2048}", n_fft); return GRAFP_ERR_ARG;
     }
 #undef LM_LAUNCH
-#undef LM_LAUNCH_WAVE
     GRAFP_CHECK_LAUNCH("logmel_kernel");
     return GRAFP_OK;
 }
