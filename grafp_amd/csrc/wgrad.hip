@@ -122,6 +122,110 @@ __global__ __launch_bounds__(256) void wgrad_partial_kernel(const unsigned short
         }
 }
 
+// f32 operands (the f32 "parity" mode of the training step): same streaming reduction, with every operand value split
+// on the way into LDS into hi = bf16(v) and lo = bf16(v - hi), and three bf16 MFMAs per tile step
+//   G X^T ~= Gh Xh^T + Gh Xl^T + Gl Xh^T     (products of bf16 pairs are exact in the f32 accumulator; the dropped
+//                                             Gl Xl^T term and the 16-bit representation are ~2^-16 relative)
+// -- 3 matrix instructions at the bf16 rate (16x the f32 MFMA rate) instead of the library's f32 GEMM, which runs
+// this tall-K shape at 42 ms per step.  64 x 64 tiles only (four LDS planes of 64 rows).
+typedef float wg_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 wg_bf16x2 __attribute__((ext_vector_type(2)));
+// two values -> (packed hi pair, packed lo pair): v_cvt_pk_bf16_f32 (round to nearest even), exact residual, again
+__device__ __forceinline__ void wg_split2(float a, float b, unsigned &hi, unsigned &lo) {
+    const wg_f32x2 v = {a, b};
+    const wg_bf16x2 h = __builtin_convertvector(v, wg_bf16x2);
+    const wg_bf16x2 l = __builtin_convertvector(v - __builtin_convertvector(h, wg_f32x2), wg_bf16x2);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+}
+__device__ __forceinline__ void wg_split8(const float4 &a, const float4 &b, uint4 &hi, uint4 &lo) {
+    wg_split2(a.x, a.y, hi.x, lo.x);
+    wg_split2(a.z, a.w, hi.y, lo.y);
+    wg_split2(b.x, b.y, hi.z, lo.z);
+    wg_split2(b.z, b.w, hi.w, lo.w);
+}
+
+__global__ __launch_bounds__(256) void wgrad3_partial_kernel(const float *__restrict__ G, const float *__restrict__ X,
+                                                             int64_t M, int cout_g, int cin_g, int tiles_o, int tiles_c,
+                                                             int64_t cols_per_split, float *__restrict__ part) {
+    constexpr int TW = 64, PL = TW * WG_LS;       // one LDS plane: 64 rows
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *sGh = smem, *sGl = smem + PL, *sXh = smem + 2 * PL, *sXl = smem + 3 * PL;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int ntiles = tiles_o * tiles_c;
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = logical / ntiles, tile = logical - split * ntiles, grp = blockIdx.z;
+    const int o0 = (tile / tiles_c) * TW, c0 = (tile % tiles_c) * TW;
+    const float *Gg = G + (size_t)grp * cout_g * M;
+    const float *Xg = X + (size_t)grp * cin_g * M;
+    const int64_t m_begin = (int64_t)split * cols_per_split;
+    const int64_t m_end = (m_begin + cols_per_split < M) ? m_begin + cols_per_split : M;
+    const int wo = wave >> 1, wc = wave & 1;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    const bool vec_ok = (M & 3) == 0;
+    float4 pg[TW / 16][2], px[TW / 16][2];
+    auto ld8 = [&](const float *rowp, int64_t m, float4 (&d)[2]) {
+        if (vec_ok && m + 8 <= m_end) {
+            d[0] = *reinterpret_cast<const float4 *>(rowp + m);
+            d[1] = *reinterpret_cast<const float4 *>(rowp + m + 4);
+        } else {
+            float t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int e = 0; e < 8 && m + e < m_end; ++e) t[e] = rowp[m + e];
+            d[0] = make_float4(t[0], t[1], t[2], t[3]);
+            d[1] = make_float4(t[4], t[5], t[6], t[7]);
+        }
+    };
+    auto fetch = [&](int64_t m0) {
+#pragma unroll
+        for (int i = 0; i < TW / 16; ++i) {
+            const int row = i * 16 + (tid >> 4), cb = tid & 15;
+            const int64_t m = m0 + cb * 8;
+            pg[i][0] = pg[i][1] = px[i][0] = px[i][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < m_end) {
+                if (o0 + row < cout_g) ld8(Gg + (size_t)(o0 + row) * M, m, pg[i]);
+                if (c0 + row < cin_g) ld8(Xg + (size_t)(c0 + row) * M, m, px[i]);
+            }
+        }
+    };
+    if (m_begin < m_end) fetch(m_begin);
+    for (int64_t m0 = m_begin; m0 < m_end; m0 += WG_KC) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TW / 16; ++i) {
+            const int row = i * 16 + (tid >> 4), cb = tid & 15;
+            uint4 h, l;
+            wg_split8(pg[i][0], pg[i][1], h, l);
+            *reinterpret_cast<uint4 *>(sGh + row * WG_LS + cb * 16) = h;
+            *reinterpret_cast<uint4 *>(sGl + row * WG_LS + cb * 16) = l;
+            wg_split8(px[i][0], px[i][1], h, l);
+            *reinterpret_cast<uint4 *>(sXh + row * WG_LS + cb * 16) = h;
+            *reinterpret_cast<uint4 *>(sXl + row * WG_LS + cb * 16) = l;
+        }
+        __syncthreads();
+        if (m0 + WG_KC < m_end) fetch(m0 + WG_KC);
+        const int ga = (wo * 32 + l31) * WG_LS + half * 16, xa = (wc * 32 + l31) * WG_LS + half * 16;
+#pragma unroll
+        for (int kk = 0; kk < WG_KC / 16; ++kk) {
+            const bf16x8 gh = *reinterpret_cast<const bf16x8 *>(sGh + ga + kk * 32);
+            const bf16x8 gl = *reinterpret_cast<const bf16x8 *>(sGl + ga + kk * 32);
+            const bf16x8 xh = *reinterpret_cast<const bf16x8 *>(sXh + xa + kk * 32);
+            const bf16x8 xl = *reinterpret_cast<const bf16x8 *>(sXl + xa + kk * 32);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gl, xh, acc, 0, 0, 0);     // small terms first
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh, xl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh, xh, acc, 0, 0, 0);
+        }
+    }
+    float *pp = part + ((size_t)split * gridDim.z + grp) * cout_g * cin_g;
+    const int c = c0 + wc * 32 + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int o = o0 + wo * 32 + mfma_row(r, half);
+        if (o < cout_g && c < cin_g) pp[(size_t)o * cin_g + c] = acc[r];
+    }
+}
+
 // out[i] = sum_k part[k][i]: 16 outputs x 16 split-lanes per workgroup, fixed summation order (deterministic)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ part, int S, int64_t n,
                                                            float *__restrict__ out) {
@@ -208,6 +312,60 @@ extern "C" int grafp_conv1x1_wgrad_bf16(const void *grad_out, const void *x, int
                            (const unsigned short *)x, M, cout_g, cin_g, p.tiles_o, p.tiles_c, p.cols, (float *)ws);
     }
     GRAFP_CHECK_LAUNCH("wgrad_partial_kernel");
+    const int64_t n = (int64_t)Cout * cin_g;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, s, (const float *)ws, p.S, n,
+                       dweight);
+    GRAFP_CHECK_LAUNCH("wgrad_reduce_kernel");
+    return GRAFP_OK;
+}
+
+static grafp::WgradPlan wgrad3_plan(int cout_g, int cin_g, int groups, int64_t M) {
+    using namespace grafp;
+    WgradPlan p;
+    p.tw = 64;
+    p.tiles_o = (cout_g + 63) / 64;
+    p.tiles_c = (cin_g + 63) / 64;
+    const int64_t tiles = (int64_t)p.tiles_o * p.tiles_c * groups;
+    int64_t S = (1024 + tiles - 1) / tiles;
+    const int64_t max_s = (M + 4 * WG_KC - 1) / (4 * WG_KC);
+    if (S > max_s) S = max_s;
+    if (S > 256) S = 256;
+    if (S < 1) S = 1;
+    int64_t cols = (M + S - 1) / S;
+    cols = (cols + WG_KC - 1) / WG_KC * WG_KC;
+    p.cols = cols;
+    p.S = (int)((M + cols - 1) / cols);
+    return p;
+}
+
+extern "C" size_t grafp_conv1x1_wgrad_f32_workspace(int Cout, int Cin, int groups, int64_t M) {
+    if (Cout <= 0 || Cin <= 0 || groups <= 0 || M <= 0 || Cout % groups || Cin % groups) return 0;
+    const grafp::WgradPlan p = wgrad3_plan(Cout / groups, Cin / groups, groups, M);
+    return (size_t)p.S * Cout * (Cin / groups) * sizeof(float);
+}
+
+extern "C" int grafp_conv1x1_wgrad_f32(const float *grad_out, const float *x, int Cout, int Cin, int groups, int64_t M,
+                                       float *dweight, void *ws, size_t ws_bytes, grafp_stream_t stream) {
+    using namespace grafp;
+    GRAFP_REQUIRE(grad_out && x && dweight, "conv1x1_wgrad_f32: null pointer");
+    GRAFP_REQUIRE(Cout > 0 && Cin > 0 && groups > 0 && M > 0 && Cout % groups == 0 && Cin % groups == 0,
+                  "conv1x1_wgrad_f32: bad shape Cout=%d Cin=%d groups=%d M=%lld", Cout, Cin, groups, (long long)M);
+    GRAFP_REQUIRE((((uintptr_t)grad_out | (uintptr_t)x) & 15) == 0, "conv1x1_wgrad_f32: operands must be 16-byte aligned");
+    const size_t need = grafp_conv1x1_wgrad_f32_workspace(Cout, Cin, groups, M);
+    if (!ws || ws_bytes < need) {
+        set_error("conv1x1_wgrad_f32: workspace %zu bytes < required %zu", ws_bytes, need);
+        return GRAFP_ERR_WORKSPACE;
+    }
+    const int cout_g = Cout / groups, cin_g = Cin / groups;
+    const WgradPlan p = wgrad3_plan(cout_g, cin_g, groups, M);
+    GRAFP_REQUIRE((int64_t)p.S * p.tiles_o * p.tiles_c < (1ll << 31), "conv1x1_wgrad_f32: output too large");
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(p.S * p.tiles_o * p.tiles_c, 1, groups);
+    const size_t lds = (size_t)4 * 64 * WG_LS;
+    (void)hipFuncSetAttribute((const void *)wgrad3_partial_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(wgrad3_partial_kernel, grid, dim3(256), lds, s, grad_out, x, M, cout_g, cin_g, p.tiles_o, p.tiles_c,
+                       p.cols, (float *)ws);
+    GRAFP_CHECK_LAUNCH("wgrad3_partial_kernel");
     const int64_t n = (int64_t)Cout * cin_g;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, s, (const float *)ws, p.S, n,
                        dweight);

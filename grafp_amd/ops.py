@@ -519,6 +519,15 @@ class _Conv1x1(torch.autograd.Function):
                 with _timed("conv1x1_wgrad", (cout, cin, groups, M)):
                     check(lib.grafp_conv1x1_wgrad_bf16(_p(g), _p(x), cout, cin, groups, M, _p(dw), _p(ws), nbytes,
                                                        _stream()), "conv1x1_wgrad")
+            elif x.dtype == torch.float32 and x.is_cuda and os.environ.get("GRAFP_WGRAD_F32_LIBRARY", "0") != "1":
+                # f32 step: split-bf16 (hi/lo) x 3 MFMAs inside the same streaming kernel; the library's f32 GEMM
+                # runs this tall-K shape ~3.5x slower (GRAFP_WGRAD_F32_LIBRARY=1 selects it)
+                dw = torch.empty((cout, cin_g), dtype=torch.float32, device=x.device)
+                nbytes = lib.grafp_conv1x1_wgrad_f32_workspace(cout, cin, groups, M)
+                ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
+                with _timed("conv1x1_wgrad", (cout, cin, groups, M)):
+                    check(lib.grafp_conv1x1_wgrad_f32(_p(g), _p(x), cout, cin, groups, M, _p(dw), _p(ws), nbytes,
+                                                      _stream()), "conv1x1_wgrad_f32")
             elif groups == 1:
                 dw = torch.mm(g, x.t()).float()
             else:

@@ -193,6 +193,13 @@ int grafp_bn_bwd_1pass(const void *x, const void *dz, int dtype, int C, int64_t 
 size_t grafp_conv1x1_wgrad_workspace(int Cout, int Cin, int groups, int64_t M);
 int grafp_conv1x1_wgrad_bf16(const void *grad_out, const void *x, int Cout, int Cin, int groups, int64_t M,
                              float *dweight, void *ws, size_t ws_bytes, grafp_stream_t stream);
+/* f32 operands (the f32 "parity" mode of the step): the same split-K streaming reduction with each value split into
+ * hi = bf16(v), lo = bf16(v - hi) on the way into LDS and three bf16 MFMAs per tile step (Gh Xh + Gh Xl + Gl Xh; the
+ * dropped Gl Xl term and the 16-bit representation are ~2^-16 relative, f32 accumulation).  Same layouts as above
+ * with f32 elements. */
+size_t grafp_conv1x1_wgrad_f32_workspace(int Cout, int Cin, int groups, int64_t M);
+int grafp_conv1x1_wgrad_f32(const float *grad_out, const float *x, int Cout, int Cin, int groups, int64_t M,
+                            float *dweight, void *ws, size_t ws_bytes, grafp_stream_t stream);
 
 /* ---- K12: NT-Xent loss, fused forward + backward ----------------------------------------------
  * Replaces ntxent_loss (simclr/ntxent.py:4-29; called train.py:71).  Rows of the similarity matrix

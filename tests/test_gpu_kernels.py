@@ -598,6 +598,34 @@ def test_conv1x1_wgrad_bf16(dev, cout, cin, groups, M):
     np.testing.assert_allclose(xg.grad.float().cpu().numpy(), (dense.t() @ gd).numpy(), rtol=2e-2, atol=3e-2)
 
 
+@pytest.mark.parametrize("cout,cin,groups,M", [(64, 64, 1, 8192), (256, 64, 1, 40000), (128, 128, 4, 8192), (512, 128, 1, 2048),
+                                                (40, 24, 1, 777), (96, 192, 4, 1001), (64, 256, 1, 262144)])
+def test_conv1x1_wgrad_f32_split_bf16(dev, monkeypatch, cout, cin, groups, M):
+    """Weight gradient of f32 operands through the split-bf16 (hi/lo, three MFMAs) streaming kernel vs a float64
+    product: 3e-5 of the largest entry (2^-16 per product, averaged over M terms); the library f32 GEMM on the same
+    data as a cross-check of the bar (it lands at ~1e-6)."""
+    from grafp_amd import ops
+    gen = torch.Generator(device=dev).manual_seed(cout * 31 + cin)
+    x = torch.randn(cin, M, device=dev, generator=gen) + 0.5
+    g = torch.randn(cout, M, device=dev, generator=gen) * 0.3
+    w = torch.randn(cout, cin // groups, device=dev, generator=gen) * 0.1
+
+    def run():
+        xg = x.clone().requires_grad_(True); wg = w.clone().requires_grad_(True)
+        ops.conv1x1_rows(xg, wg, groups).backward(g)
+        return wg.grad
+    got = run()
+    monkeypatch.setenv("GRAFP_WGRAD_F32_LIBRARY", "1")
+    lib_ = run()
+    xd, gd = x.double(), g.double()
+    want = torch.cat([gd.reshape(groups, cout // groups, M)[i] @ xd.reshape(groups, cin // groups, M)[i].t()
+                      for i in range(groups)], dim=0)
+    scale = float(want.abs().max())
+    assert got.shape == (cout, cin // groups) and got.dtype == torch.float32
+    assert float((got.double() - want).abs().max()) <= 3e-5 * scale
+    assert float((lib_.double() - want).abs().max()) <= 3e-5 * scale
+
+
 @pytest.mark.parametrize("C,M,G,dt", [(64, 8192, 2, "f32"), (256, 1536, 2, "f32"), (16, 3000, 3, "f32"), (128, 4096, 2, "bf16")])
 def test_bn_act_groups_equal_sequential_calls(dev, C, M, G, dt):
     """groups=G (views stacked along the columns) == G separate calls on the column segments: same outputs, same
