@@ -8,6 +8,9 @@ import ctypes
 import os
 import subprocess
 
+import torch  # noqa: F401  -- FIRST: the library must bind to the HIP runtime torch ships (same soname as /opt/rocm's);
+#                               loaded the other way round the process holds two runtimes and launches find no device
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgrafp_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "grafp_hip.h")
