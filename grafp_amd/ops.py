@@ -541,7 +541,7 @@ def conv1x1_rows(x, w, groups=1, w_lowp=None):
     (the rest of a block already flows in it); the weight gradient of bf16 operands is the hand-written split-K
     kernel (grafp_conv1x1_wgrad_bf16), everything else a plain library GEMM."""
     if torch.is_autocast_enabled() and x.is_cuda and x.dtype == torch.float32:
-        x = x.to(torch.get_autocast_gpu_dtype())
+        x = x.to(torch.get_autocast_dtype("cuda"))
     return _Conv1x1.apply(x.contiguous(), w, groups, w_lowp)
 
 
