@@ -258,6 +258,36 @@ def main():
         loss = loss_sum
     elapsed = float(t.item())
 
+    sharded = None
+    if world > 1 and not args.no_retrieval:
+        # BASELINE config 5 shape: the fingerprint database sharded across the GPUs (1.25 M x 128 rows per GPU, built
+        # on the device; every rank plants its share of the queries in its own shard), one batched search =
+        # local exact top-20 + all-gather of the (nq, 20) lists + merge.  Every rank runs the same collectives.
+        n_local, nq_loc = 1_250_000, 4096 // world
+        gen = torch.Generator(device=device).manual_seed(2 + rank)
+        rows = torch.nn.functional.normalize(torch.randn(n_local, 128, generator=gen, device=device), dim=1)
+        index = gdist.ShardedFlatL2Index(128)
+        index.add_local(rows, rank * n_local, world * n_local)
+        pick = torch.randint(0, n_local, (nq_loc,), generator=gen, device=device)
+        q_loc = torch.nn.functional.normalize(rows[pick] + 0.05 * torch.randn(nq_loc, 128, generator=gen, device=device), dim=1)
+        q_all = torch.empty((world * nq_loc, 128), dtype=torch.float32, device=device)
+        want = torch.empty((world * nq_loc,), dtype=torch.int64, device=device)
+        dist.all_gather_into_tensor(q_all, q_loc.contiguous())
+        dist.all_gather_into_tensor(want, (pick + rank * n_local).contiguous())
+        index.search(q_all, 20)
+        barrier()
+        t0, reps = time.perf_counter(), 5
+        for _ in range(reps):
+            _, ids = index.search(q_all, 20)
+        barrier()
+        dt = torch.tensor([(time.perf_counter() - t0) / reps], dtype=torch.float64, device=device)
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        sharded = {"db": f"{world} x {n_local} x 128 f32 shards resident (+ bf16 pre-filter copies)", "k": 20,
+                   "nq": world * nq_loc, "ms_per_batch": round(float(dt.item()) * 1e3, 4),
+                   "qps": round(world * nq_loc / float(dt.item()), 1),
+                   "top1_hit_rate": float((ids[:, 0] == want).float().mean().item()), "n_gpus": world}
+        del index, rows
+
     if rank == 0:
         clips = B * world * args.steps
         dom = kernels.get("knn_topk", {})
@@ -380,6 +410,8 @@ def main():
             del taug
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, args.cpu_baseline_seconds)
+        if sharded is not None:
+            line["retrieval_sharded"] = sharded
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

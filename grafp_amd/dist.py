@@ -207,6 +207,19 @@ class ShardedFlatL2Index:
         self._halo_rows = x[hi:min(n, hi + self.halo)]
         self.ntotal += n
 
+    def add_local(self, rows, lo, n_total, halo_rows=None):
+        """Shard-aware loading: this rank passes ONLY the rows it owns, global ids [lo, lo + len(rows)) of an n_total-row
+        index (e.g. read from its own slice of a memmap, or generated on the device), plus optionally the first `halo`
+        rows of the next shard for the sequence rerank.  Nothing is replicated on the host."""
+        if self._factory is None:
+            from .ops import FlatL2Index
+            self._factory = lambda id_base: FlatL2Index(self.d, id_base=id_base)
+        self.local = self._factory(int(lo))
+        self.local.add(rows)
+        self.lo, self.hi = int(lo), int(lo) + len(rows)
+        self._halo_rows = halo_rows
+        self.ntotal = int(n_total)
+
     def rerank(self, q_rows, topk_ids, item_row, item_len, top=10):
         """Sequence-level rerank (eval.py:262-290) over the sharded index: every rank scores the candidates whose start
         row it owns (its rows + halo make those sequences local), then one all-gather of the (n_items, top) lists

@@ -95,6 +95,11 @@ def _worker(rank, world, port, out):
     idx.add_global(db)
     D, I = idx.search(q, 20)
     wd, wi = native.flat_search_l2(db, q, 20)
+    idx2 = gdist.ShardedFlatL2Index(128, local_index_factory=OracleIndex, merge_fn=merge)
+    lo, hi = gdist.shard_range(len(db), rank, world)
+    idx2.add_local(db[lo:hi], lo, len(db))                 # shard-aware loading: only the own rows
+    D2, I2 = idx2.search(q, 20)
+    res["search_local_ok"] = bool(np.array_equal(np.asarray(I2), wi) and np.array_equal(np.asarray(D2), wd))
     res["shard_rows"] = gdist.shard_range(1001, rank, world)
     res["search_ok"] = bool(np.array_equal(np.asarray(I), wi) and np.array_equal(np.asarray(D), wd))
     out[rank] = res
@@ -110,7 +115,7 @@ def test_world_size_2_gloo():
         res = dict(out)
     assert set(res) == {0, 1}
     for rank, r in res.items():
-        assert r["loss_ok"] and r["grad_ok"] and r["gradsync_0"] and r["gradsync_1"] and r["search_ok"], (rank, r)
+        assert r["loss_ok"] and r["grad_ok"] and r["gradsync_0"] and r["gradsync_1"] and r["search_ok"] and r["search_local_ok"], (rank, r)
     assert res[0]["shard_rows"] == (0, 501) and res[1]["shard_rows"] == (501, 1001)
 
 

@@ -103,7 +103,8 @@ def test_two_ranks_match_one_process(tmp_path):
 
 
 def test_bench_two_ranks_one_gpu(tmp_path):
-    """bench.py's N > 1 path end to end (barriers, MAX over ranks, rank-0 JSON line) with both ranks on cuda:0."""
+    """bench.py's N > 1 path end to end (barriers, MAX over ranks, rank-0 JSON line, sharded retrieval leg) with both
+    ranks on cuda:0."""
     import json
     root = os.path.dirname(HERE)
     procs = []
@@ -112,7 +113,7 @@ def test_bench_two_ranks_one_gpu(tmp_path):
                    MASTER_PORT="29654", GRAFP_LOCAL_DEVICE="0", GRAFP_DIST_BACKEND="gloo",
                    HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
-                                       "--warmup", "1", "--batch-per-gpu", "16", "--no-cpu-baseline", "--no-retrieval"],
+                                       "--warmup", "1", "--batch-per-gpu", "16", "--no-cpu-baseline"],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     logs = []
     for p in procs:
@@ -124,3 +125,5 @@ def test_bench_two_ranks_one_gpu(tmp_path):
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
     assert line["config"]["global_batch"] == 32 and line["roofline"]["frac"] > 0
+    rs = line["retrieval_sharded"]                 # config-5 shape: one 1.25 M-row shard per rank, planted queries
+    assert rs["n_gpus"] == 2 and rs["nq"] == 4096 and rs["top1_hit_rate"] == 1.0 and rs["qps"] > 0
