@@ -394,8 +394,8 @@ def main():
                     fn()
                 torch.cuda.synchronize()
                 return (time.perf_counter() - t0) / reps
-            dt_ir = timed(lambda: ops.ir_convolve(x_j, tf.ir_bank, tf.ir_len, pick), 5)
-            dt_mx = timed(lambda: ops.mix_snr(x_j, tf.noise_bank, tf.noise_len, pick, off, snr), 20)
+            dt_ir = timed(lambda: ops.ir_convolve(x_j, tf.ir_bank, tf.ir_len, pick, tf.ir_start), 5)
+            dt_mx = timed(lambda: ops.mix_snr(x_j, tf.noise_bank, tf.noise_len, pick, off, snr, tf.noise_start), 20)
             Tn, Ln = x_j.shape[1], 16000
             useful = 2.0 * B * (Tn * Ln - Ln * (Ln - 1) / 2.0)
             dt_step = timed(lambda: taug.step(x_i, x_j), max(3, args.steps // 2))

@@ -69,9 +69,9 @@ SIGNATURES = {
     "grafp_merge_topk": (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),
     "grafp_seq_rerank_f32": (_I, [_P, _L, _P, _L, _P, _I, _P, _P, _I, _I, _I, _P, _P, _P]),
     "grafp_seq_rerank_shard_f32": (_I, [_P, _L, _L, _L, _L, _L, _P, _L, _P, _I, _P, _P, _I, _I, _I, _P, _P, _P]),
-    "grafp_ir_convolve_f32": (_I, [_P, _L, _I, _I, _P, _L, _I, _P, _P, _P, _L, _P]),
+    "grafp_ir_convolve_f32": (_I, [_P, _L, _I, _I, _P, _P, _I, _P, _P, _P, _L, _P]),
     "grafp_mix_snr_workspace": (_Z, [_I, _I]),
-    "grafp_mix_snr_f32": (_I, [_P, _L, _I, _I, _P, _L, _I, _P, _P, _P, _P, _P, _L, _P, _Z, _P]),
+    "grafp_mix_snr_f32": (_I, [_P, _L, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _L, _P, _Z, _P]),
 }
 
 

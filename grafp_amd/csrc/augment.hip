@@ -6,8 +6,8 @@
 //   ApplyImpulseResponse   y[t] = sum_{l <= t} ir[l] * x[t - l], truncated to the input length (its default,
 //                          compensate_for_propagation_delay=False; the library convolves by FFT)
 //   AddBackgroundNoise     y = x + rms(x) / 10^(snr_db / 20) * n / (rms(n) + 1e-8)
-// Here the whole batch stays in HBM: the impulse responses and noise recordings are resident banks, every clip picks
-// a row (or none) by index, and the two transforms are three launches for the batch.
+// Here the whole batch stays in HBM: the impulse responses and noise recordings are resident RAGGED banks (one flat
+// buffer + per-recording start and length: no padding to the longest file), every clip picks a recording (or none) by index, and the two transforms are three launches for the batch.
 //   * ir_convolve_kernel: direct convolution on the f32 FMA pipe.  A workgroup owns 4096 consecutive outputs of one
 //     clip, a thread 8 consecutive outputs in each half of the tile; the impulse response is walked in 512-tap chunks
 //     staged in LDS together with the input samples they touch, stored as (lower half, upper half) pairs.  Per 8 taps a
@@ -35,7 +35,7 @@ constexpr int AC_ROWS = (AC_H + AC_LC) / 8;     // LDS rows of 8 sample pairs (+
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __global__ __launch_bounds__(AC_THREADS) void ir_convolve_kernel(const float *__restrict__ x, int64_t x_stride, int T,
-                                                                 const float *__restrict__ ir_bank, int64_t ir_stride,
+                                                                 const float *__restrict__ ir_bank, const int64_t *__restrict__ ir_start,
                                                                  const int *__restrict__ ir_index,
                                                                  const int *__restrict__ ir_len,
                                                                  float *__restrict__ out, int64_t out_stride) {
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(AC_THREADS) void ir_convolve_kernel(const float *__
         return;
     }
     const int L = ir_len[ii];
-    const float *h = ir_bank + (size_t)ii * ir_stride;
+    const float *h = ir_bank + ir_start[ii];
     f32x2 acc[AC_R];
 #pragma unroll
     for (int j = 0; j < AC_R; ++j) acc[j] = f32x2{0.0f, 0.0f};
@@ -137,7 +137,8 @@ __device__ __forceinline__ float2 mx_block_sum2(float a, float b, float2 *scratc
 // part[b][s] = (sum x^2, sum n^2) over chunk s of clip b; n[t] = bank[index[b]][(offset[b] + t) mod noise_len]
 __global__ __launch_bounds__(MX_THREADS) void mix_partial_kernel(const float *__restrict__ x, int64_t x_stride, int T,
                                                                  const float *__restrict__ noise_bank,
-                                                                 int64_t noise_stride, const int *__restrict__ noise_len,
+                                                                 const int64_t *__restrict__ noise_start,
+                                                                 const int *__restrict__ noise_len,
                                                                  const int *__restrict__ noise_index,
                                                                  const int *__restrict__ noise_offset,
                                                                  float2 *__restrict__ part) {
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(MX_THREADS) void mix_partial_kernel(const float *__
     const int ni = noise_index[b];
     if (ni < 0) return;
     const int nl = noise_len[ni];
-    const float *xb = x + (size_t)b * x_stride, *nb = noise_bank + (size_t)ni * noise_stride;
+    const float *xb = x + (size_t)b * x_stride, *nb = noise_bank + noise_start[ni];
     const int lo = s * MX_CHUNK, hi = lo + MX_CHUNK < T ? lo + MX_CHUNK : T;
     int p = (int)(((int64_t)noise_offset[b] + lo + tid) % nl);
     const int step = MX_THREADS % nl;
@@ -164,7 +165,8 @@ __global__ __launch_bounds__(MX_THREADS) void mix_partial_kernel(const float *__
 
 __global__ __launch_bounds__(MX_THREADS) void mix_apply_kernel(const float *__restrict__ x, int64_t x_stride, int T,
                                                                const float *__restrict__ noise_bank,
-                                                               int64_t noise_stride, const int *__restrict__ noise_len,
+                                                               const int64_t *__restrict__ noise_start,
+                                                               const int *__restrict__ noise_len,
                                                                const int *__restrict__ noise_index,
                                                                const int *__restrict__ noise_offset,
                                                                const float *__restrict__ snr_db,
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(MX_THREADS) void mix_apply_kernel(const float *__re
     // AddBackgroundNoise: the background is RMS-normalised (+1e-8), then scaled to rms(x) / 10^(snr/20)
     const float scale = (rms_x / powf(10.0f, snr_db[b] / 20.0f)) / (rms_n + 1e-8f);
     const int nl = noise_len[ni];
-    const float *nb = noise_bank + (size_t)ni * noise_stride;
+    const float *nb = noise_bank + noise_start[ni];
     int p = (int)(((int64_t)noise_offset[b] + lo + tid) % nl);
     const int step = MX_THREADS % nl;
     for (int t = lo + tid; t < hi; t += MX_THREADS) {
@@ -202,16 +204,16 @@ __global__ __launch_bounds__(MX_THREADS) void mix_apply_kernel(const float *__re
 }  // namespace grafp
 
 extern "C" int grafp_ir_convolve_f32(const float *x, int64_t x_stride, int B, int T, const float *ir_bank,
-                                     int64_t ir_stride, int n_ir, const int32_t *ir_len, const int32_t *ir_index,
+                                     const int64_t *ir_start, int n_ir, const int32_t *ir_len, const int32_t *ir_index,
                                      float *out, int64_t out_stride, grafp_stream_t stream) {
     using namespace grafp;
-    GRAFP_REQUIRE(x && ir_bank && ir_len && out, "ir_convolve: null pointer");
+    GRAFP_REQUIRE(x && ir_bank && ir_start && ir_len && out, "ir_convolve: null pointer");
     GRAFP_REQUIRE(B > 0 && T > 0 && n_ir > 0 && (T + AC_TT - 1) / AC_TT <= 65535, "ir_convolve: bad shape B=%d T=%d n_ir=%d", B, T, n_ir);
-    GRAFP_REQUIRE(x_stride >= T && out_stride >= T && ir_stride > 0, "ir_convolve: strides shorter than the rows");
+    GRAFP_REQUIRE(x_stride >= T && out_stride >= T, "ir_convolve: strides shorter than the rows");
     GRAFP_REQUIRE(x != out, "ir_convolve: in-place operation is not supported");
     const dim3 grid(B, (T + AC_TT - 1) / AC_TT);
     hipLaunchKernelGGL(ir_convolve_kernel, grid, dim3(AC_THREADS), 0, (hipStream_t)stream, x, x_stride, T, ir_bank,
-                       ir_stride, (const int *)ir_index, (const int *)ir_len, out, out_stride);
+                       ir_start, (const int *)ir_index, (const int *)ir_len, out, out_stride);
     GRAFP_CHECK_LAUNCH("ir_convolve_kernel");
     return GRAFP_OK;
 }
@@ -222,13 +224,13 @@ extern "C" size_t grafp_mix_snr_workspace(int B, int T) {
 }
 
 extern "C" int grafp_mix_snr_f32(const float *x, int64_t x_stride, int B, int T, const float *noise_bank,
-                                 int64_t noise_stride, int n_noise, const int32_t *noise_len,
+                                 const int64_t *noise_start, int n_noise, const int32_t *noise_len,
                                  const int32_t *noise_index, const int32_t *noise_offset, const float *snr_db,
                                  float *out, int64_t out_stride, void *ws, size_t ws_bytes, grafp_stream_t stream) {
     using namespace grafp;
-    GRAFP_REQUIRE(x && noise_bank && noise_len && noise_index && noise_offset && snr_db && out, "mix_snr: null pointer");
+    GRAFP_REQUIRE(x && noise_bank && noise_start && noise_len && noise_index && noise_offset && snr_db && out, "mix_snr: null pointer");
     GRAFP_REQUIRE(B > 0 && T > 0 && n_noise > 0 && B <= 65535, "mix_snr: bad shape B=%d T=%d n_noise=%d", B, T, n_noise);
-    GRAFP_REQUIRE(x_stride >= T && out_stride >= T && noise_stride > 0, "mix_snr: strides shorter than the rows");
+    GRAFP_REQUIRE(x_stride >= T && out_stride >= T, "mix_snr: strides shorter than the rows");
     const size_t need = grafp_mix_snr_workspace(B, T);
     if (!ws || ws_bytes < need) {
         set_error("mix_snr: workspace %zu bytes < required %zu", ws_bytes, need);
@@ -236,10 +238,10 @@ extern "C" int grafp_mix_snr_f32(const float *x, int64_t x_stride, int B, int T,
     }
     const dim3 grid((T + MX_CHUNK - 1) / MX_CHUNK, B);
     hipLaunchKernelGGL(mix_partial_kernel, grid, dim3(MX_THREADS), 0, (hipStream_t)stream, x, x_stride, T, noise_bank,
-                       noise_stride, (const int *)noise_len, (const int *)noise_index, (const int *)noise_offset,
+                       noise_start, (const int *)noise_len, (const int *)noise_index, (const int *)noise_offset,
                        (float2 *)ws);
     hipLaunchKernelGGL(mix_apply_kernel, grid, dim3(MX_THREADS), 0, (hipStream_t)stream, x, x_stride, T, noise_bank,
-                       noise_stride, (const int *)noise_len, (const int *)noise_index, (const int *)noise_offset, snr_db,
+                       noise_start, (const int *)noise_len, (const int *)noise_index, (const int *)noise_offset, snr_db,
                        (const float2 *)ws, out, out_stride);
     GRAFP_CHECK_LAUNCH("mix_partial_kernel / mix_apply_kernel");
     return GRAFP_OK;

@@ -3,8 +3,8 @@
 log-mel and whole-track segmentation are HIP kernels (ops.logmel / ops.unfold_segments).  The IR / background-noise
 augmentation chains (:25-48, torch_audiomentations) run ON THE DEVICE for the whole batch (ops.ir_convolve /
 ops.mix_snr, csrc/augment.hip) instead of clip by clip on DataLoader workers (:67-75): `ir_dir` / `noise_dir` name
-the recordings (a list of files, a directory, or an array/tensor bank), which are decoded once into banks resident in
-HBM; every step draws, per clip and on the device, whether each transform applies (ir_prob / noise_prob), which
+the recordings (a list of files, a directory, or an array/tensor bank), which are decoded once into ragged banks (one flat buffer,
+no padding to the longest file) resident in HBM; every step draws, per clip and on the device, whether each transform applies (ir_prob / noise_prob), which
 recording, the noise offset and the SNR (uniform in tr_snr / val_snr dB).  With both unset the transforms are
 identities, as in the reference.  Decoding is limited to what the image can do without torchaudio: `.npy` arrays and
 PCM `.wav` files (stdlib `wave`) already at cfg['fs'].
@@ -41,10 +41,10 @@ def _read_audio(path, fs):
 
 
 def load_bank(src, fs, max_len=None):
-    """Recordings -> (bank (n, Lmax) f32 zero-padded, lengths (n) int32) on the CPU.
+    """Recordings -> ragged bank on the CPU: (flat f32 buffer, starts (n) int64, lengths (n) int32); recording r is
+    flat[starts[r] : starts[r] + lengths[r]] (no padding to the longest file).
     src: directory (searched recursively for .wav/.npy), list of files, 2-D array/tensor (rows = recordings), or a
-    list of 1-D arrays.  max_len truncates (impulse responses are cut to the clip length: later taps never reach a
-    sample of the clip)."""
+    list of 1-D arrays.  max_len truncates every recording."""
     if isinstance(src, torch.Tensor):
         src = src.detach().cpu().numpy()
     if isinstance(src, np.ndarray):
@@ -61,10 +61,8 @@ def load_bank(src, fs, max_len=None):
     if not rows:
         raise ValueError("no recordings found for the augmentation bank")
     lens = np.array([r.size for r in rows], dtype=np.int32)
-    bank = np.zeros((len(rows), int(lens.max())), dtype=np.float32)
-    for i, r in enumerate(rows):
-        bank[i, :r.size] = r
-    return torch.from_numpy(bank), torch.from_numpy(lens)
+    starts = np.concatenate([[0], np.cumsum(lens[:-1], dtype=np.int64)]).astype(np.int64)
+    return torch.from_numpy(np.concatenate(rows)), torch.from_numpy(starts), torch.from_numpy(lens)
 
 
 class GPUTransformNeuralfp(nn.Module):
@@ -78,17 +76,19 @@ class GPUTransformNeuralfp(nn.Module):
         has_ir = ir_dir is not None and not (isinstance(ir_dir, (list, tuple, str)) and len(ir_dir) == 0)
         has_noise = noise_dir is not None and not (isinstance(noise_dir, (list, tuple, str)) and len(noise_dir) == 0)
         if has_ir:
-            bank, lens = load_bank(ir_dir, cfg["fs"])
+            bank, starts, lens = load_bank(ir_dir, cfg["fs"])
             self.register_buffer("ir_bank", bank, persistent=False)
+            self.register_buffer("ir_start", starts, persistent=False)
             self.register_buffer("ir_len", lens, persistent=False)
         else:
-            self.ir_bank = self.ir_len = None
+            self.ir_bank = self.ir_start = self.ir_len = None
         if has_noise:
-            bank, lens = load_bank(noise_dir, cfg["fs"])
+            bank, starts, lens = load_bank(noise_dir, cfg["fs"])
             self.register_buffer("noise_bank", bank, persistent=False)
+            self.register_buffer("noise_start", starts, persistent=False)
             self.register_buffer("noise_len", lens, persistent=False)
         else:
-            self.noise_bank = self.noise_len = None
+            self.noise_bank = self.noise_start = self.noise_len = None
 
     # ---- the two torch_audiomentations chains (:25-48), batched on the device -------------------------
     def _rng(self, device):
@@ -108,16 +108,17 @@ class GPUTransformNeuralfp(nn.Module):
         dev, B = x.device, x.shape[0]
         g = self._rng(dev)
         if self.ir_bank is not None:
-            pick = torch.randint(0, self.ir_bank.shape[0], (B,), device=dev, generator=g)
+            pick = torch.randint(0, self.ir_len.numel(), (B,), device=dev, generator=g)
             keep = torch.rand(B, device=dev, generator=g) < ir_prob
-            x = ops.ir_convolve(x, self.ir_bank, self.ir_len, torch.where(keep, pick, torch.full_like(pick, -1)))
+            x = ops.ir_convolve(x, self.ir_bank, self.ir_len, torch.where(keep, pick, torch.full_like(pick, -1)), self.ir_start)
         if self.noise_bank is not None:
-            pick = torch.randint(0, self.noise_bank.shape[0], (B,), device=dev, generator=g)
+            pick = torch.randint(0, self.noise_len.numel(), (B,), device=dev, generator=g)
             keep = torch.rand(B, device=dev, generator=g) < noise_prob
             off = (torch.rand(B, device=dev, generator=g) * self.noise_len[pick]).long().clamp_(min=0)
             lo, hi = float(snr_range[0]), float(snr_range[1])
             snr = lo + (hi - lo) * torch.rand(B, device=dev, generator=g)
-            x = ops.mix_snr(x, self.noise_bank, self.noise_len, torch.where(keep, pick, torch.full_like(pick, -1)), off, snr)
+            x = ops.mix_snr(x, self.noise_bank, self.noise_len, torch.where(keep, pick, torch.full_like(pick, -1)), off, snr,
+                            self.noise_start)
         return x[0] if squeeze else x
 
     def _has_banks(self):

@@ -159,38 +159,50 @@ def _i32c(t, device):
     return t.detach().to(device=device, dtype=torch.int32).contiguous()
 
 
-def ir_convolve(x, ir_bank, ir_len, ir_index=None):
-    """ApplyImpulseResponse for a batch: x (B,T) f32, ir_bank (n_ir, Lmax) f32 rows, ir_len (n_ir) valid taps per
-    row, ir_index (B) row per signal (< 0: copied unchanged; None: row 0) -> (B,T), the full convolution truncated
-    to T (grafp_ir_convolve_f32)."""
+def _bank(bank, lens, device, starts=None):
+    """(flat f32 buffer, int64 starts, int32 lengths) of a recording bank.  bank: a flat 1-D buffer with `starts`, or a
+    2-D (n, Lmax) array whose row r holds recording r in its first lens[r] elements."""
+    bank = _f32c(bank)
+    lens = _i32c(lens, device)
+    if bank.dim() == 2:
+        starts = torch.arange(bank.shape[0], device=device, dtype=torch.int64) * bank.shape[1]
+        bank = bank.reshape(-1)
+    else:
+        starts = starts.detach().to(device=device, dtype=torch.int64).contiguous()
+    return bank, starts, lens
+
+
+def ir_convolve(x, ir_bank, ir_len, ir_index=None, ir_start=None):
+    """ApplyImpulseResponse for a batch: x (B,T) f32; the impulse responses as a ragged bank (flat buffer + ir_start
+    + ir_len) or a padded (n_ir, Lmax) array + ir_len; ir_index (B) recording per signal (< 0: copied unchanged;
+    None: recording 0) -> (B,T), the full convolution truncated to T (grafp_ir_convolve_f32)."""
     _require_gpu(x, ir_bank)
     squeeze = x.dim() == 1
     x2 = _f32c(x.reshape(1, -1) if squeeze else x)
-    bank = _f32c(ir_bank)
+    bank, starts, lens = _bank(ir_bank, ir_len, x2.device, ir_start)
     B, T = x2.shape
     out = torch.empty_like(x2)
-    idx = None if ir_index is None else _i32c(ir_index, x2.device)
-    lens = _i32c(ir_len, x2.device)          # (kept in locals: a temporary's block could be re-used before the launch)
-    check(lib.grafp_ir_convolve_f32(_p(x2), T, B, T, _p(bank), bank.shape[1], bank.shape[0], _p(lens), _p(idx), _p(out),
-                                    T, _stream()), "ir_convolve")
+    idx = None if ir_index is None else _i32c(ir_index, x2.device)   # (locals: a temporary's block could be re-used)
+    check(lib.grafp_ir_convolve_f32(_p(x2), T, B, T, _p(bank), _p(starts), lens.numel(), _p(lens), _p(idx), _p(out), T,
+                                    _stream()), "ir_convolve")
     return out[0] if squeeze else out
 
 
-def mix_snr(x, noise_bank, noise_len, noise_index, noise_offset, snr_db):
+def mix_snr(x, noise_bank, noise_len, noise_index, noise_offset, snr_db, noise_start=None):
     """AddBackgroundNoise for a batch: out = x + rms(x)/10^(snr/20) * n/(rms(n)+1e-8) with n the circular read of
-    noise_bank[noise_index[b]] (first noise_len samples) from noise_offset[b]; noise_index < 0: copied unchanged
-    (grafp_mix_snr_f32)."""
+    recording noise_index[b] (ragged bank: flat buffer + noise_start + noise_len, or a padded (n, Lmax) array) from
+    noise_offset[b]; noise_index < 0: copied unchanged (grafp_mix_snr_f32)."""
     _require_gpu(x, noise_bank)
     squeeze = x.dim() == 1
     x2 = _f32c(x.reshape(1, -1) if squeeze else x)
-    bank = _f32c(noise_bank)
+    bank, starts, lens = _bank(noise_bank, noise_len, x2.device, noise_start)
     B, T = x2.shape
     out = torch.empty_like(x2)
     nbytes = lib.grafp_mix_snr_workspace(B, T)
     ws = torch.empty((nbytes,), dtype=torch.uint8, device=x2.device)
-    lens, idx, off = (_i32c(t, x2.device) for t in (noise_len, noise_index, noise_offset))
+    idx, off = (_i32c(t, x2.device) for t in (noise_index, noise_offset))
     snr = _f32c(snr_db.to(x2.device))
-    check(lib.grafp_mix_snr_f32(_p(x2), T, B, T, _p(bank), bank.shape[1], bank.shape[0], _p(lens), _p(idx), _p(off),
+    check(lib.grafp_mix_snr_f32(_p(x2), T, B, T, _p(bank), _p(starts), lens.numel(), _p(lens), _p(idx), _p(off),
                                 _p(snr), _p(out), T, _p(ws), nbytes, _stream()), "mix_snr")
     return out[0] if squeeze else out
 

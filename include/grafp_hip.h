@@ -276,22 +276,23 @@ int grafp_seq_rerank_shard_f32(const float *index_rows, int64_t n_rows, int64_t 
 /* ---- device-side augmentation --------------------------------------------------------
  * Replaces the torch_audiomentations (==0.11.1, requirements.txt:4; not vendored) transforms composed at
  * modules/transformations.py:25-48 and applied per clip on DataLoader workers (:67-75) or per track (:98-107).
- * The impulse responses / noise recordings are resident (n, stride) f32 banks with per-row lengths; each of the B
- * signals picks a row by index (index < 0: the signal is copied unchanged -- the transform's probability p).
+ * The impulse responses / noise recordings are resident RAGGED f32 banks: one flat buffer, recording r = elements
+ * [start[r], start[r] + len[r]) (int64 starts, int32 lengths; no padding to the longest file); each of the B signals
+ * picks a recording by index (index < 0: the signal is copied unchanged -- the transform's probability p).
  *
  * grafp_ir_convolve_f32 -- ApplyImpulseResponse(compensate_for_propagation_delay=False):
  *   out[b][t] = sum_{l=0}^{min(t, len-1)} ir[l] * x[b][t-l],  t < T  (full convolution truncated to the input length)
  *   one fmaf chain per output in increasing l (order fixed in oracle/csrc/augment.c); out must not alias x.
- *   ir_index may be NULL (every signal uses row 0).
- * grafp_mix_snr_f32 -- AddBackgroundNoise: n[t] = bank[index[b]][(offset[b] + t) mod len] (the library concatenates
+ *   ir_index may be NULL (every signal uses recording 0).
+ * grafp_mix_snr_f32 -- AddBackgroundNoise: n[t] = recording index[b] at (offset[b] + t) mod len (the library concatenates
  *   random pieces of the file up to T samples; here one circular read from a random offset),
  *   out = x + rms(x) / 10^(snr_db[b]/20) * n / (rms(n) + 1e-8), rms over the T samples.  out may alias x. */
-int grafp_ir_convolve_f32(const float *x, int64_t x_stride, int B, int T, const float *ir_bank, int64_t ir_stride,
-                          int n_ir, const int32_t *ir_len, const int32_t *ir_index /* (B) or NULL */, float *out,
+int grafp_ir_convolve_f32(const float *x, int64_t x_stride, int B, int T, const float *ir_bank,
+                          const int64_t *ir_start, int n_ir, const int32_t *ir_len, const int32_t *ir_index /* (B) or NULL */, float *out,
                           int64_t out_stride, grafp_stream_t stream);
 size_t grafp_mix_snr_workspace(int B, int T);
-int grafp_mix_snr_f32(const float *x, int64_t x_stride, int B, int T, const float *noise_bank, int64_t noise_stride,
-                      int n_noise, const int32_t *noise_len, const int32_t *noise_index, const int32_t *noise_offset,
+int grafp_mix_snr_f32(const float *x, int64_t x_stride, int B, int T, const float *noise_bank,
+                      const int64_t *noise_start, int n_noise, const int32_t *noise_len, const int32_t *noise_index, const int32_t *noise_offset,
                       const float *snr_db, float *out, int64_t out_stride, void *ws, size_t ws_bytes,
                       grafp_stream_t stream);
 

@@ -12,7 +12,7 @@
 #include <math.h>
 #include <stdint.h>
 
-void oracle_ir_convolve(const float *x, int B, int T, const float *ir_bank, int64_t ir_stride, const int32_t *ir_len,
+void oracle_ir_convolve(const float *x, int B, int T, const float *ir_bank, const int64_t *ir_start, const int32_t *ir_len,
                         const int32_t *ir_index, float *out) {
 #pragma omp parallel for schedule(dynamic, 64) collapse(2)
     for (int b = 0; b < B; ++b)
@@ -23,7 +23,7 @@ void oracle_ir_convolve(const float *x, int B, int T, const float *ir_bank, int6
                 out[(int64_t)b * T + t] = xb[t];
                 continue;
             }
-            const float *h = ir_bank + (int64_t)ii * ir_stride;
+            const float *h = ir_bank + ir_start[ii];
             const int L = ir_len[ii];
             const int lmax = t < L - 1 ? t : L - 1;
             float acc = 0.0f;
@@ -32,7 +32,7 @@ void oracle_ir_convolve(const float *x, int B, int T, const float *ir_bank, int6
         }
 }
 
-void oracle_mix_snr(const float *x, int B, int T, const float *noise_bank, int64_t noise_stride, const int32_t *noise_len,
+void oracle_mix_snr(const float *x, int B, int T, const float *noise_bank, const int64_t *noise_start, const int32_t *noise_len,
                     const int32_t *noise_index, const int32_t *noise_offset, const float *snr_db, float *out) {
     for (int b = 0; b < B; ++b) {
         const float *xb = x + (int64_t)b * T;
@@ -42,7 +42,7 @@ void oracle_mix_snr(const float *x, int B, int T, const float *noise_bank, int64
             for (int t = 0; t < T; ++t) ob[t] = xb[t];
             continue;
         }
-        const float *nb = noise_bank + (int64_t)ni * noise_stride;
+        const float *nb = noise_bank + noise_start[ni];
         const int nl = noise_len[ni];
         double sx = 0.0, sn = 0.0;
         for (int t = 0; t < T; ++t) {

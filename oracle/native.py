@@ -47,9 +47,9 @@ def lib():
         L.oracle_seq_rerank.argtypes = [f32p, ctypes.c_int64, f32p, i64p, ctypes.c_int, i64p, i32p, ctypes.c_int,
                                         ctypes.c_int, i64p, f32p]
         L.oracle_seq_rerank.restype = ctypes.c_int
-        L.oracle_ir_convolve.argtypes = [f32p, ctypes.c_int, ctypes.c_int, f32p, ctypes.c_int64, i32p, i32p, f32p]
+        L.oracle_ir_convolve.argtypes = [f32p, ctypes.c_int, ctypes.c_int, f32p, i64p, i32p, i32p, f32p]
         L.oracle_ir_convolve.restype = None
-        L.oracle_mix_snr.argtypes = [f32p, ctypes.c_int, ctypes.c_int, f32p, ctypes.c_int64, i32p, i32p, i32p, f32p, f32p]
+        L.oracle_mix_snr.argtypes = [f32p, ctypes.c_int, ctypes.c_int, f32p, i64p, i32p, i32p, i32p, f32p, f32p]
         L.oracle_mix_snr.restype = None
         _LIB = L
     return _LIB
@@ -126,31 +126,40 @@ def _i32(a):
     return a, a.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
 
 
-def ir_convolve(x, ir_bank, ir_len, ir_index=None):
-    """x (B,T), ir_bank (n_ir,Lmax), ir_len (n_ir), ir_index (B) or None -> (B,T); csrc/augment.c (one fmaf chain per
-    output, taps ascending; full convolution truncated to T)."""
+def _ragged(bank, lens, starts):
+    bank = np.ascontiguousarray(bank, dtype=np.float32)
+    if bank.ndim == 2:                      # padded (n, Lmax) rows -> flat buffer + row starts
+        starts = np.arange(bank.shape[0], dtype=np.int64) * bank.shape[1]
+        bank = bank.reshape(-1)
+    return bank, np.ascontiguousarray(starts, dtype=np.int64), np.ascontiguousarray(lens, dtype=np.int32)
+
+
+def ir_convolve(x, ir_bank, ir_len, ir_index=None, ir_start=None):
+    """x (B,T); impulse responses as a padded (n_ir,Lmax) array or a flat buffer + ir_start; ir_len (n_ir); ir_index (B)
+    or None -> (B,T); csrc/augment.c (one fmaf chain per output, taps ascending; full convolution truncated to T)."""
     x, xp = _f32(x)
-    bank, bp = _f32(ir_bank)
-    ln, lp = _i32(ir_len)
+    bank, st, ln = _ragged(ir_bank, ir_len, ir_start)
     B, T = x.shape
     out = np.empty_like(x)
-    if ir_index is None:
-        ip = None
-    else:
+    ip = None
+    if ir_index is not None:
         ix, ip = _i32(ir_index)
-    lib().oracle_ir_convolve(xp, B, T, bp, bank.shape[1], lp, ip, out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+    lib().oracle_ir_convolve(xp, B, T, bank.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), _i64(st),
+                             ln.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), ip,
+                             out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
     return out
 
 
-def mix_snr(x, noise_bank, noise_len, noise_index, noise_offset, snr_db):
+def mix_snr(x, noise_bank, noise_len, noise_index, noise_offset, snr_db, noise_start=None):
     """AddBackgroundNoise restated (csrc/augment.c): x + rms(x)/10^(snr/20) * n/(rms(n)+1e-8), n read circularly."""
     x, xp = _f32(x)
-    bank, bp = _f32(noise_bank)
-    ln, lp = _i32(noise_len)
+    bank, st, ln = _ragged(noise_bank, noise_len, noise_start)
     ni, nip = _i32(noise_index)
     no, nop = _i32(noise_offset)
     sn, sp = _f32(snr_db)
     B, T = x.shape
     out = np.empty_like(x)
-    lib().oracle_mix_snr(xp, B, T, bp, bank.shape[1], lp, nip, nop, sp, out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+    lib().oracle_mix_snr(xp, B, T, bank.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), _i64(st),
+                         ln.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), nip, nop, sp,
+                         out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
     return out

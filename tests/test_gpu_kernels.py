@@ -808,3 +808,27 @@ def test_device_augmentation_in_the_transform(dev):
     track = x.reshape(-1)
     S_i, S_j = val(track.unsqueeze(0), track.unsqueeze(0))
     assert S_i.shape == S_j.shape and S_i.shape[0] > 1 and not torch.equal(S_i, S_j)
+
+
+def test_augmentation_ragged_banks_equal_padded(dev):
+    """Recordings stored back to back (flat buffer + starts + lengths, what load_bank produces) give the same bits as
+    the zero-padded (n, Lmax) rows, for both transforms, and match the oracle's ragged form."""
+    from grafp_amd import ops
+    from oracle import native as on
+    rng = np.random.default_rng(7)
+    lens = np.array([1500, 37, 9000], np.int32)
+    recs = [rng.standard_normal(n).astype(np.float32) * 0.2 for n in lens]
+    flat = np.concatenate(recs); starts = np.concatenate([[0], np.cumsum(lens[:-1])]).astype(np.int64)
+    padded = np.zeros((3, 9000), np.float32)
+    for i, r in enumerate(recs):
+        padded[i, :lens[i]] = r
+    x = rng.standard_normal((4, 12000)).astype(np.float32)
+    idx = np.array([2, 0, -1, 1], np.int32); off = np.array([8999, 3, 0, 36], np.int32)
+    snr = np.array([3.0, 10.0, 0.0, 20.0], np.float32)
+    T = torch.from_numpy
+    xd, fd, pd = T(x).to(dev), T(flat).to(dev), T(padded).to(dev)
+    a = ops.ir_convolve(xd, fd, T(lens), T(idx), T(starts)); b = ops.ir_convolve(xd, pd, T(lens), T(idx))
+    assert torch.equal(a, b) and np.array_equal(a.cpu().numpy(), on.ir_convolve(x, flat, lens, idx, starts))
+    c = ops.mix_snr(xd, fd, T(lens), T(idx), T(off), T(snr), T(starts)); d = ops.mix_snr(xd, pd, T(lens), T(idx), T(off), T(snr))
+    assert torch.equal(c, d)
+    np.testing.assert_allclose(c.cpu().numpy(), on.mix_snr(x, flat, lens, idx, off, snr, starts), rtol=0, atol=2e-6 * np.abs(x).max())

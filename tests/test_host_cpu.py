@@ -196,17 +196,18 @@ def test_augmentation_banks_and_cpu_branch(tmp_path):
     for name, fs in (("b.wav", cfg["fs"]), ("bad.wav", 8000)):
         with wave.open(str(tmp_path / name), "wb") as w:
             w.setnchannels(1); w.setsampwidth(2); w.setframerate(fs); w.writeframes(pcm.tobytes())
-    bank, lens = load_bank([str(tmp_path / "a.npy"), str(tmp_path / "b.wav")], cfg["fs"])
-    assert bank.shape == (2, 500) and lens.tolist() == [300, 500]
-    assert np.array_equal(bank[0, :300].numpy(), a) and float(bank[0, 300:].abs().max()) == 0.0
-    np.testing.assert_allclose(bank[1].numpy(), pcm.astype(np.float32) / 32768.0)
+    bank, starts, lens = load_bank([str(tmp_path / "a.npy"), str(tmp_path / "b.wav")], cfg["fs"])
+    assert bank.shape == (800,) and lens.tolist() == [300, 500] and starts.tolist() == [0, 300]     # ragged: no padding
+    assert np.array_equal(bank[:300].numpy(), a)
+    np.testing.assert_allclose(bank[300:].numpy(), pcm.astype(np.float32) / 32768.0)
     with pytest.raises(ValueError):
         load_bank(str(tmp_path / "bad.wav"), cfg["fs"])
     (tmp_path / "d").mkdir(); np.save(tmp_path / "d" / "x.npy", a)
-    assert load_bank(str(tmp_path / "d"), cfg["fs"])[1].tolist() == [300]
-    assert load_bank(np.ones((3, 7), np.float32), cfg["fs"], max_len=5)[0].shape == (3, 5)
+    assert load_bank(str(tmp_path / "d"), cfg["fs"])[2].tolist() == [300]
+    b3 = load_bank(np.ones((3, 7), np.float32), cfg["fs"], max_len=5)
+    assert b3[0].shape == (15,) and b3[1].tolist() == [0, 5, 10]
     t = GPUTransformNeuralfp(cfg, str(tmp_path / "d"), np.ones((2, 100), np.float32), train=True)
-    assert t.ir_bank.shape == (1, 300) and t.noise_len.tolist() == [100, 100]
+    assert t.ir_bank.shape == (300,) and t.noise_len.tolist() == [100, 100] and t.noise_start.tolist() == [0, 100]
     with pytest.raises(RuntimeError):
         t.train_transform(torch.zeros(2, 16000))           # CPU tensors: the HIP path refuses, nothing falls back
     t = GPUTransformNeuralfp(cfg, None, None, cpu=True)
