@@ -92,10 +92,13 @@ class GPUTransformNeuralfp(nn.Module):
 
     # ---- the two torch_audiomentations chains (:25-48), batched on the device -------------------------
     def _rng(self, device):
+        """Generator of the per-clip draws: torch's default device generator (advances correctly under HIP-graph
+        capture and replay), or -- with cfg['aug_seed'] -- a private seeded one (reproducible draws; eager only)."""
+        if self.seed is None:
+            return None
         if self._gen is None or self._gen.device != device:
             self._gen = torch.Generator(device=device)
-            if self.seed is not None:
-                self._gen.manual_seed(int(self.seed))
+            self._gen.manual_seed(int(self.seed))
         return self._gen
 
     def augment(self, x, ir_prob, noise_prob, snr_range):

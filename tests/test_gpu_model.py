@@ -354,3 +354,25 @@ def test_trainer_step_graph_equals_eager(dev):
         assert abs(loss_g - want_loss) <= 1e-5 * max(1.0, abs(want_loss))
         d_e, d_g = p_e - p_0, p_g - p_0
         assert float(d_e.norm()) > 0 and float((d_g - d_e).norm() / d_e.norm()) < 0.05     # atomics: not bit-equal
+
+
+def test_trainer_with_device_augmentation_eager_and_graph(dev):
+    """The training step with the second view augmented on the device (impulse responses + background noise for
+    every clip): runs eagerly and replayed from one HIP graph (the per-clip draws use the device generator, which
+    advances across replays), the loss stays finite and the augmented view differs from the clean one."""
+    from grafp_amd.train import Trainer, build_model, synthetic_batch
+    from grafp_amd.util import load_config
+    cfg = load_config(); cfg["bsz_train"] = 8
+    torch.manual_seed(0)
+    model = build_model(cfg, device=dev)
+    gen = torch.Generator(device=dev).manual_seed(1)
+    irs = torch.randn(4, 3000, generator=gen, device=dev) * torch.exp(-torch.arange(3000, device=dev) / 500.0)
+    noise = torch.randn(3, 40000, generator=gen, device=dev)
+    tr = Trainer(cfg, model, dev, amp_dtype=None, ir_dir=irs, noise_dir=noise)
+    x_i, x_j = synthetic_batch(8, seed=3, device=dev)
+    a, b = tr.augment(x_i, x_j)
+    assert not torch.equal(b, tr.augment.logmelspec(x_j))
+    l0 = float(tr.step(x_i, x_j))
+    losses = [float(tr.step_graph(x_i, x_j)) for _ in range(3)]
+    assert np.isfinite(l0) and all(np.isfinite(v) for v in losses)
+    assert len(set(losses)) > 1                      # new noise draws (and new weights) on every replay
