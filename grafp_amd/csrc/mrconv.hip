@@ -56,7 +56,7 @@ __device__ __forceinline__ void mr_st4(unsigned short *p, const float (&v)[4]) {
 }
 
 // Activations are addressed as base + b*sb + c*sc + n (N contiguous): (B,C,N) has sb = C*N, sc = N; the
-// GEMM-friendly (C,B,N) has sb = N, sc = B*N.  dynamic LDS: rows[CC*N] f32 | (bwd: acc[CC*N] f32) | sidx[K*N] i32.
+// GEMM-friendly (C,B,N) has sb = N, sc = B*N.  dynamic LDS: rows[CC*N] f32 | sidx[K*N] i32 (bwd: + acc[CC*N] i64, base f32).
 // A workgroup owns CC channel rows of one clip; thread t walks the slab's elements t*V, t*V + 256*V, ... as a
 // running (channel, node) pair -- no integer division in any loop.  V = 4 when N % 4 == 0 and the strides and
 // base pointers are 4-element aligned (always true for the encoder's shapes), else 1.
@@ -209,15 +209,21 @@ __global__ __launch_bounds__(MR_THREADS) void mrconv_bwd_kernel(const T *__restr
                                                                 const T *__restrict__ gout, int64_t g_sb, int64_t g_sc,
                                                                 T *__restrict__ dx, int C, int N, int K, int CC) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ float s_max[MR_THREADS / 64];
     const int b = blockIdx.y, c0 = blockIdx.x * CC, tid = threadIdx.x;
     const int cc = min(CC, C - c0);
-    float *rows = reinterpret_cast<float *>(smem);
-    float *acc = rows + (size_t)CC * N;
-    int *sidx = reinterpret_cast<int *>(acc + (size_t)CC * N);
+    // 64-bit fixed-point scatter accumulator + integer LDS atomics (see mrconv_bwd_p_kernel): deterministic, and
+    // ds_add_u64 is 30x the rate of ds_add_f32 on gfx950
+    const size_t slab_al = ((size_t)CC * N + 1) & ~(size_t)1;
+    long long *acc = reinterpret_cast<long long *>(smem);
+    float *rows = reinterpret_cast<float *>(acc + slab_al);
+    float *base = rows + slab_al;                                 // g_even - g_odd (identity branch minus the centre terms)
+    int *sidx = reinterpret_cast<int *>(base + slab_al);
     const T *xb = x + (size_t)b * x_sb + (size_t)c0 * x_sc;
     const T *gb = gout + (size_t)b * g_sb + (size_t)(2 * c0) * g_sc;
     float godd[BWD_ITEMS][4];
-    {   // stage x; acc <- g_even - g_odd (identity branch minus the centre term of every relative difference)
+    float m = 0.0f;
+    {   // stage x; base <- g_even - g_odd
         MR_WALK(V, tid, N, c, n);
 #pragma unroll
         for (int it = 0; it < BWD_ITEMS; ++it) {
@@ -235,15 +241,28 @@ __global__ __launch_bounds__(MR_THREADS) void mrconv_bwd_kernel(const T *__restr
 #pragma unroll
                 for (int e = 0; e < V; ++e) {
                     rows[c * N + n + e] = v[e];
-                    acc[c * N + n + e] = ge[e] - godd[it][e];
+                    acc[c * N + n + e] = 0;
+                    base[c * N + n + e] = ge[e] - godd[it][e];
+                    m = fmaxf(m, fabsf(godd[it][e]));
+                    if (!(fabsf(godd[it][e]) <= 3.0e38f)) m = INFINITY;
                 }
             }
             MR_NEXT(V, N, c, n);
         }
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((tid & 63) == 0) s_max[tid >> 6] = m;
     stage_idx<I>(sidx, idx + (size_t)b * N * K, N, K, tid);
     __syncthreads();
-    {   // route g_odd[c][m] to the arg-max neighbour of m (first maximum)
+    m = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+    const bool poisoned = !(m <= 3.0e38f);
+    int ex = 0;
+    (void)frexpf(m, &ex);
+    int sh = m > 0.0f ? 40 - ex : 0;
+    sh = sh > 100 ? 100 : sh;
+    const float scale = ldexpf(1.0f, sh), inv_scale = ldexpf(1.0f, -sh);
+    if (!poisoned) {   // route g_odd[c][m] to the arg-max neighbour of m (first maximum)
         MR_WALK(V, tid, N, c, n);
 #pragma unroll
         for (int it = 0; it < BWD_ITEMS; ++it) {
@@ -259,7 +278,8 @@ __global__ __launch_bounds__(MR_THREADS) void mrconv_bwd_kernel(const T *__restr
                         const float v = row[j] - xi;
                         if (v > best) { best = v; bj = j; }
                     }
-                    atomicAdd(&acc[c * N + bj], godd[it][e]);
+                    atomicAdd(reinterpret_cast<unsigned long long *>(&acc[c * N + bj]),
+                              (unsigned long long)__float2ll_rn(godd[it][e] * scale));
                 }
             }
             MR_NEXT(V, N, c, n);
@@ -272,10 +292,11 @@ __global__ __launch_bounds__(MR_THREADS) void mrconv_bwd_kernel(const T *__restr
         if (V == 4) {
             float v[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = acc[c * N + n + e];
+            for (int e = 0; e < 4; ++e)
+                v[e] = poisoned ? NAN : base[c * N + n + e] + __ll2float_rn(acc[c * N + n + e]) * inv_scale;
             mr_st4(db + (size_t)c * x_sc + n, v);
         } else {
-            mr_st(db + (size_t)c * x_sc + n, acc[c * N + n]);
+            mr_st(db + (size_t)c * x_sc + n, poisoned ? NAN : base[c * N + n] + __ll2float_rn(acc[c * N + n]) * inv_scale);
         }
         MR_NEXT(V, N, c, n);
     }
@@ -293,10 +314,17 @@ __global__ __launch_bounds__(MR_THREADS) void mrconv_bwd_p_kernel(const T *__res
                                                                   int64_t g_sc, T *__restrict__ dx, int C, int N, int K,
                                                                   int CC) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ float s_max[MR_THREADS / 64];
     const int b = blockIdx.y, tid = threadIdx.x;
-    float *rows = reinterpret_cast<float *>(smem);                 // [CC*N] x
-    float *acc = rows + MRB_SLAB;                                  // [CC*N] gradient accumulator
-    int *sidx = reinterpret_cast<int *>(acc + MRB_SLAB);           // [K][N]
+    // The scatter accumulates in 64-bit FIXED POINT with integer LDS atomics: ds_add_f32 runs at 0.33 lane-ops per
+    // clock per CU on gfx950, ds_add_u64 at 10 (measured, scratch/lds_atomic_bench.hip) -- the float atomics were
+    // ~160 us of this kernel's 215.  Per slab the scale is 2^(40 - e), e = exponent of the slab's largest |g_odd|:
+    // every addend is exact to 2^-40 of that maximum (bf16 and all but denormal-range f32 addends are exact), a node
+    // receives at most N <= 2048 addends (< 2^52), and the sum no longer depends on the order of the atomics: the
+    // gradient is deterministic.
+    long long *acc = reinterpret_cast<long long *>(smem);          // [CC*N] fixed-point scatter accumulator
+    float *rows = reinterpret_cast<float *>(acc + MRB_SLAB);       // [CC*N] x
+    int *sidx = reinterpret_cast<int *>(rows + MRB_SLAB);          // [K][N]
     const int nslab = (C + CC - 1) / CC;
     const T *xb = x + (size_t)b * x_sb;
     const T *gb = gout + (size_t)b * g_sb;
@@ -329,20 +357,34 @@ __global__ __launch_bounds__(MR_THREADS) void mrconv_bwd_p_kernel(const T *__res
     for (; slab < nslab; slab += gridDim.x) {
         const int c0 = slab * CC, cc = min(CC, C - c0);
         __syncthreads();                       // previous slab written out (and sidx staged, first time round)
-        float xi[MRB_ITEMS][4], godd[MRB_ITEMS][4];
+        float xi[MRB_ITEMS][4], godd[MRB_ITEMS][4], base[MRB_ITEMS][4];
+        float m = 0.0f;
 #pragma unroll
         for (int it = 0; it < MRB_ITEMS; ++it)
             if (pc[it] < cc) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     rows[pc[it] * N + pn[it] + e] = pv[it][e];
-                    acc[pc[it] * N + pn[it] + e] = pe[it][e] - po[it][e];   // identity branch minus the centre terms
+                    acc[pc[it] * N + pn[it] + e] = 0;
+                    base[it][e] = pe[it][e] - po[it][e];       // identity branch minus the centre terms
                     xi[it][e] = pv[it][e];
                     godd[it][e] = po[it][e];
+                    m = fmaxf(m, fabsf(po[it][e]));            // (fmaxf drops NaNs: they are caught below)
+                    if (!(fabsf(po[it][e]) <= 3.0e38f)) m = INFINITY;
                 }
             }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if ((tid & 63) == 0) s_max[tid >> 6] = m;
         __syncthreads();
         if (slab + gridDim.x < nslab) fetch(slab + gridDim.x);
+        m = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+        const bool poisoned = !(m <= 3.0e38f);                  // a non-finite gradient: the slab's output is NaN
+        int ex = 0;
+        (void)frexpf(m, &ex);                                   // m < 2^ex
+        int sh = m > 0.0f ? 40 - ex : 0;
+        sh = sh > 100 ? 100 : sh;
+        const float scale = ldexpf(1.0f, sh), inv_scale = ldexpf(1.0f, -sh);
         // route g_odd[c][m] to the arg-max neighbour of m (first maximum)
 #pragma unroll
         for (int it = 0; it < MRB_ITEMS; ++it) {
@@ -359,8 +401,12 @@ __global__ __launch_bounds__(MR_THREADS) void mrconv_bwd_p_kernel(const T *__res
                         if (k == 0 || v > best[e]) { best[e] = v; bj[e] = jj[e]; }
                     }
                 }
+                if (!poisoned) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) atomicAdd(&acc[pc[it] * N + bj[e]], godd[it][e]);
+                    for (int e = 0; e < 4; ++e)
+                        atomicAdd(reinterpret_cast<unsigned long long *>(&acc[pc[it] * N + bj[e]]),
+                                  (unsigned long long)__float2ll_rn(godd[it][e] * scale));
+                }
             }
         }
         __syncthreads();
@@ -369,7 +415,8 @@ __global__ __launch_bounds__(MR_THREADS) void mrconv_bwd_p_kernel(const T *__res
             if (pc[it] < cc) {
                 float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[pc[it] * N + pn[it] + e];
+                for (int e = 0; e < 4; ++e)
+                    v[e] = poisoned ? NAN : base[it][e] + __ll2float_rn(acc[pc[it] * N + pn[it] + e]) * inv_scale;
                 mr_st4(db + (size_t)(c0 + pc[it]) * x_sc + pn[it], v);
             }
     }
@@ -451,7 +498,7 @@ static int mrconv_bwd_impl(const void *x, int dtype, int64_t x_sb, int64_t x_sc,
         const int nslab = (C + ccp - 1) / ccp;
         int per_clip = nslab < 4 ? nslab : 4;
         while ((int64_t)per_clip * B < 1024 && per_clip < nslab) ++per_clip;
-        const size_t ldsp = ((size_t)2 * MRB_SLAB + (size_t)K * N) * 4;
+        const size_t ldsp = ((size_t)3 * MRB_SLAB + (size_t)K * N) * 4;      // i64 accumulator + f32 rows + edges
         if (ldsp <= 160 * 1024) {
             const dim3 gridp(per_clip, B);
 #define MR_BWDP(T, I)                                                                                                  \
@@ -474,7 +521,10 @@ static int mrconv_bwd_impl(const void *x, int dtype, int64_t x_sb, int64_t x_sc,
     if (CC > C) CC = C;
     GRAFP_REQUIRE((size_t)CC * N <= (size_t)items * per_item,
                   "mrconv_bwd: N=%d exceeds the %d nodes a workgroup covers", N, items * per_item);
-    const size_t lds = ((size_t)2 * CC * N + (size_t)K * N) * 4;
+    // i64 accumulator + f32 rows + f32 identity term per slab element, + the clip's edges
+    auto lds_of = [&](int cc_) { return ((size_t)4 * (((size_t)cc_ * N + 1) & ~(size_t)1) + (size_t)K * N) * 4; };
+    while (CC > 1 && lds_of(CC) > 160 * 1024) --CC;
+    const size_t lds = lds_of(CC);
     GRAFP_REQUIRE(lds <= 160 * 1024, "mrconv_bwd: N=%d K=%d needs %zu B of LDS (> 160 KiB)", N, K, lds);
     const dim3 grid((C + CC - 1) / CC, B);
 #define MR_BWD_II(T, V, I, IT)                                                                                         \
