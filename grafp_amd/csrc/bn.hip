@@ -26,8 +26,12 @@ template <> struct BnIO<float> {
         const float4 t = *reinterpret_cast<const float4 *>(p);
         v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
     }
+    // outputs are streamed with the non-temporal hint: a plain-store copy of a 67-268 MB tensor runs at 3.7-4.9 TB/s
+    // on MI355X, the same copy with `nt` stores at 6.2-6.7 TB/s (scratch/copy_bench.hip)
     __device__ static void store(float *p, const float (&v)[4]) {
-        *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const f4 t = {v[0], v[1], v[2], v[3]};
+        __builtin_nontemporal_store(t, reinterpret_cast<f4 *>(p));
     }
     using Raw = float4;
     __device__ static void unpack(const float4 &t, float (&v)[4]) { v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
@@ -55,7 +59,9 @@ template <> struct BnIO<unsigned short> {
         unsigned w[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) w[i] = (unsigned)f2bf(v[2 * i]) | ((unsigned)f2bf(v[2 * i + 1]) << 16);
-        *reinterpret_cast<uint4 *>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+        typedef unsigned u4 __attribute__((ext_vector_type(4)));
+        const u4 t = {w[0], w[1], w[2], w[3]};
+        __builtin_nontemporal_store(t, reinterpret_cast<u4 *>(p));
     }
     using Raw = uint4;
     __device__ static void unpack(const uint4 &t, float (&v)[8]) {

@@ -48,11 +48,16 @@ __device__ __forceinline__ unsigned mr_pack(float lo, float hi) {
     mr_st(&a, lo); mr_st(&b, hi);
     return (unsigned)a | ((unsigned)b << 16);
 }
+// (outputs are streamed with the non-temporal hint: +35-65 % on a plain copy of tensors this size, scratch/copy_bench.hip)
 __device__ __forceinline__ void mr_st4(float *p, const float (&v)[4]) {
-    *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 t = {v[0], v[1], v[2], v[3]};
+    __builtin_nontemporal_store(t, reinterpret_cast<f4 *>(p));
 }
 __device__ __forceinline__ void mr_st4(unsigned short *p, const float (&v)[4]) {
-    *reinterpret_cast<uint2 *>(p) = make_uint2(mr_pack(v[0], v[1]), mr_pack(v[2], v[3]));
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    const u2 t = {mr_pack(v[0], v[1]), mr_pack(v[2], v[3])};
+    __builtin_nontemporal_store(t, reinterpret_cast<u2 *>(p));
 }
 
 // Activations are addressed as base + b*sb + c*sc + n (N contiguous): (B,C,N) has sb = C*N, sc = N; the
