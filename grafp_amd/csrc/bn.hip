@@ -354,9 +354,10 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_dx_kernel(const T *__restri
 // Cross-XCD visibility: slots and counters move with agent-scope relaxed atomics, i.e. sc1 write-through stores and
 // L2-bypassing loads (the per-XCD L2s are not coherent for plain accesses); no L2 writeback/invalidate.  The wait
 // is bounded: a lost rendezvous traps instead of hanging the device.
-constexpr int BN1_ITEMS = 8;                           // 16-byte vectors per thread, kept RAW (bf16 stays packed): 32 VGPRs
+constexpr int BN1_ITEMS_FWD = 8;                       // 16-byte vectors per thread, kept RAW (bf16 stays packed)
+constexpr int BN1_ITEMS_BWD = 4;                       // per operand (x and dz); measured: fwd 8 / bwd 4 beat 4/4 and 8/8
 constexpr int BN1_THREADS = 256;
-constexpr int BN1_MIN_CHUNK = BN1_THREADS * BN1_ITEMS * 4;   // elements per workgroup: 8192 f32 / 16384 bf16
+constexpr int BN1_MIN_CHUNK = BN1_THREADS * BN1_ITEMS_BWD * 4;   // elements per workgroup: 8192 f32 / 16384 bf16
 constexpr int BN1_MAX_S = 256;                         // workgroups per row
 constexpr int BN1_SYNC_STRIDE = 64;                    // ints between row counters: one 256-byte line each, so the
                                                        // polls and arrivals of different rows never share a channel queue
@@ -417,7 +418,7 @@ __global__ __launch_bounds__(BN1_THREADS) void bn_fwd1_kernel(const T *__restric
                                                              int *__restrict__ sync, T *__restrict__ out,
                                                              float *__restrict__ save_mean,
                                                              float *__restrict__ save_invstd) {
-    constexpr int W = BnIO<T>::W, ITEMS = BN1_ITEMS, CHUNK = BN1_THREADS * ITEMS * W;
+    constexpr int W = BnIO<T>::W, ITEMS = BN1_ITEMS_FWD, CHUNK = BN1_THREADS * ITEMS * W;
     __shared__ float2 scratch[BN1_THREADS / 64];
     __shared__ float2 sp[BN1_MAX_S];
     const int c = blockIdx.y, s = blockIdx.x, tid = threadIdx.x;
@@ -520,7 +521,7 @@ __global__ __launch_bounds__(BN1_THREADS) void bn_bwd1_kernel(const T *__restric
                                                              int *__restrict__ sync, T *__restrict__ dx,
                                                              float *__restrict__ dgamma, float *__restrict__ dbeta,
                                                              float *__restrict__ dpre_bias) {
-    constexpr int W = BnIO<T>::W, ITEMS = BN1_ITEMS, CHUNK = BN1_THREADS * ITEMS * W;
+    constexpr int W = BnIO<T>::W, ITEMS = BN1_ITEMS_BWD, CHUNK = BN1_THREADS * ITEMS * W;
     __shared__ float2 scratch[BN1_THREADS / 64];
     __shared__ float2 sp[BN1_MAX_S];
     const int c = blockIdx.y, s = blockIdx.x, tid = threadIdx.x;
@@ -601,9 +602,9 @@ __global__ __launch_bounds__(BN1_THREADS) void bn_bwd1_kernel(const T *__restric
 }
 
 // single-pass plan: Sg chunks per group, or 0 when the shape does not qualify
-static int bn1_plan(int64_t Mg, int G, int W) {
+static int bn1_plan(int64_t Mg, int G, int W, int items) {
     if (Mg % W) return 0;
-    const int64_t chunk = (int64_t)BN1_THREADS * BN1_ITEMS * W;
+    const int64_t chunk = (int64_t)BN1_THREADS * items * W;
     const int64_t Sg = (Mg + chunk - 1) / chunk;
     if (Sg * G > BN1_MAX_S) return 0;
     return (int)Sg;
@@ -670,7 +671,7 @@ extern "C" int grafp_bn_fwd_1pass(const void *x, int dtype, int C, int64_t M, in
     if (sync && training) {
         const bool f32 = dtype == GRAFP_F32;
         const bool ok = f32 ? bn_vec_ok<float>(x, out, residual, nullptr, Mg) : bn_vec_ok<unsigned short>(x, out, residual, nullptr, Mg);
-        const int Sg = ok ? bn1_plan(Mg, G, f32 ? 4 : 8) : 0;
+        const int Sg = ok ? bn1_plan(Mg, G, f32 ? 4 : 8, BN1_ITEMS_FWD) : 0;
         if (Sg > 0) {
             const dim3 grid(Sg * G, C);
             if (f32)
@@ -737,7 +738,7 @@ extern "C" int grafp_bn_bwd_1pass(const void *x, const void *dz, int dtype, int 
     if (sync && training) {
         const bool f32 = dtype == GRAFP_F32;
         const bool ok = f32 ? bn_vec_ok<float>(x, dz, dx, nullptr, Mg) : bn_vec_ok<unsigned short>(x, dz, dx, nullptr, Mg);
-        const int Sg = ok ? bn1_plan(Mg, G, f32 ? 4 : 8) : 0;
+        const int Sg = ok ? bn1_plan(Mg, G, f32 ? 4 : 8, BN1_ITEMS_BWD) : 0;
         if (Sg > 0) {
             const dim3 grid(Sg * G, C);
             if (f32)

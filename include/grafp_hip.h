@@ -165,7 +165,7 @@ int grafp_bn_bwd(const void *x, const void *dz, int dtype, int C, int64_t M, int
                  int training, void *dx, float *dgamma, float *dbeta, float *dpre_bias /* (C) or NULL */, void *ws,
                  size_t ws_bytes, grafp_stream_t stream);
 /* Single-pass forms of the two entries above (same arguments, results and reference call sites, plus `sync`):
- * in training mode each workgroup keeps its chunk of a row (8192 f32 / 16384 bf16 elements) in registers across a row-wide rendezvous,
+ * in training mode each workgroup keeps its chunk of a row (a few thousand elements, bf16 left packed) in registers across a row-wide rendezvous,
  * so x (and dz) cross HBM once instead of twice -- forward 3 -> 2 passes, backward 5 -> 3.
  *   sync  grafp_bn_sync_bytes(C, M) bytes, 8-byte aligned, ALL ONES (0xff) on entry; the call leaves it all ones
  *         again (so one buffer, filled once, serves every call enqueued on the same stream).  NULL, eval mode, rows
