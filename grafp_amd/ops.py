@@ -494,6 +494,9 @@ def _block_diag_weight(w, groups, dtype=None):
     return out.reshape(cout, groups * cin_g)
 
 
+_GROUPED_BMM_MIN = int(os.environ.get("GRAFP_GROUPED_BMM_MIN", "128"))   # channels per group from which the grouped conv runs as a batched GEMM
+
+
 class _Conv1x1(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, groups, w_lowp=None):
@@ -503,6 +506,16 @@ class _Conv1x1(torch.autograd.Function):
         # w may be the 4-D Conv2d parameter itself (Cout, Cin/g, 1, 1): taking it un-reshaped keeps a view node out of
         # the graph, so the weight gradient returned below is adopted as .grad without a copy
         w2 = w.detach().reshape(w.shape[0], -1)
+        batched = groups > 1 and w2.shape[1] >= _GROUPED_BMM_MIN and x.is_cuda
+        if batched:
+            # wide groups (stages 2-3: 128 / 256 channels per group): a `groups`-batch GEMM; the dense block-diagonal
+            # form spends 4x the flops, which at 1024 x 1024 is no longer free next to the operand traffic
+            w3 = w2.to(x.dtype).reshape(groups, w2.shape[0] // groups, w2.shape[1])
+            y = torch.bmm(w3, x.reshape(groups, w2.shape[1], -1)).reshape(w2.shape[0], -1)
+            ctx.save_for_backward(x, w3)
+            ctx.groups, ctx.wshape, ctx.wfull, ctx.batched = groups, tuple(w2.shape), tuple(w.shape), True
+            return y
+        ctx.batched = False
         if groups > 1:
             dense = _block_diag_weight(w2, groups, x.dtype)
         elif w_lowp is not None and w_lowp.dtype == x.dtype and w_lowp.numel() == w.numel():
@@ -520,7 +533,12 @@ class _Conv1x1(torch.autograd.Function):
         groups = ctx.groups
         cout, cin_g = ctx.wshape
         g = g.detach().to(x.dtype).contiguous()
-        dx = torch.mm(dense.t(), g) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if ctx.batched:
+                dx = torch.bmm(dense.transpose(1, 2), g.reshape(groups, cout // groups, -1)).reshape(x.shape)
+            else:
+                dx = torch.mm(dense.t(), g)
         dw = None
         if ctx.needs_input_grad[1]:
             cin, M = x.shape
