@@ -346,8 +346,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_dx_kernel(const T *__restri
 
 // ---- single-pass variants: the chunk stays in registers across a row-wide rendezvous --------------------------
 // The two-kernel forms above read X twice (forward) or X and dZ twice (backward).  Here a workgroup keeps its chunk
-// (eight 16-byte vectors per thread, bf16 left packed) in VGPRs, publishes its partial sums, waits until all S workgroups of ITS ROW have
-// published (the S workgroups of a row have consecutive block ids and are dispatched together -- the
+// (8 / 4 16-byte vectors per thread and operand, bf16 left packed) in VGPRs, publishes its partial sums, waits until
+// all S workgroups of ITS ROW have published (the S workgroups of a row have consecutive block ids and are dispatched together -- the
 // forward-progress assumption of a decoupled look-back scan), reduces the partials in the fixed order the two-kernel
 // form uses, and finishes from registers: forward 3 -> 2 passes over HBM, backward 5 -> 3.
 // `sync` = one counter line per row followed by S 8-byte slots per row, ALL ONES on entry and again on exit.
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_dx_kernel(const T *__restri
 constexpr int BN1_ITEMS_FWD = 8;                       // 16-byte vectors per thread, kept RAW (bf16 stays packed)
 constexpr int BN1_ITEMS_BWD = 4;                       // per operand (x and dz); measured: fwd 8 / bwd 4 beat 4/4 and 8/8
 constexpr int BN1_THREADS = 256;
-constexpr int BN1_MIN_CHUNK = BN1_THREADS * BN1_ITEMS_BWD * 4;   // elements per workgroup: 8192 f32 / 16384 bf16
+constexpr int BN1_MIN_CHUNK = BN1_THREADS * BN1_ITEMS_BWD * 4;   // smallest chunk (f32 backward): bounds the slots per row
 constexpr int BN1_MAX_S = 256;                         // workgroups per row
 constexpr int BN1_SYNC_STRIDE = 64;                    // ints between row counters: one 256-byte line each, so the
                                                        // polls and arrivals of different rows never share a channel queue
