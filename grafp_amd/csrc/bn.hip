@@ -27,7 +27,7 @@ template <> struct BnIO<float> {
         v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
     }
     // outputs are streamed with the non-temporal hint: a plain-store copy of a 67-268 MB tensor runs at 3.7-4.9 TB/s
-    // on MI355X, the same copy with `nt` stores at 6.2-6.7 TB/s (scratch/copy_bench.hip)
+    // on MI355X, the same copy with `nt` stores at 6.2-6.7 TB/s (tools/microbench/copy_bench.hip)
     __device__ static void store(float *p, const float (&v)[4]) {
         typedef float f4 __attribute__((ext_vector_type(4)));
         const f4 t = {v[0], v[1], v[2], v[3]};

@@ -48,7 +48,7 @@ __device__ __forceinline__ unsigned mr_pack(float lo, float hi) {
     mr_st(&a, lo); mr_st(&b, hi);
     return (unsigned)a | ((unsigned)b << 16);
 }
-// (outputs are streamed with the non-temporal hint: +35-65 % on a plain copy of tensors this size, scratch/copy_bench.hip)
+// (outputs are streamed with the non-temporal hint: +35-65 % on a plain copy of tensors this size, tools/microbench/copy_bench.hip)
 __device__ __forceinline__ void mr_st4(float *p, const float (&v)[4]) {
     typedef float f4 __attribute__((ext_vector_type(4)));
     const f4 t = {v[0], v[1], v[2], v[3]};
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(MR_THREADS) void mrconv_bwd_p_kernel(const T *__res
     __shared__ float s_max[MR_THREADS / 64];
     const int b = blockIdx.y, tid = threadIdx.x;
     // The scatter accumulates in 64-bit FIXED POINT with integer LDS atomics: ds_add_f32 runs at 0.33 lane-ops per
-    // clock per CU on gfx950, ds_add_u64 at 10 (measured, scratch/lds_atomic_bench.hip) -- the float atomics were
+    // clock per CU on gfx950, ds_add_u64 at 10 (measured, tools/microbench/lds_atomic_bench.hip) -- the float atomics were
     // ~160 us of this kernel's 215.  Per slab the scale is 2^(40 - e), e = exponent of the slab's largest |g_odd|:
     // every addend is exact to 2^-40 of that maximum (bf16 and all but denormal-range f32 addends are exact), a node
     // receives at most N <= 2048 addends (< 2^52), and the sum no longer depends on the order of the atomics: the
