@@ -211,7 +211,34 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const T *__restric
     const int64_t gend = (int64_t)(grp + 1) * Mg;
     const int64_t lo = (int64_t)grp * Mg + (int64_t)sl * chunk, hi = (lo + chunk < gend) ? lo + chunk : gend;
     constexpr int W = VEC ? BnIO<T>::W : 1;
-    for (int64_t m = lo + (int64_t)tid * W; m < hi; m += (int64_t)BN_THREADS * W) {
+    int64_t m = lo + (int64_t)tid * W;
+    if (VEC) {
+        // four vectors in flight per thread (one load -> use -> store per iteration left the kernel latency-bound at
+        // ~4.7 TB/s; this is the eval-mode / fingerprinting path)
+        constexpr int U = 4;
+        const int64_t step = (int64_t)BN_THREADS * W;
+        for (; m + (U - 1) * step + W <= hi; m += U * step) {
+            typename BnIO<T>::Raw rx[U], rr[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                rx[u] = *reinterpret_cast<const typename BnIO<T>::Raw *>(row + m + u * step);
+                if (rrow) rr[u] = *reinterpret_cast<const typename BnIO<T>::Raw *>(rrow + m + u * step);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float v[BnIO<T>::W], r[BnIO<T>::W];
+                BnIO<T>::unpack(rx[u], v);
+                if (rrow) BnIO<T>::unpack(rr[u], r);
+#pragma unroll
+                for (int i = 0; i < BnIO<T>::W; ++i) {
+                    v[i] = act_fwd(__builtin_fmaf(v[i], g, off), act, slope);
+                    if (rrow) v[i] += r[i];
+                }
+                BnIO<T>::store(orow + m + u * step, v);
+            }
+        }
+    }
+    for (; m < hi; m += (int64_t)BN_THREADS * W) {
         if (VEC && m + W <= hi) {
             float v[BnIO<T>::W], r[BnIO<T>::W];
             BnIO<T>::load(row + m, v);
@@ -406,7 +433,7 @@ __device__ __forceinline__ void bn1_rearm(int old, int S, int *counter, unsigned
     }
 }
 
-template <typename T>
+template <typename T, bool RES>
 __global__ __launch_bounds__(BN1_THREADS) void bn_fwd1_kernel(const T *__restrict__ x, int64_t M, int64_t Mg, int Sg,
                                                              int G, const float *__restrict__ pre_bias,
                                                              const float *__restrict__ gamma,
@@ -450,6 +477,17 @@ __global__ __launch_bounds__(BN1_THREADS) void bn_fwd1_kernel(const T *__restric
             }
         }
     }
+    // the shortcut rows do not depend on the statistics: fetch them now, so their latency passes during the rendezvous
+    // (RES is a template parameter: the 32 extra registers only exist in the instantiation that needs them)
+    const T *rrow = RES ? residual + (size_t)c * M : nullptr;
+    typename BnIO<T>::Raw rres[RES ? ITEMS : 1];
+    if (RES) {
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            const int64_t m = lo + ((int64_t)it * BN1_THREADS + tid) * W;
+            if (m < hi) rres[it] = *reinterpret_cast<const typename BnIO<T>::Raw *>(rrow + m);
+        }
+    }
     const float2 r = block_sum2<BN1_THREADS>(a, q, scratch, tid);
     unsigned long long *slots_row = reinterpret_cast<unsigned long long *>(sync + (size_t)gridDim.y * BN1_SYNC_STRIDE) + (size_t)c * S;
     int *counter = sync + (size_t)c * BN1_SYNC_STRIDE;
@@ -489,7 +527,6 @@ __global__ __launch_bounds__(BN1_THREADS) void bn_fwd1_kernel(const T *__restric
     }
     const float g = gamma[c] * invstd;
     const float off = beta[c] + (pb - mean) * g;
-    const T *rrow = residual ? residual + (size_t)c * M : nullptr;
     T *orow = out + (size_t)c * M;
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
@@ -497,11 +534,11 @@ __global__ __launch_bounds__(BN1_THREADS) void bn_fwd1_kernel(const T *__restric
         if (m < hi) {
             float v[W], rr[W];
             BnIO<T>::unpack(raw[it], v);
-            if (rrow) BnIO<T>::load(rrow + m, rr);
+            if (RES) BnIO<T>::unpack(rres[it], rr);
 #pragma unroll
             for (int i = 0; i < W; ++i) {
                 v[i] = act_fwd(__builtin_fmaf(v[i], g, off), act, slope);
-                if (rrow) v[i] += rr[i];
+                if (RES) v[i] += rr[i];
             }
             BnIO<T>::store(orow + m, v);
         }
@@ -674,15 +711,13 @@ extern "C" int grafp_bn_fwd_1pass(const void *x, int dtype, int C, int64_t M, in
         const int Sg = ok ? bn1_plan(Mg, G, f32 ? 4 : 8, BN1_ITEMS_FWD) : 0;
         if (Sg > 0) {
             const dim3 grid(Sg * G, C);
-            if (f32)
-                hipLaunchKernelGGL((bn_fwd1_kernel<float>), grid, dim3(BN1_THREADS), 0, s, (const float *)x, M, Mg, Sg, G,
-                                   pre_bias, gamma, beta, (const float *)residual, act, slope, eps, momentum,
-                                   running_mean, running_var, (int *)sync, (float *)out, save_mean, save_invstd);
-            else
-                hipLaunchKernelGGL((bn_fwd1_kernel<unsigned short>), grid, dim3(BN1_THREADS), 0, s,
-                                   (const unsigned short *)x, M, Mg, Sg, G, pre_bias, gamma, beta,
-                                   (const unsigned short *)residual, act, slope, eps, momentum, running_mean,
-                                   running_var, (int *)sync, (unsigned short *)out, save_mean, save_invstd);
+#define BN_FWD1(T, RES)                                                                                                \
+    hipLaunchKernelGGL((bn_fwd1_kernel<T, RES>), grid, dim3(BN1_THREADS), 0, s, (const T *)x, M, Mg, Sg, G, pre_bias,  \
+                       gamma, beta, (const T *)residual, act, slope, eps, momentum, running_mean, running_var,         \
+                       (int *)sync, (T *)out, save_mean, save_invstd)
+            if (f32) { if (residual) BN_FWD1(float, true); else BN_FWD1(float, false); }
+            else { if (residual) BN_FWD1(unsigned short, true); else BN_FWD1(unsigned short, false); }
+#undef BN_FWD1
             GRAFP_CHECK_LAUNCH("bn_fwd1_kernel");
             return GRAFP_OK;
         }
