@@ -135,7 +135,10 @@ class GraphEncoder(nn.Module):
                     x = mod[1].forward_cbn(mod[0].forward_cbn(x, g), g)
         # readout: mean over nodes commutes with the (linear) 1x1 projection -- project the (C,B) means instead
         # of the (C,B,N) activations (graph_encoder.py:187-188 projects first: same result, 128x the work)
-        pooled = x.float().mean(dim=2)                                              # (C, B)
-        w = self.proj.weight.reshape(self.proj.out_channels, -1)
-        h = torch.mm(w, pooled.to(w.dtype)) + self.proj.bias.reshape(-1, 1)
+        # Always f32, also under bf16 autocast: B*512 numbers per step, and it keeps the embedding one rounding-free
+        # function of the last block's (bf16-stored) node features.
+        with torch.autocast("cuda", enabled=False):
+            pooled = x.float().mean(dim=2)                                          # (C, B)
+            w = self.proj.weight.reshape(self.proj.out_channels, -1)
+            h = torch.mm(w.float(), pooled) + self.proj.bias.float().reshape(-1, 1)
         return h.t().contiguous()

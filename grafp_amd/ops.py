@@ -603,6 +603,64 @@ class lowp_weights:
 
 
 # ------------------------------------------------------------------------------------------------
+# K9  the 1x1 convolution as the hand-written streaming GEMM (gemm.hip), BatchNorm statistics / normalisation folded in
+# ------------------------------------------------------------------------------------------------
+def gemm_supported(R, K, groups, M, views=1):
+    return bool(lib.grafp_conv1x1_gemm_supported(int(R), int(K), int(groups), int(M), int(views)))
+
+
+def conv1x1_gemm(w, x, groups=1, views=1, pro_tab=None, pro_act=ACT_NONE, pro_slope=0.0, stats=False):
+    """y = W f(x): w (R, K/groups) bf16, x (K, M) bf16 rows -> y (R, M) bf16 [, partial statistics (R, views, P, 3) f32].
+    pro_tab (K, views, 2) f32: f(x) = act(x * scale + shift) applied to the operand tile on the fly (the BatchNorm +
+    activation of the layer that produced x); stats: shifted sums of the rounded outputs for bn_finalize."""
+    _require_gpu(w, x)
+    if w.dtype != torch.bfloat16 or x.dtype != torch.bfloat16:
+        raise TypeError("conv1x1_gemm: bf16 operands")
+    w, x = w.contiguous(), x.contiguous()
+    R, K, M = w.shape[0], x.shape[0], x.shape[1]
+    if w.shape[1] * groups != K:
+        raise ValueError(f"conv1x1_gemm: weight {tuple(w.shape)} x groups {groups} does not match {K} operand rows")
+    y = torch.empty((R, M), dtype=torch.bfloat16, device=x.device)
+    part = None
+    if stats:
+        P = lib.grafp_conv1x1_gemm_partials(R, K, groups, M, views)
+        part = torch.empty((R, views, max(P, 1), 3), dtype=torch.float32, device=x.device)
+    tab = None if pro_tab is None else _f32c(pro_tab)
+    with _timed("conv1x1_gemm", (R, K, groups, M)):
+        check(lib.grafp_conv1x1_gemm_bf16(_p(w), _p(x), R, K, groups, M, views, _p(tab), int(pro_act), float(pro_slope),
+                                          _p(y), _p(part), _stream()), "conv1x1_gemm")
+    return (y, part) if stats else y
+
+
+def bn_finalize(part, C, K, groups, M, views, gamma, beta, pre_bias, running_mean, running_var, training, momentum, eps):
+    """GEMM partial sums (or, in eval mode, the running statistics) -> (mean (C,views), invstd (C,views),
+    tab (C,views,2) = (scale, shift) with z = act(y * scale + shift)); advances the running statistics when training."""
+    dev = gamma.device
+    mean = torch.empty((C, views), dtype=torch.float32, device=dev)
+    invstd = torch.empty((C, views), dtype=torch.float32, device=dev)
+    tab = torch.empty((C, views, 2), dtype=torch.float32, device=dev)
+    g32, b32 = _f32c(gamma), _f32c(beta)
+    pb = None if pre_bias is None else _f32c(pre_bias)
+    check(lib.grafp_bn_finalize(_p(part), C, K, groups, M, views, _p(pb), _p(g32), _p(b32), float(eps), float(momentum),
+                                int(bool(training)), _p(running_mean), _p(running_var), _p(mean), _p(invstd), _p(tab),
+                                _stream()), "bn_finalize")
+    return mean, invstd, tab
+
+
+def bn_affine(y, tab, views=1, residual=None, act=ACT_NONE, slope=0.0):
+    """z = act(y * scale + shift) + residual over bf16 (C, M) rows (one read [+ residual], one write)."""
+    _require_gpu(y, tab)
+    y = y.contiguous()
+    C, M = y.shape[0], y.numel() // y.shape[0]
+    res = None if residual is None else residual.to(torch.bfloat16).contiguous()
+    out = torch.empty_like(y)
+    with _timed("bn_affine", (C, M)):
+        check(lib.grafp_bn_affine_bf16(_p(y), C, M, views, _p(tab), _p(res), int(act), float(slope), _p(out), _stream()),
+              "bn_affine")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
 # K12  NT-Xent
 # ------------------------------------------------------------------------------------------------
 class _NTXent(torch.autograd.Function):

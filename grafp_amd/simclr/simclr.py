@@ -28,7 +28,9 @@ class SimCLR(nn.Module):
         if self.peak_extractor is not None:
             x = self.peak_extractor(x)
         h = self.encoder(x, views=views) if views > 1 else self.encoder(x)
-        return h, F.normalize(self.projector(h), p=2)
+        # the projector head is two (B x 1024 x 128)-sized products: it stays in f32 under bf16 autocast
+        with torch.autocast(h.device.type, enabled=False):
+            return h, F.normalize(self.projector(h.float()), p=2)
 
     def forward(self, x_i, x_j):
         if self.fuse_views and x_i.shape == x_j.shape and x_i.shape[0] > 0:

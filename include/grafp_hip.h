@@ -183,6 +183,40 @@ int grafp_bn_bwd_1pass(const void *x, const void *dz, int dtype, int C, int64_t 
                        float *dpre_bias /* (C) or NULL */, void *ws, size_t ws_bytes, int32_t *sync,
                        grafp_stream_t stream);
 
+/* ---- K9 forward / data gradient: the 1x1 convolution itself as a streaming bf16 GEMM, BatchNorm folded in ----
+ * y[r][m] = sum_k w[r][k] * f(x[k][m]) for every Conv2d(1x1) of the encoder (encoder/gcn_lib/torch_vertex.py:152-162,
+ * torch_nn.py:56-60, encoder/graph_encoder.py:21-24,52-55) and, with w transposed by the caller, its data gradient
+ * (autograd of the same lines).  w (R, K/groups) bf16 row-major (the Conv2d weight layout: group g owns rows
+ * [g*R/groups, ...) and operand rows [g*K/groups, ...)), x (K, M) bf16, y (R, M) bf16, rows contiguous, 16-byte aligned.
+ *   views      number of equal column segments with separate BatchNorm statistics (the views of a contrastive batch)
+ *   pro_tab    NULL, or (K, views, 2) f32 (scale, shift): f(x) = act(x * scale + shift), i.e. the BatchNorm +
+ *              activation of the layer that PRODUCED x, applied while the operand tile sits in LDS (its normalised
+ *              output is then never written: torch_nn.py:59-62 -> torch_vertex.py:160; graph_encoder.py:53-54,62-64);
+ *              pro_act: 0 none, 1 ReLU, 2 LeakyReLU(pro_slope)
+ *   stats_part NULL, or (R, views, P, 3) f32 with P = grafp_conv1x1_gemm_partials(...): per output row and view the
+ *              shifted sums of the ROUNDED outputs (sum(y - s), sum((y - s)^2), s), which grafp_bn_finalize turns into
+ *              the batch statistics of the BatchNorm that follows (torch_nn.py:60; torch_vertex.py:153,161)
+ * Shapes: rows per group a multiple of 32, K per group a multiple of 32, columns per view a multiple of 128
+ * (grafp_conv1x1_gemm_supported); anything else is the caller's library GEMM. */
+int grafp_conv1x1_gemm_supported(int R, int K, int groups, int64_t M, int views);
+int grafp_conv1x1_gemm_partials(int R, int K, int groups, int64_t M, int views);
+int grafp_conv1x1_gemm_bf16(const void *w, const void *x, int R, int K, int groups, int64_t M, int views,
+                            const float *pro_tab, int pro_act, float pro_slope, void *y, float *stats_part,
+                            grafp_stream_t stream);
+/* BatchNorm2d statistics from the GEMM's partial sums (training != 0; nn.BatchNorm2d semantics as grafp_bn_fwd:
+ * biased variance for the normalisation, unbiased for the running update, once per view in order) or from the running
+ * statistics (training == 0, stats_part ignored).  (C, K, groups, M, views) are the arguments of the GEMM launch that
+ * wrote stats_part.  Writes save_mean / save_invstd (C, views) for grafp_bn_bwd and tab (C, views, 2) =
+ * (gamma * invstd, beta + (pre_bias - mean) * gamma * invstd): z = act(y * tab.x + tab.y). */
+int grafp_bn_finalize(const float *stats_part, int C, int K, int groups, int64_t M, int views, const float *pre_bias,
+                      const float *gamma, const float *beta, float eps, float momentum, int training,
+                      float *running_mean, float *running_var, float *save_mean, float *save_invstd, float *tab,
+                      grafp_stream_t stream);
+/* out = act(y * tab.x + tab.y) + residual over bf16 (C, M) rows: the apply half of BatchNorm + activation + shortcut
+ * (torch_vertex.py:191-193, graph_encoder.py:65) for outputs that ARE materialised; one read (+ residual), one write. */
+int grafp_bn_affine_bf16(const void *y, int C, int64_t M, int views, const float *tab, const void *residual, int act,
+                         float slope, void *out, grafp_stream_t stream);
+
 /* ---- K9 backward: weight gradient of a 1x1 convolution on the (C, M) layout ------------------------------
  * dW[o][c] = sum_m grad_out[o][m] * x[c][m] for every 1x1 Conv2d of the encoder (torch_vertex.py:152-162,
  * torch_nn.py:56, graph_encoder.py:52-55,131): tiny output, contraction over M = B*N with both operands contiguous

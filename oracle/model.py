@@ -116,46 +116,73 @@ def _bn(sd, name, x, train, momentum=0.1, eps=1e-5):
                         sd[name + ".weight"], sd[name + ".bias"], train, momentum, eps)
 
 
-def _conv1x1(sd, name, x, groups=1):
-    return F.conv2d(x, sd[name + ".weight"], sd.get(name + ".bias"), groups=groups)
+def round_bf16(x):
+    """Round-to-nearest-even to bfloat16, returned as f32: the storage rounding of the bf16 mode."""
+    return x.to(torch.bfloat16).to(torch.float32)
 
 
-def grapher(sd, p, x, k, train, idx_fn=knn_graph_torch):
-    """torch_vertex.py:183-194.  x (B,C,N,1)."""
+def _conv1x1(sd, name, x, groups=1, q=None, **conv_kw):
+    """q = None: the reference's f32 convolution.  q = round_bf16: the bf16 mode of the HIP path restated -- operands
+    rounded to bf16, products accumulated in f32, the bias-free output rounded to bf16 for storage, the conv bias
+    added in f32 by the normalisation that follows (grafp_amd/encoder/_dense.py: `pre_bias`)."""
+    if q is None:
+        return F.conv2d(x, sd[name + ".weight"], sd.get(name + ".bias"), groups=groups, **conv_kw)
+    y = q(F.conv2d(q(x), q(sd[name + ".weight"]), None, groups=groups, **conv_kw))
+    b = sd.get(name + ".bias")
+    return y if b is None else y + b.reshape(1, -1, 1, 1)
+
+
+def _q(q, x):
+    return x if q is None else q(x)
+
+
+def _notap(name, t):
+    return t
+
+
+def grapher(sd, p, x, k, train, idx_fn=knn_graph_torch, q=None, tap=None):
+    """torch_vertex.py:183-194.  x (B,C,N,1).  q: storage rounding of the bf16 mode (see _conv1x1); tap(name, tensor)
+    sees (and may replace) every stored activation -- the layer-by-layer comparisons of tests/test_gpu_bf16.py."""
+    tap = tap or _notap
     short = x
-    x = _bn(sd, p + "fc1.1", _conv1x1(sd, p + "fc1.0", x), train)
+    x = tap(p + "fc1", _q(q, _bn(sd, p + "fc1.1", _conv1x1(sd, p + "fc1.0", x, q=q), train)))
     idx = idx_fn(x.squeeze(-1), k)
-    m = max_relative(x.squeeze(-1), idx).unsqueeze(-1)
+    m = tap(p + "mr", _q(q, max_relative(x.squeeze(-1), idx).unsqueeze(-1)))
     g = p + "graph_conv.gconv.nn."
-    m = F.relu(_bn(sd, g + "1", _conv1x1(sd, g + "0", m, groups=4), train))
-    x = _bn(sd, p + "fc2.1", _conv1x1(sd, p + "fc2.0", m), train)
-    return x + short
+    m = tap(g + "0", _q(q, F.relu(_bn(sd, g + "1", _conv1x1(sd, g + "0", m, groups=4, q=q), train))))
+    x = _bn(sd, p + "fc2.1", _conv1x1(sd, p + "fc2.0", m, q=q), train)
+    return tap(p + "fc2", _q(q, x + short))
 
 
-def ffn(sd, p, x, train):
+def ffn(sd, p, x, train, q=None, tap=None):
     """graph_encoder.py:60-67."""
-    h = F.relu(_bn(sd, p + "fc1.1", _conv1x1(sd, p + "fc1.0", x), train))
-    return _bn(sd, p + "fc2.1", _conv1x1(sd, p + "fc2.0", h), train) + x
+    tap = tap or _notap
+    h = tap(p + "fc1", _q(q, F.relu(_bn(sd, p + "fc1.1", _conv1x1(sd, p + "fc1.0", x, q=q), train))))
+    return tap(p + "fc2", _q(q, _bn(sd, p + "fc2.1", _conv1x1(sd, p + "fc2.0", h, q=q), train) + x))
 
 
-def downsample(sd, p, x, train):
+def downsample(sd, p, x, train, q=None, tap=None):
     """graph_encoder.py:21-28: 3x3 stride-2 pad-1 conv on the (N,1) grid, then BN."""
-    y = F.conv2d(x, sd[p + "conv.0.weight"], sd[p + "conv.0.bias"], stride=2, padding=1)
-    return _bn(sd, p + "conv.1", y, train)
+    tap = tap or _notap
+    y = _conv1x1(sd, p + "conv.0", x, q=q, stride=2, padding=1)
+    return tap(p + "conv", _q(q, _bn(sd, p + "conv.1", y, train)))
 
 
-def graph_encoder(sd, x, train, k=3, prefix="encoder.", idx_fn=knn_graph_torch):
-    """graph_encoder.py:167-191.  x (B,C_in,N) -> (B,1024)."""
+def graph_encoder(sd, x, train, k=3, prefix="encoder.", idx_fn=knn_graph_torch, q=None, tap=None):
+    """graph_encoder.py:167-191.  x (B,C_in,N) -> (B,1024).  With q the node features are stored in bf16 after every
+    layer; the readout (mean over nodes and the projection, which commute) stays in f32 as in the HIP path."""
+    tap_ = tap or _notap
     x = x.unsqueeze(-1)
-    x = F.leaky_relu(_bn(sd, prefix + "stem.1", _conv1x1(sd, prefix + "stem.0", x), train), 0.2)
+    x = tap_(prefix + "stem", _q(q, F.leaky_relu(_bn(sd, prefix + "stem.1", _conv1x1(sd, prefix + "stem.0", x, q=q),
+                                                      train), 0.2)))
     i = 0
     while True:
         p = f"{prefix}backbone.{i}."
         if (p + "conv.0.weight") in sd:
-            x = downsample(sd, p, x, train)
+            x = downsample(sd, p, x, train, q, tap)
         elif (p + "0.fc1.0.weight") in sd:
-            x = grapher(sd, p + "0.", x, k, train, idx_fn)
-            x = ffn(sd, p + "1.", x, train)
+            x = grapher(sd, p + "0.", x, k, train, idx_fn, q, tap)
+            x = ffn(sd, p + "1.", x, train, q, tap)
         else:
             break
         i += 1
@@ -163,10 +190,10 @@ def graph_encoder(sd, x, train, k=3, prefix="encoder.", idx_fn=knn_graph_torch):
     return torch.mean(x, dim=2).squeeze(-1).squeeze(-1)
 
 
-def simclr_forward(sd, x_i, x_j, train, k=3, stride=2, idx_fn=knn_graph_torch):
+def simclr_forward(sd, x_i, x_j, train, k=3, stride=2, idx_fn=knn_graph_torch, q=None, tap=None):
     """simclr.py:29-47: views run sequentially through the same modules."""
     def one(spec):
-        h = graph_encoder(sd, peak_extract(sd, spec, stride), train, k, idx_fn=idx_fn)
+        h = graph_encoder(sd, peak_extract(sd, spec, stride), train, k, idx_fn=idx_fn, q=q, tap=tap)
         z = F.linear(F.elu(F.linear(h, sd["projector.0.weight"], sd["projector.0.bias"])),
                      sd["projector.2.weight"], sd["projector.2.bias"])
         return h, F.normalize(z, p=2)

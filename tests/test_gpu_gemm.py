@@ -1,0 +1,120 @@
+"""GPU tests of the hand-written 1x1-convolution GEMM (gemm.hip): product, folded BatchNorm statistics, normalise-on-load
+prologue, grouped form -- against plain torch f32 arithmetic on the same bf16 operands.  `pytest -m gpu`."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _rand(shape, seed, scale=1.0, shift=0.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale + shift).to(torch.bfloat16).to(DEV)
+
+
+def _check_product(y, ref):
+    """bf16 result of an f32 accumulation in ANOTHER order: equal up to one rounding step on a small fraction."""
+    y, ref = y.float(), ref.float()
+    tol = ref.abs() * 2.0 ** -7 + ref.abs().max() * 2.0 ** -15
+    bad = (y - ref).abs() > tol
+    assert not bool(bad.any()), (int(bad.sum()), float((y - ref).abs().max()))
+    assert float((y != ref).float().mean()) < 5e-3
+
+
+# (R, K, groups, M, views): every stage shape of the encoder at a small batch, ragged ranges, R < tile, grouped
+SHAPES = [(64, 64, 1, 8192, 2), (256, 64, 1, 8192, 2), (64, 256, 1, 8192, 2), (128, 128, 4, 4096, 2),
+          (128, 64, 1, 2048 * 3, 1), (512, 2048, 1, 1024, 2), (2048, 512, 1, 1024, 1), (256, 768, 1, 2560, 2),
+          (1024, 1024, 4, 2048, 2), (96, 32, 1, 1280, 1), (64, 64, 1, 128 * 2 * 37, 2)]
+
+
+@pytest.mark.parametrize("R,K,groups,M,views", SHAPES)
+def test_gemm_product_and_stats(R, K, groups, M, views):
+    from grafp_amd import ops
+    assert ops.gemm_supported(R, K, groups, M, views)
+    w = _rand((R, K // groups), 1, 0.2)
+    x = _rand((K, M), 2, 1.0, 0.3)
+    y, part = ops.conv1x1_gemm(w, x, groups, views, stats=True)
+    y2 = ops.conv1x1_gemm(w, x, groups, views)
+    assert torch.equal(y, y2)                       # the statistics epilogue does not change the product
+    wf, xf = w.float(), x.float()
+    Rg, Kg = R // groups, K // groups
+    ref = torch.cat([wf[g * Rg:(g + 1) * Rg] @ xf[g * Kg:(g + 1) * Kg] for g in range(groups)], dim=0)
+    _check_product(y, ref.to(torch.bfloat16))
+    # statistics of the ROUNDED outputs, per view
+    gamma = torch.linspace(0.5, 1.5, R, device=DEV)
+    beta = torch.linspace(-0.2, 0.2, R, device=DEV)
+    bias = torch.linspace(-1.0, 1.0, R, device=DEV)
+    rm, rv = torch.zeros(R, device=DEV), torch.ones(R, device=DEV)
+    mean, invstd, tab = ops.bn_finalize(part, R, K, groups, M, views, gamma, beta, bias, rm, rv, True, 0.1, 1e-5)
+    yv = y.float().reshape(R, views, M // views).double()
+    want_mean = yv.mean(dim=2) + bias.double()[:, None]
+    want_var = yv.var(dim=2, unbiased=False)
+    np.testing.assert_allclose(mean.cpu().numpy(), want_mean.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(invstd.cpu().numpy(), (1.0 / torch.sqrt(want_var + 1e-5)).cpu().numpy(), rtol=2e-5)
+    scale = gamma.double()[:, None] * (1.0 / torch.sqrt(want_var + 1e-5))
+    np.testing.assert_allclose(tab[..., 0].cpu().numpy(), scale.cpu().numpy(), rtol=2e-5)
+    np.testing.assert_allclose(tab[..., 1].cpu().numpy(), (beta.double()[:, None] - yv.mean(dim=2) * scale).cpu().numpy(),
+                               rtol=1e-4, atol=1e-4)
+    # running statistics: once per view, in order, unbiased variance
+    erm, erv = torch.zeros(R, dtype=torch.float64, device=DEV), torch.ones(R, dtype=torch.float64, device=DEV)
+    for v in range(views):
+        erm = 0.9 * erm + 0.1 * want_mean[:, v]
+        erv = 0.9 * erv + 0.1 * yv[:, v].var(dim=1, unbiased=True)
+    np.testing.assert_allclose(rm.cpu().numpy(), erm.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(rv.cpu().numpy(), erv.cpu().numpy(), rtol=1e-5)
+    # the apply half
+    res = _rand((R, M), 5)
+    z = ops.bn_affine(y, tab, views, residual=res, act=ops.ACT_RELU)
+    t = tab.reshape(R, views, 1, 2)
+    zr = torch.relu(torch.addcmul(t[..., 1], y.float().reshape(R, views, -1), t[..., 0])).reshape(R, M) + res.float()
+    assert float((z.float() - zr.to(torch.bfloat16).float()).abs().max()) <= float(zr.abs().max()) * 2.0 ** -7
+
+
+def test_gemm_statistics_with_large_mean():
+    """|mean| >> std rows: the shifted sums keep the variance (E[y^2] - E[y]^2 in f32 would lose it)."""
+    from grafp_amd import ops
+    R, K, M = 64, 64, 128 * 64
+    w = torch.zeros((R, K), dtype=torch.bfloat16, device=DEV)
+    w[:, 0] = 1.0
+    w[torch.arange(R), 1 + torch.arange(R) % (K - 1)] = 0.01
+    x = _rand((K, M), 3)
+    x[0] = 200.0
+    y, part = ops.conv1x1_gemm(w, x, 1, 1, stats=True)
+    one = torch.ones(R, device=DEV)
+    mean, invstd, _ = ops.bn_finalize(part, R, K, 1, M, 1, one, 0 * one, None, None, None, True, 0.1, 0.0)
+    yv = y.float().double()
+    np.testing.assert_allclose(mean[:, 0].cpu().numpy(), yv.mean(dim=1).cpu().numpy(), rtol=1e-6)
+    np.testing.assert_allclose(invstd[:, 0].cpu().numpy(), (1 / yv.std(dim=1, unbiased=False)).cpu().numpy(), rtol=1e-4)
+
+
+@pytest.mark.parametrize("R,K,groups,M,views,act", [(64, 128, 1, 4096, 2, 1), (128, 256, 1, 2048, 2, 1),
+                                                    (512, 2048, 1, 1024, 2, 1), (64, 64, 1, 2048, 1, 2),
+                                                    (128, 128, 4, 2048, 2, 0)])
+def test_gemm_normalise_on_load(R, K, groups, M, views, act):
+    from grafp_amd import ops
+    w = _rand((R, K // groups), 11, 0.2)
+    x = _rand((K, M), 12, 2.0, 1.0)
+    g = torch.Generator().manual_seed(13)
+    tab = torch.stack((torch.rand((K, views), generator=g) + 0.5, torch.randn((K, views), generator=g)), dim=-1).to(DEV)
+    y, part = ops.conv1x1_gemm(w, x, groups, views, pro_tab=tab, pro_act=act, pro_slope=0.2, stats=True)
+    t = tab.reshape(K, views, 1, 2)
+    u = torch.addcmul(t[..., 1], x.float().reshape(K, views, -1), t[..., 0])          # fma rounding differs by <= 1 ulp f32
+    u = torch.relu(u) if act == 1 else (torch.where(u > 0, u, 0.2 * u) if act == 2 else u)
+    u = u.reshape(K, M).to(torch.bfloat16).float()
+    Rg, Kg = R // groups, K // groups
+    ref = torch.cat([w.float()[i * Rg:(i + 1) * Rg] @ u[i * Kg:(i + 1) * Kg] for i in range(groups)], dim=0)
+    y, ref = y.float(), ref.to(torch.bfloat16).float()
+    # an f32 fma vs mul+add can move an operand across a bf16 rounding boundary (rare): bound the relative L2 error too
+    assert float((y - ref).norm() / ref.norm()) < 2e-3
+    assert float(((y - ref).abs() > ref.abs() * 2.0 ** -6 + ref.abs().max() * 2.0 ** -12).float().mean()) < 1e-3
+
+
+def test_gemm_rejects_unsupported_shapes():
+    from grafp_amd import ops
+    assert not ops.gemm_supported(64, 8, 1, 1024, 1)        # K = 8 (the stem): library GEMM
+    assert not ops.gemm_supported(64, 64, 1, 1000, 1)
+    w, x = _rand((64, 8), 1), _rand((8, 1024), 2)
+    with pytest.raises(RuntimeError):
+        ops.conv1x1_gemm(w, x)
