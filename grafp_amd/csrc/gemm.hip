@@ -34,14 +34,28 @@ typedef __bf16 gm_bf16x2 __attribute__((ext_vector_type(2)));
 typedef const void __attribute__((address_space(1))) *gm_gptr;
 typedef void __attribute__((address_space(3))) *gm_lptr;
 
-constexpr int GM_T = 128;                      // output tile edge (rows r and columns m)
 constexpr int GM_KC = 32;                      // contraction per chunk
-constexpr int GM_A_BYTES = GM_T * GM_KC * 2;   // W chunk: 128 rows x 64 B
-constexpr int GM_B_BYTES = GM_KC * GM_T * 2;   // X chunk: 32 rows x 256 B
-constexpr int GM_STAGE = GM_A_BYTES + GM_B_BYTES;
 constexpr int GM_OUT_BYTES = 32 * 128;         // per-wave output staging: 32 rows (r) x 64 m bf16
-constexpr int GM_DMA_PER_CHUNK = 4;            // LDS-DMA instructions per wave and chunk (2 W + 2 X)
+constexpr int GM_DMA_PER_CHUNK = 4;            // LDS-DMA instructions per wave and chunk (2 W + 2 X) in both configs
 constexpr int GM_STORES_PER_RT = 4;            // 16-byte store instructions per wave and 32-row output tile
+
+// Tile configurations: WR x WM waves, each wave RT x 2 MFMA tiles (32 RT rows x 64 columns).
+//   S: 2 x 2 waves, RT 2 -> 128 x 128 tile, 4 waves, 2 workgroups per CU: the streaming shapes (stages 0-1), where what
+//      matters is X/Y bytes in flight per CU;
+//   L: 2 x 4 waves, RT 4 -> 256 x 256 tile, 8 waves, 1 workgroup per CU: the matrix-heavy shapes (stages 2-3).  The S
+//      tile moves 16 KB of operands through the LDS-DMA path per 1 MFLOP (64 flop/B) and that path saturates at about
+//      9 TB/s chip-wide (measured: 580-820 TFLOP/s on every stage 2-3 shape); the L tile moves 32 KB per 4 MFLOP.
+template <int WR_, int WM_, int RT_> struct GemmCfg {
+    static constexpr int WR = WR_, WM = WM_, RT = RT_, NW = WR_ * WM_, THREADS = 64 * NW;
+    static constexpr int TR = WR_ * RT_ * 32, TN = WM_ * 64;
+    static constexpr int A_BYTES = TR * GM_KC * 2, B_BYTES = GM_KC * TN * 2, STAGE = A_BYTES + B_BYTES;
+    static constexpr int ROWB = TN * 2;                   // bytes per X tile row
+    static constexpr int SLOTS = TN / 8;                  // 16-byte slots per X tile row
+    static constexpr int RPI = 64 / SLOTS;                // X tile rows per DMA instruction
+    static_assert(TR / 16 / NW == 2 && TN / 16 / NW == 2, "two W and two X DMA instructions per wave and chunk");
+};
+typedef GemmCfg<2, 2, 2> GemmS;
+typedef GemmCfg<2, 4, 4> GemmL;
 
 __device__ __forceinline__ unsigned gm_pack_bf16(float a, float b) {
     const gm_f32x2 v = {a, b};
@@ -59,27 +73,54 @@ __device__ __forceinline__ void gm_dma16(const void *gsrc, unsigned lds_base) {
 template <int N> __device__ __forceinline__ void gm_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 // at most `allowed` of this wave's newest vector-memory operations may still be in flight (rounded DOWN to a step)
 __device__ __forceinline__ void gm_wait_allowed(int allowed) {
-    if (allowed >= 32) gm_wait_vm<32>();
-    else if (allowed >= 24) gm_wait_vm<24>();
-    else if (allowed >= 20) gm_wait_vm<20>();
-    else if (allowed >= 16) gm_wait_vm<16>();
-    else if (allowed >= 12) gm_wait_vm<12>();
-    else if (allowed >= 8) gm_wait_vm<8>();
-    else if (allowed >= 4) gm_wait_vm<4>();
-    else gm_wait_vm<0>();
+    if (allowed >= 24) {
+        if (allowed >= 48) gm_wait_vm<48>();
+        else if (allowed >= 40) gm_wait_vm<40>();
+        else if (allowed >= 36) gm_wait_vm<36>();
+        else if (allowed >= 32) gm_wait_vm<32>();
+        else gm_wait_vm<24>();
+    } else if (allowed >= 12) {
+        if (allowed >= 20) gm_wait_vm<20>();
+        else if (allowed >= 16) gm_wait_vm<16>();
+        else gm_wait_vm<12>();
+    } else {
+        if (allowed >= 8) gm_wait_vm<8>();
+        else if (allowed >= 4) gm_wait_vm<4>();
+        else gm_wait_vm<0>();
+    }
 }
 
 struct GemmPlan {
-    int row_tiles, col_tiles_view, ranges_view, tiles_range, nblocks, P;
+    int large;                                   // tile configuration: 0 = S, 1 = L
+    int tr, tn, wm, row_tiles, col_tiles_view, ranges_view, tiles_range, nblocks, P;
 };
+static int gemm_force_cfg() {
+    static int v = -2;
+    if (v == -2) {
+        const char *e = getenv("GRAFP_GEMM_TILE");           // "S" / "L": force a configuration (measurements)
+        v = !e ? -1 : (e[0] == 'L' ? 1 : 0);
+    }
+    return v;
+}
 // R rows per conv group, M columns, `views` column segments with separate statistics (a range never straddles two)
 static GemmPlan gemm_plan(int Rg, int K, int groups, int64_t M, int views) {
     GemmPlan p;
-    p.row_tiles = (Rg + GM_T - 1) / GM_T;
-    p.col_tiles_view = (int)((M / views) / GM_T);
+    const int64_t Mg = M / views;
+    // measured crossover (tools/gemm_bench.py, 512 clip-views): the large tile for >= 512 output rows per group, and
+    // for 256 rows when the operand is deep (K >= 512: matrix-heavy) or shallow (4K <= R: X is then read once for all
+    // 256 rows of a write-bound product)
+    bool large = (Rg >= 512 || (Rg >= 256 && (K >= 512 || 4 * K <= Rg))) && Mg % GemmL::TN == 0;
+    if (gemm_force_cfg() >= 0) large = gemm_force_cfg() == 1 && Mg % GemmL::TN == 0;
+    p.large = large ? 1 : 0;
+    p.tr = large ? GemmL::TR : GemmS::TR;
+    p.tn = large ? GemmL::TN : GemmS::TN;
+    p.wm = large ? GemmL::WM : GemmS::WM;
+    const int per_cu = large ? 1 : 2;
+    p.row_tiles = (Rg + p.tr - 1) / p.tr;
+    p.col_tiles_view = (int)(Mg / p.tn);
     const int nch = K / GM_KC;
-    // ~1024 workgroups (two rounds of 2 per CU), but at least ~8 chunks per workgroup to amortise the pipeline fill
-    int64_t want = 1024 / ((int64_t)p.row_tiles * groups * views);
+    // two rounds of resident workgroups, but at least ~8 chunks per workgroup to amortise the pipeline fill
+    int64_t want = (int64_t)(512 * per_cu) / ((int64_t)p.row_tiles * groups * views);
     if (want < 1) want = 1;
     int tiles_range = (int)((p.col_tiles_view + want - 1) / want);
     const int min_tiles = (8 + nch - 1) / nch;
@@ -88,23 +129,24 @@ static GemmPlan gemm_plan(int Rg, int K, int groups, int64_t M, int views) {
     p.tiles_range = tiles_range;
     p.ranges_view = (p.col_tiles_view + tiles_range - 1) / tiles_range;
     p.nblocks = p.row_tiles * p.ranges_view * views;
-    p.P = p.ranges_view * 2;          // one partial per (range, wave column)
+    p.P = p.ranges_view * p.wm;       // one partial per (range, wave column)
     return p;
 }
 
-template <int NS, bool PRO, bool STATS>
-__global__ __launch_bounds__(256, 2) void conv1x1_gemm_kernel(
+template <typename CFG, int NS, bool PRO, bool STATS>
+__global__ __launch_bounds__(CFG::THREADS) void conv1x1_gemm_kernel(
     const unsigned short *__restrict__ A, int lda, const unsigned short *__restrict__ X, unsigned short *__restrict__ Y,
     int64_t M, int Rg, int K, int row_tiles, int ranges_view, int tiles_range, int col_tiles_view, int views,
     const float2 *__restrict__ pro_tab, int pro_act, float pro_slope, float *__restrict__ part, int P, int nblocks) {
     constexpr int D = NS - 1;                               // chunks in flight
+    constexpr int RT = CFG::RT, TN = CFG::TN, ROWB = CFG::ROWB;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *const s_out = smem + NS * GM_STAGE;      // 4 x GM_OUT_BYTES
-    unsigned char *const s_tab = s_out + 4 * GM_OUT_BYTES;  // PRO: K x float2 (scale, shift) of this view
+    unsigned char *const s_out = smem + NS * CFG::STAGE;              // NW x GM_OUT_BYTES
+    unsigned char *const s_tab = s_out + CFG::NW * GM_OUT_BYTES;      // PRO: K x float2 (scale, shift) of this view
 
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // scalar: everything derived stays in SGPRs
-    const int wr = wave >> 1, wm = wave & 1;
+    const int wr = wave / CFG::WM, wm = wave % CFG::WM;
     const unsigned lds0 = (unsigned)(uintptr_t)(gm_lptr)smem;
     const int logical = xcd_remap(blockIdx.x, nblocks);
     const int rt = logical % row_tiles, range = logical / row_tiles;
@@ -114,15 +156,15 @@ __global__ __launch_bounds__(256, 2) void conv1x1_gemm_kernel(
     const int ntile = (tiles_range < col_tiles_view - tile0) ? tiles_range : col_tiles_view - tile0;
     const int nch = K / GM_KC;
     const int T = ntile * nch;
-    const int r0 = rt * GM_T;
-    const int64_t col0 = (int64_t)view * (M / views) + (int64_t)tile0 * GM_T;
+    const int r0 = rt * CFG::TR;
+    const int64_t col0 = (int64_t)view * (M / views) + (int64_t)tile0 * TN;
     A += (size_t)grp * Rg * lda;
     X += (size_t)grp * K * M;
     Y += (size_t)grp * Rg * M;
 
     if (PRO) {       // this view's (scale, shift) per operand row -> LDS (ordinary loads: before any DMA is in flight)
         const float2 *src = pro_tab + ((size_t)grp * K) * views;
-        for (int k = tid; k < K; k += 256) reinterpret_cast<float2 *>(s_tab)[k] = src[(size_t)k * views + view];
+        for (int k = tid; k < K; k += CFG::THREADS) reinterpret_cast<float2 *>(s_tab)[k] = src[(size_t)k * views + view];
     }
 
     // ---- DMA source addresses of this lane (LDS side is lane-linear: stage + instruction * 1 KiB + lane * 16) ----
@@ -136,27 +178,28 @@ __global__ __launch_bounds__(256, 2) void conv1x1_gemm_kernel(
         const int slot = (lane & 3) ^ ((lane >> 4) & 3);
         a_src[j] = A + (size_t)row * lda + slot * 8;
     }
-    // X chunk: instruction q covers k-rows 4q .. 4q+3 (256 B each); 16-byte slot s' = lane & 15 of row (lane >> 4)
-    //          holds source segment (s' >> 2) ^ (row & 3), piece s' & 3
+    // X chunk: instruction q covers RPI k-rows (ROWB bytes each); 16-byte slot s' = lane % SLOTS of its row holds
+    //          source segment (s' >> 2) ^ (row & 3) (low two bits of the 64-byte segment index), piece s' & 3
     const unsigned short *b_src[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int row = 4 * (2 * wave + j) + (lane >> 4);
-        const int seg = ((lane & 15) >> 2) ^ (lane >> 4);
-        b_src[j] = X + (size_t)row * M + col0 + (seg * 4 + (lane & 3)) * 8;
+        const int row = CFG::RPI * (2 * wave + j) + lane / CFG::SLOTS;
+        const int sl = lane % CFG::SLOTS;
+        const int seg = (sl >> 2) ^ (row & 3);
+        b_src[j] = X + (size_t)row * M + col0 + (seg * 4 + (sl & 3)) * 8;
     }
     int is_ch = 0;                                           // chunk-in-tile of the next chunk to issue
     auto issue = [&](int t) {
-        const unsigned st = lds0 + (t % NS) * GM_STAGE + 2 * wave * 1024;
+        const unsigned st = lds0 + (t % NS) * CFG::STAGE + 2 * wave * 1024;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             gm_dma16(a_src[j] + is_ch * GM_KC, st + j * 1024);
-            gm_dma16(b_src[j] + (size_t)is_ch * GM_KC * M, st + GM_A_BYTES + j * 1024);
+            gm_dma16(b_src[j] + (size_t)is_ch * GM_KC * M, st + CFG::A_BYTES + j * 1024);
         }
         if (++is_ch == nch) {
             is_ch = 0;
-            b_src[0] += GM_T;
-            b_src[1] += GM_T;
+            b_src[0] += TN;
+            b_src[1] += TN;
         }
     };
 
@@ -169,34 +212,38 @@ __global__ __launch_bounds__(256, 2) void conv1x1_gemm_kernel(
         const int i = lane & 15;
         const int bytecol = (wm * 64 + mi * 32 + 16 * ((lane >> 4) & 1) + 4 * (i & 3)) * 2;
         const int seg = (bytecol >> 6) ^ (i >> 2);
-        xoff[mi] = GM_A_BYTES + (8 * half + (i >> 2)) * 256 + seg * 64 + (bytecol & 63);
+        xoff[mi] = CFG::A_BYTES + (8 * half + (i >> 2)) * ROWB + seg * 64 + (bytecol & 63);
     }
-    // W fragment (B operand, j = r): row wr*64 + ri*32 + l31, 16-byte slot (2 ks + half) ^ ((row >> 2) & 3)
-    int woff[2][2];
+    // W fragment (B operand, j = r): row wr*32*RT + ri*32 + l31, 16-byte slot (2 ks + half) ^ ((row >> 2) & 3)
+    int woff[RT][2];
 #pragma unroll
-    for (int ri = 0; ri < 2; ++ri)
+    for (int ri = 0; ri < RT; ++ri)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            const int row = wr * 64 + ri * 32 + l31;
+            const int row = wr * 32 * RT + ri * 32 + l31;
             woff[ri][ks] = row * 64 + (((2 * ks + half) ^ ((row >> 2) & 3)) << 4);
         }
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][RT];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < RT; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
-    float sS[2] = {0.f, 0.f}, sQ[2] = {0.f, 0.f}, sShift[2] = {0.f, 0.f};
+    float sS[RT], sQ[RT], sShift[RT];
     // output tiles of 32 rows this wave really owns (R is a multiple of 32)
-    bool rt_valid[2];
+    bool rt_valid[RT];
+    int stores_per_epi = 0;
 #pragma unroll
-    for (int ri = 0; ri < 2; ++ri) rt_valid[ri] = r0 + wr * 64 + ri * 32 < Rg;
-    const int stores_per_epi = GM_STORES_PER_RT * ((int)rt_valid[0] + (int)rt_valid[1]);
+    for (int ri = 0; ri < RT; ++ri) {
+        sS[ri] = sQ[ri] = sShift[ri] = 0.0f;
+        rt_valid[ri] = r0 + wr * 32 * RT + ri * 32 < Rg;
+        stores_per_epi += rt_valid[ri] ? GM_STORES_PER_RT : 0;
+    }
 
     // vector-memory operations issued AFTER the DMA of chunk t, by iteration: dma_hist[j] / st_hist[j] = issued in
-    // iteration t-1-j (see the header: the wait for chunk t may leave exactly those in flight)
+    // iteration t-1-j (the wait for chunk t may leave exactly those in flight)
     int dma_hist[D], st_hist[D + 1];
 #pragma unroll
     for (int j = 0; j < D; ++j) dma_hist[j] = 0;
@@ -209,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_gemm_kernel(
     for (int c = 0; c < D; ++c)
         if (c < T) {
             issue(c);
-            if (c >= 1) dma_hist[D - 1 - c] = GM_DMA_PER_CHUNK;     // iteration c - D = -(D - c): slot (−1) − (c − D) = D-1-c
+            if (c >= 1) dma_hist[D - 1 - c] = GM_DMA_PER_CHUNK;
         }
 
     unsigned char *const my_out = s_out + wave * GM_OUT_BYTES;
@@ -221,7 +268,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_gemm_kernel(
             for (int j = 0; j < D - 1; ++j) allowed += dma_hist[j];         // iterations t-1 .. t-D+1
 #pragma unroll
             for (int j = 0; j < D; ++j) allowed += st_hist[j];              // iterations t-1 .. t-D
-            gm_wait_allowed(allowed);
+            gm_wait_allowed(__builtin_amdgcn_readfirstlane(allowed));
             __builtin_amdgcn_s_barrier();
         }
         int issued_now = 0;
@@ -229,14 +276,14 @@ __global__ __launch_bounds__(256, 2) void conv1x1_gemm_kernel(
             issue(t + D);
             issued_now = GM_DMA_PER_CHUNK;
         }
-        unsigned char *const st = smem + (t % NS) * GM_STAGE;
+        unsigned char *const st = smem + (t % NS) * CFG::STAGE;
         if (PRO) {
-            // normalise + activate the X chunk in place: 512 16-byte pieces, row = piece / 16
+            // normalise + activate the X chunk in place: 32 rows x SLOTS 16-byte pieces, two per thread
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int p = tid + 256 * j;
-                const float2 ss = reinterpret_cast<const float2 *>(s_tab)[ch * GM_KC + (p >> 4)];
-                uint4 *cell = reinterpret_cast<uint4 *>(st + GM_A_BYTES + p * 16);
+                const int p = tid + CFG::THREADS * j;
+                const float2 ss = reinterpret_cast<const float2 *>(s_tab)[ch * GM_KC + p / CFG::SLOTS];
+                uint4 *cell = reinterpret_cast<uint4 *>(st + CFG::A_BYTES + p * 16);
                 uint4 v = *cell;
                 unsigned w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -253,33 +300,33 @@ __global__ __launch_bounds__(256, 2) void conv1x1_gemm_kernel(
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
-        // ---- 2 k-steps x (2 x 2) MFMAs ----
+        // ---- 2 k-steps x (2 x RT) MFMAs ----
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            gm_bf16x8 xa[2], wb[2];
+            gm_bf16x8 xa[2], wb[RT];
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) {
                 const gm_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (gm_s16x4 __attribute__((address_space(3))) *)(st + xoff[mi] + ks * 4096));
+                    (gm_s16x4 __attribute__((address_space(3))) *)(st + xoff[mi] + ks * 16 * ROWB));
                 const gm_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (gm_s16x4 __attribute__((address_space(3))) *)(st + xoff[mi] + ks * 4096 + 1024));
+                    (gm_s16x4 __attribute__((address_space(3))) *)(st + xoff[mi] + ks * 16 * ROWB + 4 * ROWB));
                 xa[mi] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             }
 #pragma unroll
-            for (int ri = 0; ri < 2; ++ri) wb[ri] = *reinterpret_cast<const gm_bf16x8 *>(st + woff[ri][ks]);
+            for (int ri = 0; ri < RT; ++ri) wb[ri] = *reinterpret_cast<const gm_bf16x8 *>(st + woff[ri][ks]);
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int ri = 0; ri < RT; ++ri)
 #pragma unroll
-                for (int ri = 0; ri < 2; ++ri)
+                for (int mi = 0; mi < 2; ++mi)
                     acc[mi][ri] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[mi], wb[ri], acc[mi][ri], 0, 0, 0);
         }
         int stored_now = 0;
         if (++ch == nch) {
             ch = 0;
             // ---- epilogue of one output tile: round, statistics, transpose through LDS, 16-byte row stores ----
-            const int64_t mcol = col0 + (int64_t)tile * GM_T + wm * 64;
+            const int64_t mcol = col0 + (int64_t)tile * TN + wm * 64;
 #pragma unroll
-            for (int ri = 0; ri < 2; ++ri) {
+            for (int ri = 0; ri < RT; ++ri) {
                 if (rt_valid[ri]) {
                     if (STATS && tile == 0) {
                         // shift = the row's first rounded output of this wave (lane l31 of the lower half holds it)
@@ -312,7 +359,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_gemm_kernel(
                     for (int it = 0; it < 4; ++it) {
                         const int row = it * 8 + (lane >> 3), p16 = lane & 7;
                         const uint4 v = *reinterpret_cast<const uint4 *>(my_out + row * 128 + ((p16 ^ (row & 7)) << 4));
-                        const int r = r0 + wr * 64 + ri * 32 + row;
+                        const int r = r0 + wr * 32 * RT + ri * 32 + row;
                         *reinterpret_cast<uint4 *>(Y + (size_t)r * M + mcol + p16 * 8) = v;
                     }
                 }
@@ -331,11 +378,11 @@ __global__ __launch_bounds__(256, 2) void conv1x1_gemm_kernel(
     if (STATS) {
         // per row: this wave's (sum, sum of squares, shift) over its 64-column share of every tile of the range
 #pragma unroll
-        for (int ri = 0; ri < 2; ++ri) {
+        for (int ri = 0; ri < RT; ++ri) {
             const float s = sS[ri] + __shfl_xor(sS[ri], 32), q = sQ[ri] + __shfl_xor(sQ[ri], 32);
-            const int r = r0 + wr * 64 + ri * 32 + l31;
+            const int r = r0 + wr * 32 * RT + ri * 32 + l31;
             if (half == 0 && rt_valid[ri]) {
-                float *pp = part + ((((size_t)grp * Rg + r) * views + view) * P + (rloc * 2 + wm)) * 3;
+                float *pp = part + ((((size_t)grp * Rg + r) * views + view) * P + (rloc * CFG::WM + wm)) * 3;
                 pp[0] = s;
                 pp[1] = q;
                 pp[2] = sShift[ri];
@@ -345,47 +392,67 @@ __global__ __launch_bounds__(256, 2) void conv1x1_gemm_kernel(
 }
 
 // Statistics of row c, view v from the P partials of the GEMM (n_p columns each): Chan's combination of
-// (count, mean, M2) in double, fixed order -> mean, invstd saved for backward; (scale, shift) for the affine
-// kernel / the next GEMM's PRO: z = act(y * scale + shift); running statistics advance once per view, in order.
-__global__ __launch_bounds__(64) void bn_finalize_kernel(const float *__restrict__ part, int C, int views, int P,
-                                                         int tiles_range, int col_tiles_view, int64_t Mg,
-                                                         const float *__restrict__ pre_bias,
-                                                         const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                         float eps, float momentum, float *__restrict__ running_mean,
-                                                         float *__restrict__ running_var, float *__restrict__ save_mean,
-                                                         float *__restrict__ save_invstd, float2 *__restrict__ tab) {
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= C) return;
+// (count, mean, M2) in a fixed order (lane-strided partials, then a 6-step butterfly: deterministic) -> mean, invstd
+// saved for backward; (scale, shift) for the affine kernel / the next GEMM's PRO: z = act(y * scale + shift); running
+// statistics advance once per view, in order.  One workgroup per row, one wave per view.  f32 is enough here: the
+// partials are already centred on a sample of their own row, and the combination never subtracts large numbers.
+__device__ __forceinline__ void gm_chan(float &n, float &mean, float &m2, float nb, float mb, float m2b) {
+    const float nn = n + nb;
+    if (nn > 0.0f) {
+        const float delta = mb - mean, f = nb / nn;
+        mean = __builtin_fmaf(delta, f, mean);
+        m2 += m2b + delta * delta * (n * f);
+        n = nn;
+    }
+}
+__global__ __launch_bounds__(512) void bn_finalize_kernel(const float *__restrict__ part, int C, int views, int P,
+                                                          int wm, int tiles_range, int col_tiles_view, int64_t Mg,
+                                                          const float *__restrict__ pre_bias,
+                                                          const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                          float eps, float momentum, float *__restrict__ running_mean,
+                                                          float *__restrict__ running_var, float *__restrict__ save_mean,
+                                                          float *__restrict__ save_invstd, float2 *__restrict__ tab) {
+    __shared__ float2 s_stat[8];                 // (mean + bias, unbiased variance) per view
+    const int c = blockIdx.x, lane = threadIdx.x & 63, v = threadIdx.x >> 6;
     const float pb = pre_bias ? pre_bias[c] : 0.0f;
-    float rm = running_mean ? running_mean[c] : 0.f, rv = running_var ? running_var[c] : 0.f;
-    for (int v = 0; v < views; ++v) {
-        double n = 0.0, mean = 0.0, m2 = 0.0;
-        for (int p = 0; p < P; ++p) {
-            const float *pp = part + (((size_t)c * views + v) * P + p) * 3;
-            const int range = p >> 1;
-            const int tiles = (tiles_range < col_tiles_view - range * tiles_range) ? tiles_range
-                                                                                   : col_tiles_view - range * tiles_range;
-            const double np = 64.0 * tiles;
-            const double S = pp[0], Q = pp[1], sh = pp[2];
-            const double mp = sh + S / np, m2p = Q - S * S / np;
-            const double nn = n + np, delta = mp - mean;
-            mean += delta * (np / nn);
-            m2 += m2p + delta * delta * (n * np / nn);
-            n = nn;
+    float n = 0.0f, mean = 0.0f, m2 = 0.0f;
+    for (int p = lane; p < P; p += 64) {
+        const float *pp = part + (((size_t)c * views + v) * P + p) * 3;
+        const int range = p / wm;
+        const int tiles = (tiles_range < col_tiles_view - range * tiles_range) ? tiles_range
+                                                                               : col_tiles_view - range * tiles_range;
+        const float np = 64.0f * tiles, S = pp[0], Q = pp[1], sh = pp[2];
+        const float dm = S / np;
+        gm_chan(n, mean, m2, np, sh + dm, fmaxf(Q - S * dm, 0.0f));
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float nb = __shfl_xor(n, o), mb = __shfl_xor(mean, o), m2b = __shfl_xor(m2, o);
+        if (lane & o) {          // both partners compute the SAME ordered combination (lower lane's set first)
+            float n2 = nb, me2 = mb, q2 = m2b;
+            gm_chan(n2, me2, q2, n, mean, m2);
+            n = n2; mean = me2; m2 = q2;
+        } else {
+            gm_chan(n, mean, m2, nb, mb, m2b);
         }
-        double var = m2 / n;
-        if (var < 0.0) var = 0.0;
-        const float meanf = (float)mean + pb;                       // statistics of y + conv bias
-        const float invstd = 1.0f / sqrtf((float)var + eps);
+    }
+    if (lane == 0) {
+        const float var = fmaxf(m2 / n, 0.0f);
+        const float meanf = mean + pb;                              // statistics of y + conv bias
+        const float invstd = 1.0f / sqrtf(var + eps);
         save_mean[c * views + v] = meanf;
         save_invstd[c * views + v] = invstd;
         const float g = gamma[c] * invstd;
         tab[(size_t)c * views + v] = make_float2(g, beta[c] + (pb - meanf) * g);
-        const float unbiased = Mg > 1 ? (float)(m2 / (n - 1.0)) : (float)var;
-        rm = (1.0f - momentum) * rm + momentum * meanf;
-        rv = (1.0f - momentum) * rv + momentum * unbiased;
+        s_stat[v] = make_float2(meanf, Mg > 1 ? m2 / (n - 1.0f) : var);
     }
-    if (running_mean) {
+    __syncthreads();
+    if (threadIdx.x == 0 && running_mean) {
+        float rm = running_mean[c], rv = running_var[c];
+        for (int u = 0; u < views; ++u) {
+            rm = (1.0f - momentum) * rm + momentum * s_stat[u].x;
+            rv = (1.0f - momentum) * rv + momentum * s_stat[u].y;
+        }
         running_mean[c] = rm;
         running_var[c] = rv;
     }
@@ -463,7 +530,7 @@ static bool gemm_shape_ok(int R, int K, int groups, int64_t M, int views) {
     if (R <= 0 || K <= 0 || groups <= 0 || M <= 0 || views <= 0) return false;
     if (R % groups || K % groups) return false;
     const int Rg = R / groups, Kg = K / groups;
-    return Rg % 32 == 0 && Kg % GM_KC == 0 && M % views == 0 && (M / views) % GM_T == 0;
+    return Rg % 32 == 0 && Kg % GM_KC == 0 && M % views == 0 && (M / views) % GemmS::TN == 0;
 }
 
 }  // namespace grafp
@@ -493,21 +560,28 @@ extern "C" int grafp_conv1x1_gemm_bf16(const void *w, const void *x, int R, int 
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(p.nblocks, 1, groups);
     const bool pro = pro_tab != nullptr, stats = stats_part != nullptr;
-    const int ns = pro ? 3 : 4;
-    const size_t lds = (size_t)ns * GM_STAGE + 4 * GM_OUT_BYTES + (pro ? (size_t)Kg * 8 : 0);
-#define GM_LAUNCH(NS, PRO, STATS)                                                                                       \
+#define GM_LAUNCH(CFG, NS, PRO, STATS)                                                                                  \
     do {                                                                                                                \
-        (void)hipFuncSetAttribute((const void *)conv1x1_gemm_kernel<NS, PRO, STATS>,                                    \
+        const size_t lds = (size_t)(NS) * CFG::STAGE + CFG::NW * GM_OUT_BYTES + ((PRO) ? (size_t)Kg * 8 : 0);           \
+        (void)hipFuncSetAttribute((const void *)conv1x1_gemm_kernel<CFG, NS, PRO, STATS>,                               \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                \
-        hipLaunchKernelGGL((conv1x1_gemm_kernel<NS, PRO, STATS>), grid, dim3(256), lds, s, (const unsigned short *)w,   \
-                           Kg, (const unsigned short *)x, (unsigned short *)y, M, Rg, Kg, p.row_tiles, p.ranges_view,   \
-                           p.tiles_range, p.col_tiles_view, views, (const float2 *)pro_tab, pro_act, pro_slope,         \
-                           stats_part, p.P, p.nblocks);                                                                 \
+        hipLaunchKernelGGL((conv1x1_gemm_kernel<CFG, NS, PRO, STATS>), grid, dim3(CFG::THREADS), lds, s,                \
+                           (const unsigned short *)w, Kg, (const unsigned short *)x, (unsigned short *)y, M, Rg, Kg,    \
+                           p.row_tiles, p.ranges_view, p.tiles_range, p.col_tiles_view, views, (const float2 *)pro_tab, \
+                           pro_act, pro_slope, stats_part, p.P, p.nblocks);                                             \
     } while (0)
-    if (pro && stats) GM_LAUNCH(3, true, true);
-    else if (pro) GM_LAUNCH(3, true, false);
-    else if (stats) GM_LAUNCH(4, false, true);
-    else GM_LAUNCH(4, false, false);
+    // ring depth: S keeps 2 workgroups per CU (80 KB each: 4 stages, 3 with the PRO table); L is alone on its CU (3 stages)
+    if (p.large) {
+        if (pro && stats) GM_LAUNCH(GemmL, 3, true, true);
+        else if (pro) GM_LAUNCH(GemmL, 3, true, false);
+        else if (stats) GM_LAUNCH(GemmL, 3, false, true);
+        else GM_LAUNCH(GemmL, 3, false, false);
+    } else {
+        if (pro && stats) GM_LAUNCH(GemmS, 3, true, true);
+        else if (pro) GM_LAUNCH(GemmS, 3, true, false);
+        else if (stats) GM_LAUNCH(GemmS, 4, false, true);
+        else GM_LAUNCH(GemmS, 4, false, false);
+    }
 #undef GM_LAUNCH
     GRAFP_CHECK_LAUNCH("conv1x1_gemm_kernel");
     return GRAFP_OK;
@@ -530,7 +604,8 @@ extern "C" int grafp_bn_finalize(const float *stats_part, int C, int K, int grou
     GRAFP_REQUIRE(stats_part, "bn_finalize: null partials");
     GRAFP_REQUIRE(gemm_shape_ok(C, K, groups, M, views), "bn_finalize: shape does not match a conv1x1_gemm launch");
     const GemmPlan p = gemm_plan(C / groups, K / groups, groups, M, views);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, stats_part, C, views, p.P, p.tiles_range,
+    GRAFP_REQUIRE(views <= 8, "bn_finalize: at most 8 views");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64 * views), 0, s, stats_part, C, views, p.P, p.wm, p.tiles_range,
                        p.col_tiles_view, M / views, pre_bias, gamma, beta, eps, momentum, running_mean, running_var,
                        save_mean, save_invstd, (float2 *)tab);
     GRAFP_CHECK_LAUNCH("bn_finalize_kernel");

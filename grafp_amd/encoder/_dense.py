@@ -74,9 +74,54 @@ def conv3_stride2(conv, x):
     cin, B, N = x.shape
     cout = conv.out_channels
     n_out = (N - 1) // 2 + 1
-    taps = ops.stride2_taps(x)                                                          # (3, Cin, B, n_out)
-    w = conv.weight[:, :, :, 1].permute(0, 2, 1).reshape(cout, 3 * cin)                 # [o][t*Cin + c]
+    taps, w = stride2_operands(conv, x)
     return ops.conv1x1_rows(taps.reshape(3 * cin, B * n_out), w).reshape(cout, B, n_out)
+
+
+def stride2_operands(conv, x):
+    """The (3*Cin, B, n_out) tap gather of x and the (Cout, 3*Cin) weight matrix whose product is conv3_stride2."""
+    cin, B, N = x.shape
+    taps = ops.stride2_taps(x)                                                          # (3, Cin, B, n_out)
+    w = conv.weight[:, :, :, 1].permute(0, 2, 1).reshape(conv.out_channels, 3 * cin)    # [o][t*Cin + c]
+    return taps.reshape(3 * cin, B, taps.shape[-1]), w
+
+
+def _bn_training(bn, groups):
+    """nn.BatchNorm2d bookkeeping shared by the fused and the two-step forms: returns (use batch statistics, momentum)
+    and advances num_batches_tracked (once per view)."""
+    training = bn.training or not bn.track_running_stats
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        if _PENDING_COUNTERS is not None:
+            _PENDING_COUNTERS.append((bn.num_batches_tracked, groups))
+        else:
+            bn.num_batches_tracked.add_(groups)
+    return training, (0.0 if bn.momentum is None else bn.momentum)
+
+
+def conv_bn_act(conv, bn, x, residual=None, act=ops.ACT_NONE, slope=0.0, groups=1, weight=None, use_bias=True):
+    """[1x1 Conv2d -> BatchNorm2d -> activation -> + shortcut] on x (Cin, B, N) -> (Cout, B, N).  bf16 activations on
+    the GPU take the fused path (ops.conv_bn_act: hand-written GEMM with the batch statistics in its epilogue, one
+    normalise pass); everything else the GEMM + fused BatchNorm kernel pair.  `weight`: a 2-D (Cout, K) weight derived
+    from conv.weight (Downsample's tap matrix) instead of the conv's own; groups = views stacked along B."""
+    cin, B, N = x.shape
+    cout = conv.out_channels
+    cg = conv.groups if weight is None else 1
+    if torch.is_autocast_enabled() and x.is_cuda and x.dtype == torch.float32:
+        x = x.to(torch.get_autocast_dtype("cuda"))
+    x2 = x.reshape(cin, B * N)
+    bias = conv.bias if use_bias else None
+    if ops.conv_bn_act_supported(x2, cout, cg, groups):
+        training, momentum = _bn_training(bn, groups)
+        w = conv.weight if weight is None else weight
+        res = None if residual is None else residual.reshape(cout, B * N)
+        z = ops.conv_bn_act(x2, w, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum, bn.eps,
+                            bias, res, act, slope, cg, groups, getattr(conv, "_w_lowp", None) if weight is None else None)
+        return z.reshape(cout, B, N)
+    if weight is None:
+        y = conv1x1(conv, x)
+    else:
+        y = ops.conv1x1_rows(x2, weight).reshape(cout, B, N)
+    return bn_act(bn, y, pre_bias=bias, residual=residual, act=act, slope=slope, groups=groups)
 
 
 def bn_act(bn, y, pre_bias=None, residual=None, act=ops.ACT_NONE, slope=0.0, groups=1):
@@ -84,11 +129,6 @@ def bn_act(bn, y, pre_bias=None, residual=None, act=ops.ACT_NONE, slope=0.0, gro
     fused with the preceding conv's bias, the activation and the residual add.  groups = number of views stacked
     along B: each view keeps its OWN batch statistics and the running statistics advance once per view, exactly
     as when the views pass through the module one after the other (simclr/simclr.py:35,43)."""
-    training = bn.training or not bn.track_running_stats
-    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        if _PENDING_COUNTERS is not None:
-            _PENDING_COUNTERS.append((bn.num_batches_tracked, groups))
-        else:
-            bn.num_batches_tracked.add_(groups)
-    return ops.bn_act(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, training,
-                      0.0 if bn.momentum is None else bn.momentum, bn.eps, pre_bias, residual, act, slope, groups)
+    training, momentum = _bn_training(bn, groups)
+    return ops.bn_act(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum, bn.eps, pre_bias,
+                      residual, act, slope, groups)

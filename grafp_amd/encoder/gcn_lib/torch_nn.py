@@ -4,7 +4,7 @@ import torch
 from torch import nn
 
 from ... import ops
-from .._dense import bn_act, conv1x1, from_cbn, to_cbn
+from .._dense import bn_act, conv1x1, conv_bn_act, from_cbn, to_cbn
 
 _ACTS = {
     "relu": lambda inplace, slope, n: nn.ReLU(inplace),
@@ -76,17 +76,17 @@ class BasicConv(nn.Sequential):
         while i < len(mods):
             m = mods[i]
             if isinstance(m, nn.Conv2d):
-                y = conv1x1(m, x)
                 nxt = mods[i + 1] if i + 1 < len(mods) else None
                 if isinstance(nxt, nn.BatchNorm2d):
                     act_mod = mods[i + 2] if i + 2 < len(mods) else None
                     if isinstance(act_mod, nn.ReLU):
-                        x, i = bn_act(nxt, y, pre_bias=m.bias, act=ops.ACT_RELU, groups=groups), i + 3
+                        x, i = conv_bn_act(m, nxt, x, act=ops.ACT_RELU, groups=groups), i + 3
                     elif isinstance(act_mod, nn.LeakyReLU):
-                        x, i = bn_act(nxt, y, pre_bias=m.bias, act=ops.ACT_LEAKY, slope=act_mod.negative_slope, groups=groups), i + 3
+                        x, i = conv_bn_act(m, nxt, x, act=ops.ACT_LEAKY, slope=act_mod.negative_slope, groups=groups), i + 3
                     else:
-                        x, i = bn_act(nxt, y, pre_bias=m.bias, groups=groups), i + 2
+                        x, i = conv_bn_act(m, nxt, x, groups=groups), i + 2
                     continue
+                y = conv1x1(m, x)
                 x = y if m.bias is None else y + m.bias.reshape(-1, 1, 1).to(y.dtype)
             elif isinstance(m, (nn.BatchNorm2d, nn.InstanceNorm2d, nn.Dropout2d)):
                 x = bn_act(m, x, groups=groups) if isinstance(m, nn.BatchNorm2d) else to_cbn(m(from_cbn(x, x.new_empty(0, 0, 0, 0))))

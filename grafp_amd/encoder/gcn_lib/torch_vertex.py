@@ -11,7 +11,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ... import ops
-from .._dense import bn_act, conv1x1, from_cbn, to_cbn
+from .._dense import conv_bn_act, from_cbn, to_cbn
 from .pos_embed import get_2d_relative_pos_embed
 from .torch_edge import DenseDilatedKnnGraph
 from .torch_nn import BasicConv
@@ -91,9 +91,9 @@ class Grapher(nn.Module):
 
     def forward_cbn(self, x, groups=1):
         """x (C,B,N) -> (C,B,N): 3 GEMMs, 3 fused BN kernels, the k-NN build and the max-relative gather."""
-        y = bn_act(self.fc1[1], conv1x1(self.fc1[0], x), pre_bias=self.fc1[0].bias, groups=groups)
+        y = conv_bn_act(self.fc1[0], self.fc1[1], x, groups=groups)
         y = self.graph_conv.forward_cbn(y, groups)
-        return bn_act(self.fc2[1], conv1x1(self.fc2[0], y), pre_bias=self.fc2[0].bias, residual=x, groups=groups)
+        return conv_bn_act(self.fc2[0], self.fc2[1], y, residual=x, groups=groups)
 
     def forward(self, x):
         return from_cbn(self.forward_cbn(to_cbn(x)), x)

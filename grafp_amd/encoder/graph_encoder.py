@@ -10,7 +10,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .. import ops
-from ._dense import bn_act, conv1x1, conv3_stride2, deferred_counters, from_cbn, to_cbn
+from ._dense import bn_act, conv1x1, conv_bn_act, deferred_counters, from_cbn, stride2_operands, to_cbn
 from .gcn_lib.torch_nn import act_layer
 from .gcn_lib.torch_vertex import Grapher
 
@@ -29,7 +29,8 @@ class Downsample(nn.Module):
         self.conv = nn.Sequential(nn.Conv2d(in_dim, out_dim, 3, stride=2, padding=1), nn.BatchNorm2d(out_dim))
 
     def forward_cbn(self, x, groups=1):
-        return bn_act(self.conv[1], conv3_stride2(self.conv[0], x), pre_bias=self.conv[0].bias, groups=groups)
+        taps, w = stride2_operands(self.conv[0], x)
+        return conv_bn_act(self.conv[0], self.conv[1], taps, groups=groups, weight=w)
 
     def forward(self, x):
         return from_cbn(self.forward_cbn(to_cbn(x)), x)
@@ -43,7 +44,7 @@ class ChannelConv(nn.Module):
         self.conv = nn.Sequential(nn.Conv2d(in_dim, out_dim, kernel_size=1, bias=False), nn.BatchNorm2d(out_dim))
 
     def forward_cbn(self, x, groups=1):
-        return bn_act(self.conv[1], conv1x1(self.conv[0], x), groups=groups)
+        return conv_bn_act(self.conv[0], self.conv[1], x, groups=groups)
 
     def forward(self, x):
         return from_cbn(self.forward_cbn(to_cbn(x)), x)
@@ -64,10 +65,10 @@ class FFN(nn.Module):
     def forward_cbn(self, x, groups=1):
         """x (C,B,N) -> (C,B,N): 2 GEMMs + 2 fused BN kernels (ReLU and the shortcut add are inside them)."""
         if isinstance(self.act, torch.nn.ReLU):
-            h = bn_act(self.fc1[1], conv1x1(self.fc1[0], x), act=ops.ACT_RELU, groups=groups)
+            h = conv_bn_act(self.fc1[0], self.fc1[1], x, act=ops.ACT_RELU, groups=groups)
         else:
-            h = self.act(bn_act(self.fc1[1], conv1x1(self.fc1[0], x), groups=groups))
-        return bn_act(self.fc2[1], conv1x1(self.fc2[0], h), residual=x, groups=groups)
+            h = self.act(conv_bn_act(self.fc1[0], self.fc1[1], x, groups=groups))
+        return conv_bn_act(self.fc2[0], self.fc2[1], h, residual=x, groups=groups)
 
     def forward(self, x):
         return from_cbn(self.forward_cbn(to_cbn(x)), x)
@@ -126,8 +127,8 @@ class GraphEncoder(nn.Module):
         elif self._lowp is not None:
             self._lowp.clear()
         with deferred_counters():
-            x = bn_act(self.stem[1], conv1x1(self.stem[0], x), act=ops.ACT_LEAKY, slope=self.stem[2].negative_slope,
-                       groups=g)
+            x = conv_bn_act(self.stem[0], self.stem[1], x, act=ops.ACT_LEAKY, slope=self.stem[2].negative_slope,
+                            groups=g)
             for mod in self.backbone:
                 if isinstance(mod, Downsample):
                     x = mod.forward_cbn(x, g)

@@ -660,6 +660,105 @@ def bn_affine(y, tab, views=1, residual=None, act=ACT_NONE, slope=0.0):
     return out
 
 
+def _group_transpose(wl, groups):
+    """(R, K/g) grouped weight -> (K, R/g): per group the transposed block, the operand of the data-gradient GEMM."""
+    R, Kg = wl.shape
+    if groups == 1:
+        return wl.t().contiguous()
+    return wl.reshape(groups, R // groups, Kg).transpose(1, 2).reshape(groups * Kg, R // groups).contiguous()
+
+
+def _bn_bwd(y, dz, C, M, views, pb, g32, b32, mean, invstd, act, slope, training):
+    """BatchNorm + activation backward on (C, M) rows (grafp_bn_bwd_1pass): -> dy, dgamma, dbeta, dpre_bias."""
+    dy = torch.empty_like(y)
+    dgamma = torch.empty((C,), dtype=torch.float32, device=y.device)
+    dbeta = torch.empty((C,), dtype=torch.float32, device=y.device)
+    dpb = torch.empty((C,), dtype=torch.float32, device=y.device) if pb is not None else None
+    nbytes = lib.grafp_bn_workspace(C, M)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=y.device)
+    with _timed("bn_bwd", (C, M, y.element_size())):
+        check(lib.grafp_bn_bwd_1pass(_p(y), _p(dz), _DT[y.dtype], C, M, views, _p(pb), _p(g32), _p(b32), _p(mean),
+                                     _p(invstd), act, slope, int(training), _p(dy), _p(dgamma), _p(dbeta), _p(dpb),
+                                     _p(ws), nbytes, _p(_bn_sync(y.device, C, M)), _stream()), "bn_bwd")
+    return dy, dgamma, dbeta, dpb
+
+
+def _wgrad_bf16(g, x, cout, cin, groups, M):
+    dw = torch.empty((cout, cin // groups), dtype=torch.float32, device=x.device)
+    nbytes = lib.grafp_conv1x1_wgrad_workspace(cout, cin, groups, M)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
+    with _timed("conv1x1_wgrad", (cout, cin, groups, M)):
+        check(lib.grafp_conv1x1_wgrad_bf16(_p(g), _p(x), cout, cin, groups, M, _p(dw), _p(ws), nbytes, _stream()),
+              "conv1x1_wgrad")
+    return dw
+
+
+class _ConvBnAct(torch.autograd.Function):
+    """z = act(BatchNorm(W x + bias)) + residual on bf16 (C, M) rows, the bf16 training path of every
+    [Conv2d(1x1) -> BatchNorm2d -> activation -> shortcut] chain: ONE hand-written GEMM whose epilogue also yields the
+    batch statistics, a per-row finalize, one normalise/activate/add pass.  Backward: BatchNorm backward (single
+    pass), data gradient by the same GEMM kernel on the transposed weight, weight gradient by the split-K kernel."""
+
+    @staticmethod
+    def forward(ctx, x, w, w_lowp, conv_groups, views, gamma, beta, pre_bias, residual, running_mean, running_var,
+                training, momentum, eps, act, slope):
+        x = x.detach()
+        K, M = x.shape
+        R = w.shape[0]
+        if w_lowp is not None and w_lowp.dtype == torch.bfloat16 and w_lowp.numel() == w.numel():
+            wl = w_lowp.detach().reshape(R, -1)
+        else:
+            wl = w.detach().reshape(R, -1).to(torch.bfloat16)
+        g32, b32 = _f32c(gamma), _f32c(beta)
+        pb = None if pre_bias is None else _f32c(pre_bias)
+        if training:
+            y, part = conv1x1_gemm(wl, x, conv_groups, views, stats=True)
+        else:
+            y, part = conv1x1_gemm(wl, x, conv_groups, views), None
+        mean, invstd, tab = bn_finalize(part, R, K, conv_groups, M, views, g32, b32, pb, running_mean, running_var,
+                                        training, momentum, eps)
+        res = None if residual is None else residual.detach()
+        z = bn_affine(y, tab, views, res, act, slope)
+        ctx.save_for_backward(x, wl, y, mean, invstd, g32, b32, pb if pb is not None else mean.new_empty(0))
+        ctx.cfg = (R, K, M, conv_groups, views, act, float(slope), bool(training), pb is not None, residual is not None,
+                   tuple(w.shape))
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, wl, y, mean, invstd, g32, b32, pb = ctx.saved_tensors
+        R, K, M, cg, views, act, slope, training, has_pb, has_res, wfull = ctx.cfg
+        dz = dz.detach().to(torch.bfloat16).contiguous()
+        dy, dgamma, dbeta, dpb = _bn_bwd(y, dz, R, M, views, pb if has_pb else None, g32, b32, mean, invstd, act, slope,
+                                         training)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = conv1x1_gemm(_group_transpose(wl, cg), dy, cg, 1)
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dw = _wgrad_bf16(dy, x, R, K, cg, M).reshape(wfull)
+        return (dx, dw, None, None, None, dgamma, dbeta, dpb, (dz if has_res else None), None, None, None, None, None,
+                None, None)
+
+
+def conv_bn_act_supported(x, cout, conv_groups, views):
+    """The fused bf16 path applies to HIP bf16 (K, M) rows whose shape both GEMMs (forward, data gradient) accept."""
+    if not (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 2):
+        return False
+    if os.environ.get("GRAFP_LIBRARY_GEMM", "0") == "1":
+        return False
+    K, M = x.shape
+    return gemm_supported(cout, K, conv_groups, M, views) and gemm_supported(K, cout, conv_groups, M, 1)
+
+
+def conv_bn_act(x, w, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, pre_bias=None,
+                residual=None, act=ACT_NONE, slope=0.0, conv_groups=1, views=1, w_lowp=None):
+    """act(BatchNorm(W x + pre_bias)) + residual for bf16 (K, M) rows (see _ConvBnAct)."""
+    return _ConvBnAct.apply(x.contiguous(), w, w_lowp, int(conv_groups), int(views), gamma, beta, pre_bias, residual,
+                            running_mean, running_var, bool(training), float(momentum), float(eps), int(act),
+                            float(slope))
+
+
 # ------------------------------------------------------------------------------------------------
 # K12  NT-Xent
 # ------------------------------------------------------------------------------------------------
