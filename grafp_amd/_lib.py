@@ -60,6 +60,8 @@ SIGNATURES = {
     "grafp_bn_affine_bf16": (_I, [_P, _I, _L, _I, _P, _P, _I, _F, _P, _P]),
     "grafp_conv1x1_wgrad_workspace": (_Z, [_I, _I, _I, _L]),
     "grafp_conv1x1_wgrad_bf16": (_I, [_P, _P, _I, _I, _I, _L, _P, _P, _Z, _P]),
+    "grafp_conv1x1_wgrad_pro_workspace": (_Z, [_I, _I, _I, _L, _I]),
+    "grafp_conv1x1_wgrad_pro_bf16": (_I, [_P, _P, _I, _I, _I, _L, _I, _P, _I, _F, _P, _P, _Z, _P]),
     "grafp_conv1x1_wgrad_f32_workspace": (_Z, [_I, _I, _I, _L]),
     "grafp_conv1x1_wgrad_f32": (_I, [_P, _P, _I, _I, _I, _L, _P, _P, _Z, _P]),
     "grafp_ntxent_workspace": (_Z, [_I]),

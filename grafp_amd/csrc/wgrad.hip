@@ -15,6 +15,7 @@
 //   * partial tiles go to a (S, Cout, Cin/g) f32 scratch, summed by wgrad_reduce_kernel (deterministic, no atomics).
 // HBM-bound: (Cout + Cin) * M * 2 bytes per launch (+ re-reads of the smaller operand across output tiles).
 #include "common.h"
+#include "dma_ring.h"
 
 namespace grafp {
 
@@ -226,6 +227,224 @@ __global__ __launch_bounds__(256) void wgrad3_partial_kernel(const float *__rest
     }
 }
 
+// ---- the LDS-DMA form (every shape of the encoder: rows per group % 32 == 0, M per view % 64 == 0) ---------------------
+// Same split-K streaming reduction, restructured like gemm.hip: 64-column chunks of the G tile (TO rows x 128 B) and the
+// X tile (TC rows x 128 B) arrive by global_load_lds_dwordx4 into a ring of NS stages with NS-1 chunks in flight across
+// ONE raw s_barrier per chunk and counted vmcnt (no staging registers, no ds_write pass, no second barrier -- the
+// register-staged kernel above spends 119 of 128 us on loads + LDS writes + barriers on the wide shapes).  Rows are
+// 128 B; their eight 16-byte slots are XOR-swizzled by (row >> 1) & 7 on the DMA source side and on the ds_read_b128
+// side: a 16-lane read group covers 16 distinct (row & 1, (row >> 1) & 7) pairs = all 64 banks once.
+//   T: 2 x 2 waves x (1 x 1) MFMA tiles ->  64 x  64 outputs, 4 stages, 2 workgroups per CU (fc1/gconv of stages 0-1)
+//   S: 2 x 2 waves x (2 x 2)            -> 128 x 128 outputs, 2 stages, 2 workgroups per CU
+//   L: 2 x 4 waves x (4 x 2)            -> 256 x 256 outputs, 2 stages, 1 workgroup per CU (128 flop per DMA byte)
+// PRO: X is the RAW output of the previous layer's convolution; its BatchNorm + activation (per X row: scale, shift of
+// the slice's view) is applied to the X tile in LDS, so the normalised activation the forward pass never wrote is not
+// needed here either (grafp_conv1x1_gemm_bf16's pro_tab, same table).
+template <int WR_, int WM_, int RT_, int CT_, int NS_> struct WgCfg {
+    static constexpr int WR = WR_, WM = WM_, RT = RT_, CT = CT_, NS = NS_, NW = WR_ * WM_, THREADS = 64 * NW;
+    static constexpr int TO = WR_ * RT_ * 32, TC = WM_ * CT_ * 32;
+    static constexpr int KC = 64;                                  // contraction (m) per chunk: 128-byte rows
+    static constexpr int G_BYTES = TO * 128, X_BYTES = TC * 128, STAGE = G_BYTES + X_BYTES;
+    static constexpr int G_DMA = TO / 8 / NW, X_DMA = TC / 8 / NW;   // DMA instructions (8 rows each) per wave and chunk
+    static_assert(TO % (8 * NW) == 0 && TC % (8 * NW) == 0, "whole DMA instructions per wave");
+};
+typedef WgCfg<2, 2, 1, 1, 4> WgT;
+typedef WgCfg<2, 2, 2, 2, 2> WgS;
+typedef WgCfg<2, 4, 4, 2, 2> WgL;
+
+template <typename CFG, bool PRO>
+__global__ __launch_bounds__(CFG::THREADS) void wgrad_dma_kernel(
+    const unsigned short *__restrict__ G, const unsigned short *__restrict__ X, int64_t M, int cout_g, int cin_g,
+    int tiles_o, int tiles_c, int slices_view, int64_t cols_per_slice, int views, const float2 *__restrict__ pro_tab,
+    int pro_act, float pro_slope, float *__restrict__ part, int nblocks) {
+    constexpr int NS = CFG::NS, D = NS - 1, RT = CFG::RT, CT = CFG::CT, KC = CFG::KC;
+    constexpr int DMA_PER_CHUNK = CFG::G_DMA + CFG::X_DMA;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *const s_tab = smem + NS * CFG::STAGE;            // PRO: TC x float2
+
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wo = wave / CFG::WM, wc = wave % CFG::WM;
+    const unsigned lds0 = (unsigned)(uintptr_t)(gm_lptr)smem;
+    const int ntiles = tiles_o * tiles_c;
+    const int logical = xcd_remap(blockIdx.x, nblocks);
+    const int slice = logical / ntiles, tile = logical - slice * ntiles, grp = blockIdx.z;
+    const int view = slice / slices_view, sl = slice - view * slices_view;
+    const int o0 = (tile / tiles_c) * CFG::TO, c0 = (tile % tiles_c) * CFG::TC;
+    const int64_t Mv = M / views;
+    const int64_t m_begin = (int64_t)view * Mv + (int64_t)sl * cols_per_slice;
+    int64_t m_len = Mv - (int64_t)sl * cols_per_slice;
+    if (m_len > cols_per_slice) m_len = cols_per_slice;
+    const int T = (int)(m_len / KC);
+    const unsigned short *Gg = G + (size_t)grp * cout_g * M + m_begin;
+    const unsigned short *Xg = X + (size_t)grp * cin_g * M + m_begin;
+
+    if (PRO) {
+        const float2 *src = pro_tab + ((size_t)grp * cin_g) * views;
+        for (int r = tid; r < CFG::TC; r += CFG::THREADS) {
+            const int c = c0 + r < cin_g ? c0 + r : cin_g - 1;
+            reinterpret_cast<float2 *>(s_tab)[r] = src[(size_t)c * views + view];
+        }
+    }
+    // DMA: instruction q covers tile rows 8q .. 8q+7 (128 B each); lane -> row 8q + lane/8, slot' = lane & 7 holds the
+    // source slot slot' ^ ((row >> 1) & 7).  Rows beyond the matrix re-read its last row (their outputs are not stored).
+    const unsigned short *g_src[CFG::G_DMA], *x_src[CFG::X_DMA];
+#pragma unroll
+    for (int j = 0; j < CFG::G_DMA; ++j) {
+        const int row = 8 * (CFG::G_DMA * wave + j) + (lane >> 3);
+        int o = o0 + row;
+        if (o > cout_g - 1) o = cout_g - 1;
+        g_src[j] = Gg + (size_t)o * M + (((lane & 7) ^ ((row >> 1) & 7)) << 3);
+    }
+#pragma unroll
+    for (int j = 0; j < CFG::X_DMA; ++j) {
+        const int row = 8 * (CFG::X_DMA * wave + j) + (lane >> 3);
+        int c = c0 + row;
+        if (c > cin_g - 1) c = cin_g - 1;
+        x_src[j] = Xg + (size_t)c * M + (((lane & 7) ^ ((row >> 1) & 7)) << 3);
+    }
+    auto issue = [&](int t) {
+        const unsigned st = lds0 + (t % NS) * CFG::STAGE;
+#pragma unroll
+        for (int j = 0; j < CFG::G_DMA; ++j) gm_dma16(g_src[j] + (size_t)t * KC, st + (CFG::G_DMA * wave + j) * 1024);
+#pragma unroll
+        for (int j = 0; j < CFG::X_DMA; ++j)
+            gm_dma16(x_src[j] + (size_t)t * KC, st + CFG::G_BYTES + (CFG::X_DMA * wave + j) * 1024);
+    };
+    // fragment read offsets: row * 128 + ((2 ks + half) ^ ((row >> 1) & 7)) * 16; the XOR is applied per k-step below
+    int goff[RT], gx[RT], xoff[CT], xx[CT];
+#pragma unroll
+    for (int a = 0; a < RT; ++a) {
+        const int row = wo * 32 * RT + a * 32 + l31;
+        goff[a] = row * 128;
+        gx[a] = (row >> 1) & 7;
+    }
+#pragma unroll
+    for (int b = 0; b < CT; ++b) {
+        const int row = wc * 32 * CT + b * 32 + l31;
+        xoff[b] = CFG::G_BYTES + row * 128;
+        xx[b] = (row >> 1) & 7;
+    }
+    f32x16 acc[RT][CT];
+#pragma unroll
+    for (int a = 0; a < RT; ++a)
+#pragma unroll
+        for (int b = 0; b < CT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+    if (PRO) __syncthreads();
+#pragma unroll
+    for (int c = 0; c < D; ++c)
+        if (c < T) issue(c);
+    for (int t = 0; t < T; ++t) {
+        // chunks t .. min(t + D, T) - 1 are in flight: allow all but chunk t's
+        const int ahead = (T - 1 - t < D - 1) ? T - 1 - t : D - 1;
+        gm_wait_allowed(__builtin_amdgcn_readfirstlane(ahead * DMA_PER_CHUNK));
+        __builtin_amdgcn_s_barrier();
+        if (t + D < T) issue(t + D);
+        unsigned char *const st = smem + (t % NS) * CFG::STAGE;
+        if (PRO) {
+            // X tile: TC rows x 8 slots; every thread the same number of 16-byte pieces
+            constexpr int PIECES = CFG::TC * 8 / CFG::THREADS;
+#pragma unroll
+            for (int j = 0; j < PIECES; ++j) {
+                const int p = tid + CFG::THREADS * j;
+                const float2 ss = reinterpret_cast<const float2 *>(s_tab)[p >> 3];
+                uint4 *cell = reinterpret_cast<uint4 *>(st + CFG::G_BYTES + p * 16);
+                uint4 v = *cell;
+                unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float lo = __uint_as_float(w[e] << 16), hi = __uint_as_float(w[e] & 0xffff0000u);
+                    lo = __builtin_fmaf(lo, ss.x, ss.y);
+                    hi = __builtin_fmaf(hi, ss.x, ss.y);
+                    if (pro_act == 1) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
+                    else if (pro_act == 2) { lo = lo > 0.f ? lo : lo * pro_slope; hi = hi > 0.f ? hi : hi * pro_slope; }
+                    w[e] = gm_pack_bf16(lo, hi);
+                }
+                *cell = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+#pragma unroll
+        for (int ks = 0; ks < KC / 16; ++ks) {
+            gm_bf16x8 av[RT], bv[CT];
+#pragma unroll
+            for (int a = 0; a < RT; ++a)
+                av[a] = *reinterpret_cast<const gm_bf16x8 *>(st + goff[a] + (((2 * ks + half) ^ gx[a]) << 4));
+#pragma unroll
+            for (int b = 0; b < CT; ++b)
+                bv[b] = *reinterpret_cast<const gm_bf16x8 *>(st + xoff[b] + (((2 * ks + half) ^ xx[b]) << 4));
+#pragma unroll
+            for (int a = 0; a < RT; ++a)
+#pragma unroll
+                for (int b = 0; b < CT; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[a], bv[b], acc[a][b], 0, 0, 0);
+        }
+    }
+    // partial tile -> part[slice][grp][o][c]
+    float *pp = part + ((size_t)slice * gridDim.z + grp) * cout_g * cin_g;
+#pragma unroll
+    for (int a = 0; a < RT; ++a)
+#pragma unroll
+        for (int b = 0; b < CT; ++b) {
+            const int c = c0 + wc * 32 * CT + b * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = o0 + wo * 32 * RT + a * 32 + mfma_row(r, half);
+                if (o < cout_g && c < cin_g) pp[(size_t)o * cin_g + c] = acc[a][b][r];
+            }
+        }
+}
+
+struct WgDmaPlan {
+    int cfg;                      // 0 = T (64 x 64), 1 = S (128 x 128), 2 = L (256 x 256)
+    int to, tc, tiles_o, tiles_c, slices_view, nslices;
+    int64_t cols;
+};
+static int wg_force_cfg() {
+    static int v = -2;
+    if (v == -2) {
+        const char *e = getenv("GRAFP_WGRAD_TILE");            // "T" / "S" / "L" / "old": measurements
+        v = !e ? -1 : (e[0] == 'T' ? 0 : e[0] == 'S' ? 1 : e[0] == 'L' ? 2 : 3);
+    }
+    return v;
+}
+static bool wgrad_dma_ok(int cout_g, int cin_g, int64_t M, int views) {
+    return wg_force_cfg() != 3 && cout_g % 32 == 0 && cin_g % 32 == 0 && views >= 1 && M % views == 0 &&
+           (M / views) % 64 == 0;
+}
+static WgDmaPlan wgrad_dma_plan(int cout_g, int cin_g, int groups, int64_t M, int views, bool pro) {
+    WgDmaPlan p;
+    const int64_t outs = (int64_t)cout_g * cin_g;
+    // measured (tools/gemm_bench.py --wgrad, 512 clip-views): the 64 x 64 tile wins up to 2^19 outputs (many small
+    // workgroups, partial sums of a few MB; its operand re-reads are L2 hits at ~14 TB/s), the 128 x 128 tile beyond
+    // (stage 3, and the FFN layers of stage 2 tie); with the in-LDS normalisation the 128 tile from 256 operand rows
+    // (half the transform work per output).  The 256 x 256 tile (L) loses everywhere to its partial-sum traffic.
+    p.cfg = (outs >= (1 << 19) && cout_g >= 128 && cin_g >= 128) ? 1 : 0;
+    if (pro && cin_g >= 256 && cout_g >= 128) p.cfg = 1;
+    if (wg_force_cfg() >= 0 && wg_force_cfg() <= 2) p.cfg = wg_force_cfg();
+    p.to = p.tc = p.cfg == 2 ? 256 : (p.cfg == 1 ? 128 : 64);
+    p.tiles_o = (cout_g + p.to - 1) / p.to;
+    p.tiles_c = (cin_g + p.tc - 1) / p.tc;
+    const int64_t tiles = (int64_t)p.tiles_o * p.tiles_c * groups;
+    const int64_t Mv = M / views;
+    // two rounds of resident workgroups (L: one per CU, T/S: two), at least 8 chunks per slice
+    const int64_t target = p.cfg == 2 ? 512 : 1024;
+    int64_t sv = (target + tiles * views - 1) / (tiles * views);
+    const int64_t max_sv = (Mv / 64 + 7) / 8;
+    if (sv > max_sv) sv = max_sv;
+    if (sv < 1) sv = 1;
+    int64_t cols = (Mv + sv - 1) / sv;
+    cols = (cols + 63) / 64 * 64;
+    p.cols = cols;
+    p.slices_view = (int)((Mv + cols - 1) / cols);
+    p.nslices = p.slices_view * views;
+    return p;
+}
+
 // out[i] = sum_k part[k][i]: 16 outputs x 16 split-lanes per workgroup, fixed summation order (deterministic)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ part, int S, int64_t n,
                                                            float *__restrict__ out) {
@@ -278,29 +497,70 @@ static WgradPlan wgrad_plan(int cout_g, int cin_g, int groups, int64_t M) {
 
 }  // namespace grafp
 
-extern "C" size_t grafp_conv1x1_wgrad_workspace(int Cout, int Cin, int groups, int64_t M) {
+extern "C" size_t grafp_conv1x1_wgrad_pro_workspace(int Cout, int Cin, int groups, int64_t M, int views) {
     using namespace grafp;
     if (Cout <= 0 || Cin <= 0 || groups <= 0 || M <= 0 || Cout % groups || Cin % groups) return 0;
-    const WgradPlan p = wgrad_plan(Cout / groups, Cin / groups, groups, M);
-    return (size_t)p.S * Cout * (Cin / groups) * sizeof(float);
+    const int cout_g = Cout / groups, cin_g = Cin / groups;
+    if (wgrad_dma_ok(cout_g, cin_g, M, views)) {
+        const WgDmaPlan p = wgrad_dma_plan(cout_g, cin_g, groups, M, views, false);
+        const WgDmaPlan q = wgrad_dma_plan(cout_g, cin_g, groups, M, views, true);
+        return (size_t)(p.nslices > q.nslices ? p.nslices : q.nslices) * Cout * cin_g * sizeof(float);
+    }
+    const WgradPlan p = wgrad_plan(cout_g, cin_g, groups, M);
+    return (size_t)p.S * Cout * cin_g * sizeof(float);
 }
 
-extern "C" int grafp_conv1x1_wgrad_bf16(const void *grad_out, const void *x, int Cout, int Cin, int groups, int64_t M,
-                                        float *dweight, void *ws, size_t ws_bytes, grafp_stream_t stream) {
+extern "C" size_t grafp_conv1x1_wgrad_workspace(int Cout, int Cin, int groups, int64_t M) {
+    return grafp_conv1x1_wgrad_pro_workspace(Cout, Cin, groups, M, 1);
+}
+
+extern "C" int grafp_conv1x1_wgrad_pro_bf16(const void *grad_out, const void *x, int Cout, int Cin, int groups,
+                                            int64_t M, int views, const float *pro_tab, int pro_act, float pro_slope,
+                                            float *dweight, void *ws, size_t ws_bytes, grafp_stream_t stream) {
     using namespace grafp;
     GRAFP_REQUIRE(grad_out && x && dweight, "conv1x1_wgrad: null pointer");
     GRAFP_REQUIRE(Cout > 0 && Cin > 0 && groups > 0 && M > 0 && Cout % groups == 0 && Cin % groups == 0,
                   "conv1x1_wgrad: bad shape Cout=%d Cin=%d groups=%d M=%lld", Cout, Cin, groups, (long long)M);
     GRAFP_REQUIRE((((uintptr_t)grad_out | (uintptr_t)x) & 15) == 0, "conv1x1_wgrad: operands must be 16-byte aligned");
-    const size_t need = grafp_conv1x1_wgrad_workspace(Cout, Cin, groups, M);
+    GRAFP_REQUIRE(pro_act >= 0 && pro_act <= 2, "conv1x1_wgrad: bad activation %d", pro_act);
+    const size_t need = grafp_conv1x1_wgrad_pro_workspace(Cout, Cin, groups, M, views);
     if (!ws || ws_bytes < need) {
         set_error("conv1x1_wgrad: workspace %zu bytes < required %zu", ws_bytes, need);
         return GRAFP_ERR_WORKSPACE;
     }
     const int cout_g = Cout / groups, cin_g = Cin / groups;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n = (int64_t)Cout * cin_g;
+    if (wgrad_dma_ok(cout_g, cin_g, M, views)) {
+        const WgDmaPlan p = wgrad_dma_plan(cout_g, cin_g, groups, M, views, pro_tab != nullptr);
+        const int nblocks = p.nslices * p.tiles_o * p.tiles_c;
+        const dim3 grid(nblocks, 1, groups);
+#define WG_LAUNCH(CFG, PRO)                                                                                              \
+    do {                                                                                                                 \
+        const size_t lds = (size_t)CFG::NS * CFG::STAGE + ((PRO) ? (size_t)CFG::TC * 8 : 0);                             \
+        (void)hipFuncSetAttribute((const void *)wgrad_dma_kernel<CFG, PRO>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                  (int)lds);                                                                             \
+        hipLaunchKernelGGL((wgrad_dma_kernel<CFG, PRO>), grid, dim3(CFG::THREADS), lds, s,                               \
+                           (const unsigned short *)grad_out, (const unsigned short *)x, M, cout_g, cin_g, p.tiles_o,     \
+                           p.tiles_c, p.slices_view, p.cols, views, (const float2 *)pro_tab, pro_act, pro_slope,         \
+                           (float *)ws, nblocks);                                                                        \
+    } while (0)
+        if (pro_tab) {
+            if (p.cfg == 2) WG_LAUNCH(WgL, true); else if (p.cfg == 1) WG_LAUNCH(WgS, true); else WG_LAUNCH(WgT, true);
+        } else {
+            if (p.cfg == 2) WG_LAUNCH(WgL, false); else if (p.cfg == 1) WG_LAUNCH(WgS, false); else WG_LAUNCH(WgT, false);
+        }
+#undef WG_LAUNCH
+        GRAFP_CHECK_LAUNCH("wgrad_dma_kernel");
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, s, (const float *)ws,
+                           p.nslices, n, dweight);
+        GRAFP_CHECK_LAUNCH("wgrad_reduce_kernel");
+        return GRAFP_OK;
+    }
+    GRAFP_REQUIRE(!pro_tab, "conv1x1_wgrad: the normalise-on-load form needs rows per group %% 32 == 0 and columns per "
+                            "view %% 64 == 0");
     const WgradPlan p = wgrad_plan(cout_g, cin_g, groups, M);
     GRAFP_REQUIRE((int64_t)p.S * p.tiles_o * p.tiles_c < (1ll << 31), "conv1x1_wgrad: output too large");
-    hipStream_t s = (hipStream_t)stream;
     const dim3 grid(p.S * p.tiles_o * p.tiles_c, 1, groups);
     const size_t lds = (size_t)2 * p.tw * WG_LS;
     if (p.tw == 64) {
@@ -312,11 +572,16 @@ extern "C" int grafp_conv1x1_wgrad_bf16(const void *grad_out, const void *x, int
                            (const unsigned short *)x, M, cout_g, cin_g, p.tiles_o, p.tiles_c, p.cols, (float *)ws);
     }
     GRAFP_CHECK_LAUNCH("wgrad_partial_kernel");
-    const int64_t n = (int64_t)Cout * cin_g;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, s, (const float *)ws, p.S, n,
                        dweight);
     GRAFP_CHECK_LAUNCH("wgrad_reduce_kernel");
     return GRAFP_OK;
+}
+
+extern "C" int grafp_conv1x1_wgrad_bf16(const void *grad_out, const void *x, int Cout, int Cin, int groups, int64_t M,
+                                        float *dweight, void *ws, size_t ws_bytes, grafp_stream_t stream) {
+    return grafp_conv1x1_wgrad_pro_bf16(grad_out, x, Cout, Cin, groups, M, 1, nullptr, 0, 0.0f, dweight, ws, ws_bytes,
+                                        stream);
 }
 
 static grafp::WgradPlan wgrad3_plan(int cout_g, int cin_g, int groups, int64_t M) {

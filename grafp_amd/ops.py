@@ -683,14 +683,20 @@ def _bn_bwd(y, dz, C, M, views, pb, g32, b32, mean, invstd, act, slope, training
     return dy, dgamma, dbeta, dpb
 
 
-def _wgrad_bf16(g, x, cout, cin, groups, M):
+def _wgrad_bf16(g, x, cout, cin, groups, M, views=1, pro_tab=None, pro_act=ACT_NONE, pro_slope=0.0):
+    """dW = g f(x)^T for bf16 (rows, M) operands -> (cout, cin/groups) f32; pro_tab (cin, views, 2): f = the BatchNorm
+    + activation of the layer that produced x, applied on the fly (see conv1x1_gemm)."""
     dw = torch.empty((cout, cin // groups), dtype=torch.float32, device=x.device)
-    nbytes = lib.grafp_conv1x1_wgrad_workspace(cout, cin, groups, M)
+    nbytes = lib.grafp_conv1x1_wgrad_pro_workspace(cout, cin, groups, M, views)
     ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
+    tab = None if pro_tab is None else _f32c(pro_tab)
     with _timed("conv1x1_wgrad", (cout, cin, groups, M)):
-        check(lib.grafp_conv1x1_wgrad_bf16(_p(g), _p(x), cout, cin, groups, M, _p(dw), _p(ws), nbytes, _stream()),
-              "conv1x1_wgrad")
+        check(lib.grafp_conv1x1_wgrad_pro_bf16(_p(g), _p(x), cout, cin, groups, M, views, _p(tab), int(pro_act),
+                                               float(pro_slope), _p(dw), _p(ws), nbytes, _stream()), "conv1x1_wgrad")
     return dw
+
+
+conv1x1_wgrad = _wgrad_bf16
 
 
 class _ConvBnAct(torch.autograd.Function):

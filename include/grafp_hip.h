@@ -227,6 +227,14 @@ int grafp_bn_affine_bf16(const void *y, int C, int64_t M, int views, const float
 size_t grafp_conv1x1_wgrad_workspace(int Cout, int Cin, int groups, int64_t M);
 int grafp_conv1x1_wgrad_bf16(const void *grad_out, const void *x, int Cout, int Cin, int groups, int64_t M,
                              float *dweight, void *ws, size_t ws_bytes, grafp_stream_t stream);
+/* The same weight gradient when x is the RAW output of the previous convolution and the operand of this layer was
+ * act(BatchNorm(x)) applied on the fly (grafp_conv1x1_gemm_bf16's pro_tab): the (Cin, views, 2) table is applied to the
+ * x tile in LDS again, so the normalised activation is never materialised in either direction.  views: column segments
+ * with their own table entries (a split-K slice never straddles two); pro_tab NULL = plain weight gradient. */
+size_t grafp_conv1x1_wgrad_pro_workspace(int Cout, int Cin, int groups, int64_t M, int views);
+int grafp_conv1x1_wgrad_pro_bf16(const void *grad_out, const void *x, int Cout, int Cin, int groups, int64_t M,
+                                 int views, const float *pro_tab, int pro_act, float pro_slope, float *dweight,
+                                 void *ws, size_t ws_bytes, grafp_stream_t stream);
 /* f32 operands (the f32 "parity" mode of the step): the same split-K streaming reduction with each value split into
  * hi = bf16(v), lo = bf16(v - hi) on the way into LDS and three bf16 MFMAs per tile step (Gh Xh + Gh Xl + Gl Xh; the
  * dropped Gl Xl term and the 16-bit representation are ~2^-16 relative, f32 accumulation).  Same layouts as above

@@ -118,3 +118,35 @@ def test_gemm_rejects_unsupported_shapes():
     w, x = _rand((64, 8), 1), _rand((8, 1024), 2)
     with pytest.raises(RuntimeError):
         ops.conv1x1_gemm(w, x)
+
+
+# (cout, cin, groups, M, views): the three tile configurations (64 / 128 / 256), grouped, ragged rows, short slices
+WG_SHAPES = [(64, 64, 1, 8192, 2), (256, 64, 1, 16384, 2), (128, 128, 4, 8192, 2), (128, 256, 1, 4096, 1),
+             (1024, 256, 1, 2048, 2), (512, 2048, 1, 1024, 2), (96, 160, 1, 1280, 1), (64, 256, 1, 262144, 2)]
+
+
+@pytest.mark.parametrize("cout,cin,groups,M,views", WG_SHAPES)
+@pytest.mark.parametrize("pro", [False, True])
+def test_wgrad_dma(cout, cin, groups, M, views, pro):
+    """LDS-DMA weight gradient (plain and with the normalise-on-load X operand) vs a float64 product of the same bf16
+    operands: 2e-3 of the largest entry."""
+    from grafp_amd import ops
+    g = _rand((cout, M), 21)
+    x = _rand((cin, M), 22, 1.5, 0.5)
+    tab = None
+    xe = x.float()
+    if pro:
+        gen = torch.Generator().manual_seed(23)
+        tab = torch.stack((torch.rand((cin, views), generator=gen) + 0.5, torch.randn((cin, views), generator=gen)), -1).to(DEV)
+        t = tab.reshape(cin, views, 1, 2)
+        xe = torch.relu(torch.addcmul(t[..., 1], x.float().reshape(cin, views, -1), t[..., 0])).reshape(cin, M)
+        xe = xe.to(torch.bfloat16).float()
+    dw = ops.conv1x1_wgrad(g, x, cout, cin, groups, M, views, tab, ops.ACT_RELU if pro else ops.ACT_NONE)
+    gd, xd = g.double(), xe.double()
+    og, cg = cout // groups, cin // groups
+    want = torch.cat([gd[i * og:(i + 1) * og] @ xd[i * cg:(i + 1) * cg].t() for i in range(groups)], dim=0)
+    assert dw.shape == (cout, cg) and dw.dtype == torch.float32
+    tol = (4e-3 if pro else 2e-3) * float(want.abs().max())      # pro: an f32 fma can flip an operand's bf16 rounding
+    assert float((dw.double() - want).abs().max()) <= tol
+    # deterministic (fixed-order reduction, no atomics)
+    assert torch.equal(dw, ops.conv1x1_wgrad(g, x, cout, cin, groups, M, views, tab, ops.ACT_RELU if pro else ops.ACT_NONE))

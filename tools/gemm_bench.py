@@ -25,12 +25,34 @@ def timeit(fn, reps=20):
     return s.elapsed_time(e) / reps * 1e3          # us
 
 
+def wgrad(args, dev):
+    """dW = G X^T per layer shape (GRAFP_WGRAD_TILE=T/S/L/old selects a tile configuration / the register-staged kernel)."""
+    depth, tot = (2, 2, 6, 2), 0.0
+    for stage, (C, N) in enumerate(((64, 1024), (128, 512), (256, 256), (512, 128))):
+        M = args.clips * N
+        for name, co, ci, g in (("fc1", C, C, 1), ("gconv g4", 2 * C, 2 * C, 4), ("gfc2", C, 2 * C, 1),
+                                ("ffn1", 4 * C, C, 1), ("ffn2", C, 4 * C, 1)):
+            G = torch.randn(co, M, device=dev).to(torch.bfloat16)
+            X = torch.randn(ci, M, device=dev).to(torch.bfloat16)
+            tab = torch.rand(ci, args.views, 2, device=dev)
+            t0 = timeit(lambda: ops.conv1x1_wgrad(G, X, co, ci, g, M, args.views))
+            t1 = timeit(lambda: ops.conv1x1_wgrad(G, X, co, ci, g, M, args.views, tab, 1))
+            by, fl = (co + ci) * M * 2.0, 2.0 * co * (ci // g) * M
+            tot += t0 * depth[stage]
+            print(f"s{stage} {name:9s} {co:5d} x {ci:5d} g={g} M={M:7d}  wgrad {t0:7.1f} us (+pro {t1:7.1f}) | "
+                  f"{by / t0 / 1e6:5.2f} TB/s {fl / t0 / 1e6:7.1f} TF/s", flush=True)
+    print(f"weighted by blocks per stage: {tot / 1e3:.2f} ms")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--views", type=int, default=2)
     ap.add_argument("--clips", type=int, default=512)
+    ap.add_argument("--wgrad", action="store_true", help="time the weight-gradient kernel instead")
     args = ap.parse_args()
     dev = "cuda:0"
+    if args.wgrad:
+        return wgrad(args, dev)
     rows = []
     for stage, (C, N) in enumerate(((64, 1024), (128, 512), (256, 256), (512, 128))):
         M = args.clips * N
