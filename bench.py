@@ -174,7 +174,7 @@ def retrieval_probe(device, cpu_check=True):
         _, I_seg = ops.search_l2(db, sq, qs, 20, db_bf16=dbh)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        pred, _ = ops.seq_rerank(db, qs, I_seg, item_row, item_len, top=10)
+        pred, _ = ops.seq_rerank(db, qs, I_seg, item_row, item_len, top=10, max_len=max(lens))
         torch.cuda.synchronize()
         t2 = time.perf_counter()
     hit = (pred[:, 0].reshape(n_ids, len(lens)) == starts[:, None]).float().mean(0)

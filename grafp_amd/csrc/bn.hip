@@ -380,7 +380,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_dx_kernel(const T *__restri
 // `sync` = one counter line per row followed by S 8-byte slots per row, ALL ONES on entry and again on exit.
 // Cross-XCD visibility: slots and counters move with agent-scope relaxed atomics, i.e. sc1 write-through stores and
 // L2-bypassing loads (the per-XCD L2s are not coherent for plain accesses); no L2 writeback/invalidate.  The wait
-// is bounded: a lost rendezvous traps instead of hanging the device.
+// is bounded: a workgroup whose row-mates do not show up recomputes their partial sums itself (no trap, no hang).
 constexpr int BN1_ITEMS_FWD = 8;                       // 16-byte vectors per thread, kept RAW (bf16 stays packed)
 constexpr int BN1_ITEMS_BWD = 4;                       // per operand (x and dz); measured: fwd 8 / bwd 4 beat 4/4 and 8/8
 constexpr int BN1_THREADS = 256;
@@ -394,29 +394,39 @@ constexpr unsigned BN1_EMPTY = 0xffffffffu;            // "not published yet" (a
 // Publishes this workgroup's partial pair into slot s of its row and waits until every slot of the row is filled.
 // No read-modify-write sits on the critical path: a slot is ONE 8-byte write-through store, the wait is wave 0 polling
 // the row's S slots with L2-bypassing loads (the successful poll already holds the data).  Returns with sp[0..S) set.
-__device__ __forceinline__ void bn1_publish_and_wait(float a, float b, unsigned long long *slots_row, int s, int S,
-                                                     float2 *sp, int tid) {
+// The wait is BOUNDED and never traps: after `spin_limit` polls the slots that are still empty are left marked in sp
+// (BN1_EMPTY in .x) and the caller recomputes exactly those partials from global memory itself (same thread mapping,
+// same summation order => the same bits), so a workgroup never depends on row-mates that are not resident -- other
+// kernels holding CUs (RCCL all-reduces overlapping backward, several ranks on one device, CU masks) cost time, not
+// correctness.  Returns the number of slots the caller has to fill in (workgroup-uniform).
+__device__ __forceinline__ int bn1_publish_and_wait(float a, float b, unsigned long long *slots_row, int s, int S,
+                                                    float2 *sp, int *n_missing, int spin_limit, int tid) {
     if (tid == 0) {
         unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
         if (ua == BN1_EMPTY) ua = 0xfffffffeu;          // still a NaN, but not the marker
         __hip_atomic_store(slots_row + s, (unsigned long long)ua | ((unsigned long long)ub << 32), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
+        *n_missing = 0;
     }
     if (tid < 64) {
         int spins = 0;
         for (;;) {
-            bool ok = true;
+            int missing = 0;
             for (int i = tid; i < S; i += 64) {
                 const unsigned long long v = __hip_atomic_load(slots_row + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((unsigned)v == BN1_EMPTY) ok = false;
-                else sp[i] = make_float2(__uint_as_float((unsigned)v), __uint_as_float((unsigned)(v >> 32)));
+                if ((unsigned)v == BN1_EMPTY) ++missing;
+                sp[i] = make_float2(__uint_as_float((unsigned)v), __uint_as_float((unsigned)(v >> 32)));
             }
-            if (__all(ok)) break;
+            if (__all(missing == 0)) break;
+            if (++spins > spin_limit) {
+                if (missing) atomicAdd(n_missing, missing);
+                break;
+            }
             __builtin_amdgcn_s_sleep(8);
-            if (++spins > (1 << 22)) __builtin_trap();
         }
     }
     __syncthreads();
+    return *n_missing;
 }
 
 // After a workgroup has its copy of the partials it checks out of the row (fire and forget: the returned count is
@@ -444,10 +454,11 @@ __global__ __launch_bounds__(BN1_THREADS) void bn_fwd1_kernel(const T *__restric
                                                              float *__restrict__ running_var,
                                                              int *__restrict__ sync, T *__restrict__ out,
                                                              float *__restrict__ save_mean,
-                                                             float *__restrict__ save_invstd) {
+                                                             float *__restrict__ save_invstd, int spin_limit) {
     constexpr int W = BnIO<T>::W, ITEMS = BN1_ITEMS_FWD, CHUNK = BN1_THREADS * ITEMS * W;
     __shared__ float2 scratch[BN1_THREADS / 64];
     __shared__ float2 sp[BN1_MAX_S];
+    __shared__ int n_missing;
     const int c = blockIdx.y, s = blockIdx.x, tid = threadIdx.x;
     const int S = gridDim.x, grp = s / Sg, sl = s - grp * Sg;
     const T *row = x + (size_t)c * M;
@@ -491,7 +502,34 @@ __global__ __launch_bounds__(BN1_THREADS) void bn_fwd1_kernel(const T *__restric
     const float2 r = block_sum2<BN1_THREADS>(a, q, scratch, tid);
     unsigned long long *slots_row = reinterpret_cast<unsigned long long *>(sync + (size_t)gridDim.y * BN1_SYNC_STRIDE) + (size_t)c * S;
     int *counter = sync + (size_t)c * BN1_SYNC_STRIDE;
-    bn1_publish_and_wait(r.x, r.y, slots_row, s, S, sp, tid);
+    if (bn1_publish_and_wait(r.x, r.y, slots_row, s, S, sp, &n_missing, spin_limit, tid) > 0) {
+        // row-mates that did not show up in time: their partial sums straight from the row (identical order and bits)
+        for (int i = 0; i < S; ++i) {
+            if (__float_as_uint(sp[i].x) != BN1_EMPTY) continue;            // LDS value: workgroup-uniform branch
+            const int g2 = i / Sg;
+            const float sh2 = BnIO<T>::ld1(row + (int64_t)g2 * Mg) + pb;
+            const int64_t lo2 = (int64_t)g2 * Mg + (int64_t)(i - g2 * Sg) * CHUNK;
+            const int64_t hi2 = (lo2 + CHUNK < (int64_t)(g2 + 1) * Mg) ? lo2 + CHUNK : (int64_t)(g2 + 1) * Mg;
+            float a2 = 0.0f, q2 = 0.0f;
+#pragma unroll
+            for (int it = 0; it < ITEMS; ++it) {
+                const int64_t m = lo2 + ((int64_t)it * BN1_THREADS + tid) * W;
+                if (m < hi2) {
+                    float v[W];
+                    BnIO<T>::load(row + m, v);
+#pragma unroll
+                    for (int e = 0; e < W; ++e) {
+                        const float d = (v[e] + pb) - sh2;
+                        a2 += d;
+                        q2 = __builtin_fmaf(d, d, q2);
+                    }
+                }
+            }
+            const float2 r2 = block_sum2<BN1_THREADS>(a2, q2, scratch, tid);
+            if (tid == 0) sp[i] = r2;
+        }
+        __syncthreads();
+    }
     int checkout = 0;
     if (tid == 0) checkout = bn1_checkout(counter);
     a = 0.0f, q = 0.0f;
@@ -557,10 +595,11 @@ __global__ __launch_bounds__(BN1_THREADS) void bn_bwd1_kernel(const T *__restric
                                                              float slope,
                                                              int *__restrict__ sync, T *__restrict__ dx,
                                                              float *__restrict__ dgamma, float *__restrict__ dbeta,
-                                                             float *__restrict__ dpre_bias) {
+                                                             float *__restrict__ dpre_bias, int spin_limit) {
     constexpr int W = BnIO<T>::W, ITEMS = BN1_ITEMS_BWD, CHUNK = BN1_THREADS * ITEMS * W;
     __shared__ float2 scratch[BN1_THREADS / 64];
     __shared__ float2 sp[BN1_MAX_S];
+    __shared__ int n_missing;
     const int c = blockIdx.y, s = blockIdx.x, tid = threadIdx.x;
     const int S = gridDim.x, grp = s / Sg, sl = s - grp * Sg;
     const T *row = x + (size_t)c * M, *grow = dz + (size_t)c * M;
@@ -599,7 +638,35 @@ __global__ __launch_bounds__(BN1_THREADS) void bn_bwd1_kernel(const T *__restric
     const float2 r = block_sum2<BN1_THREADS>(sd, sdx, scratch, tid);
     unsigned long long *slots_row = reinterpret_cast<unsigned long long *>(sync + (size_t)gridDim.y * BN1_SYNC_STRIDE) + (size_t)c * S;
     int *counter = sync + (size_t)c * BN1_SYNC_STRIDE;
-    bn1_publish_and_wait(r.x, r.y, slots_row, s, S, sp, tid);
+    if (bn1_publish_and_wait(r.x, r.y, slots_row, s, S, sp, &n_missing, spin_limit, tid) > 0) {
+        for (int i = 0; i < S; ++i) {
+            if (__float_as_uint(sp[i].x) != BN1_EMPTY) continue;
+            const int g2 = i / Sg;
+            const float mean2 = save_mean[c * G + g2], invstd2 = save_invstd[c * G + g2];
+            const int64_t lo2 = (int64_t)g2 * Mg + (int64_t)(i - g2 * Sg) * CHUNK;
+            const int64_t hi2 = (lo2 + CHUNK < (int64_t)(g2 + 1) * Mg) ? lo2 + CHUNK : (int64_t)(g2 + 1) * Mg;
+            float sd2 = 0.0f, sdx2 = 0.0f;
+#pragma unroll
+            for (int it = 0; it < ITEMS; ++it) {
+                const int64_t m = lo2 + ((int64_t)it * BN1_THREADS + tid) * W;
+                if (m < hi2) {
+                    float v[W], d[W];
+                    BnIO<T>::load(row + m, v);
+                    BnIO<T>::load(grow + m, d);
+#pragma unroll
+                    for (int e = 0; e < W; ++e) {
+                        const float xh = ((v[e] + pb) - mean2) * invstd2;
+                        const float dy = d[e] * act_grad(__builtin_fmaf(xh, ga, be), act, slope);
+                        sd2 += dy;
+                        sdx2 = __builtin_fmaf(dy, xh, sdx2);
+                    }
+                }
+            }
+            const float2 r2 = block_sum2<BN1_THREADS>(sd2, sdx2, scratch, tid);
+            if (tid == 0) sp[i] = r2;
+        }
+        __syncthreads();
+    }
     int checkout = 0;
     if (tid == 0) checkout = bn1_checkout(counter);
     sd = 0.0f, sdx = 0.0f;
@@ -673,6 +740,14 @@ static bool bn_vec_ok(const void *a, const void *b, const void *c, const void *d
 
 }  // namespace grafp
 
+static int g_bn_spin_limit = 1 << 12;       // polls (~1 us each) before a workgroup stops waiting for its row-mates
+
+extern "C" int grafp_bn_debug_spin_limit(int polls) {
+    const int old = g_bn_spin_limit;
+    if (polls >= 0) g_bn_spin_limit = polls;
+    return old;
+}
+
 extern "C" size_t grafp_bn_workspace(int C, int64_t M) {
     if (C <= 0 || M <= 0) return 0;
     const size_t two_pass = (size_t)4096 + (size_t)C * 8;          // >= C * G * Sg partial pairs for any G <= 8
@@ -714,7 +789,7 @@ extern "C" int grafp_bn_fwd_1pass(const void *x, int dtype, int C, int64_t M, in
 #define BN_FWD1(T, RES)                                                                                                \
     hipLaunchKernelGGL((bn_fwd1_kernel<T, RES>), grid, dim3(BN1_THREADS), 0, s, (const T *)x, M, Mg, Sg, G, pre_bias,  \
                        gamma, beta, (const T *)residual, act, slope, eps, momentum, running_mean, running_var,         \
-                       (int *)sync, (T *)out, save_mean, save_invstd)
+                       (int *)sync, (T *)out, save_mean, save_invstd, g_bn_spin_limit)
             if (f32) { if (residual) BN_FWD1(float, true); else BN_FWD1(float, false); }
             else { if (residual) BN_FWD1(unsigned short, true); else BN_FWD1(unsigned short, false); }
 #undef BN_FWD1
@@ -779,12 +854,12 @@ extern "C" int grafp_bn_bwd_1pass(const void *x, const void *dz, int dtype, int 
             if (f32)
                 hipLaunchKernelGGL((bn_bwd1_kernel<float>), grid, dim3(BN1_THREADS), 0, s, (const float *)x,
                                    (const float *)dz, M, Mg, Sg, G, pre_bias, gamma, beta, save_mean, save_invstd, act,
-                                   slope, (int *)sync, (float *)dx, dgamma, dbeta, dpre_bias);
+                                   slope, (int *)sync, (float *)dx, dgamma, dbeta, dpre_bias, g_bn_spin_limit);
             else
                 hipLaunchKernelGGL((bn_bwd1_kernel<unsigned short>), grid, dim3(BN1_THREADS), 0, s,
                                    (const unsigned short *)x, (const unsigned short *)dz, M, Mg, Sg, G, pre_bias, gamma,
                                    beta, save_mean, save_invstd, act, slope, (int *)sync, (unsigned short *)dx,
-                                   dgamma, dbeta, dpre_bias);
+                                   dgamma, dbeta, dpre_bias, g_bn_spin_limit);
             GRAFP_CHECK_LAUNCH("bn_bwd1_kernel");
             return GRAFP_OK;
         }

@@ -125,20 +125,25 @@ class GradSync:
 
     def zero(self):
         """Use instead of optimizer.zero_grad(): autograd then ASSIGNS fresh gradients (no per-parameter accumulate
-        kernels); finish() leaves every .grad a view of the flat buffer."""
+        kernels); finish() leaves every .grad a view of the flat buffer.  Also the start of a step for the hook state:
+        a backward pass that raised, or a finish() that was skipped (out of memory, a NaN guard), must not leave
+        half-counted buckets or un-waited collectives behind -- every rank then resets here, in the same place."""
         for p in self.params:
             p.grad = None
+        if self.flat is not None:
+            for h in self._handles:
+                h.wait()
+            self._handles, self._left, self._fired = [], list(self._size), [False] * len(self.bounds)
 
     def _pack(self, b):
-        """Bucket b's gradients -> its slice of the flat buffer: one multi-tensor copy."""
+        """Bucket b's gradients -> its slice of the flat buffer: one multi-tensor copy.  A parameter that took no part
+        in this step (grad None) contributes zero: ONLY its own slice is cleared -- members whose .grad already is
+        their flat view (gradient accumulation without zero()) keep what they hold."""
         members = self._members[b]
+        missing = [p for p in members if p.grad is None]
+        if missing:
+            torch._foreach_zero_([self._view[id(p)] for p in missing])
         have = [p for p in members if p.grad is not None and p.grad.data_ptr() != self._view[id(p)].data_ptr()]
-        if len(have) != len(members):
-            lo, hi = self.bounds[b]
-            missing = [p for p in members if p.grad is None]
-            if missing:
-                self.flat[lo:hi].zero_()           # parameters that took no part in this step contribute zero
-                have = [p for p in members if p.grad is not None]
         if have:
             torch._foreach_copy_([self._view[id(p)] for p in have], [p.grad for p in have])
 
@@ -233,11 +238,16 @@ class ShardedFlatL2Index:
             rows = torch.cat([rows, halo], dim=0)
         as_t = lambda a, dt: torch.as_tensor(a).to(dev, dtype=dt)
         item_len_t = as_t(item_len, torch.int32)
-        if int(item_len_t.max().item()) - 1 > self.halo and self.world > 1:
-            raise ValueError(f"sequences of {int(item_len_t.max().item())} segments need halo >= that minus one")
+        # host-side arrays (what eval.py passes) give the length bound without a device round trip
+        max_len = int(np.max(item_len)) if not torch.is_tensor(item_len) else int(item_len_t.max().item())
+        if max_len - 1 > self.halo and self.world > 1:
+            raise ValueError(f"sequences of {max_len} segments need halo >= that minus one")
+        known = not torch.is_tensor(item_len) and not torch.is_tensor(item_row)
+        if known and (int(np.max(np.asarray(item_row) + np.asarray(item_len))) > len(q_rows) or int(np.min(item_row)) < 0):
+            raise ValueError("seq_rerank: an item reaches outside q_rows")
         ids, sc = ops.seq_rerank(rows, as_t(q_rows, torch.float32), as_t(topk_ids, torch.int64),
                                  as_t(item_row, torch.int64), item_len_t, top=top,
-                                 shard=(self.lo, self.ntotal, self.lo, self.hi))
+                                 shard=(self.lo, self.ntotal, self.lo, self.hi), max_len=max_len if known else None)
         if self.world == 1:
             return ids, sc
         n_items = ids.shape[0]

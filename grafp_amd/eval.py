@@ -95,7 +95,19 @@ def _eval_faiss(emb_dir, emb_dummy_dir, index_type, nogpu, max_train, test_ids, 
         from . import dist as gdist
         max_sl_ = int(max(test_seq_len))
         index = gdist.ShardedFlatL2Index(int(dummy_db.shape[1]), halo=max(max_sl_ - 1, 0))
-        index.add_global(np.concatenate([np.asarray(dummy_db), np.asarray(db)], axis=0))   # dummy rows first (:212-213)
+        # the virtual table [dummy_db; db] (dummy rows first, eval.py:212-213) is never built on the host: every rank
+        # copies out only the rows it owns (+ the halo the sequence rerank reads) from the two memmaps
+        n_all = n_dummy + len(db)
+        lo, hi = gdist.shard_range(n_all, index.rank, index.world)
+
+        def rows(a, b):
+            parts = []
+            if a < min(b, n_dummy):
+                parts.append(np.asarray(dummy_db[a:min(b, n_dummy)]))
+            if max(a, n_dummy) < b:
+                parts.append(np.asarray(db[max(a, n_dummy) - n_dummy:b - n_dummy]))
+            return np.concatenate(parts, axis=0) if parts else np.empty((0, int(dummy_db.shape[1])), dtype=np.float32)
+        index.add_local(rows(lo, hi), lo, n_all, halo_rows=rows(hi, min(n_all, hi + index.halo)))
         index.device = index.local.device
     else:
         index = get_index(index_type, dummy_db, dummy_db.shape, (not nogpu), max_train, n_centroids=n_centroids)
@@ -142,8 +154,9 @@ def _eval_faiss(emb_dir, emb_dummy_dir, index_type, nogpu, max_train, test_ids, 
         if sharded:
             ids, _ = index.rerank(q_dev, I_all, item_row[live], item_len[live], top=10)
         else:
+            assert int((item_row[live] + item_len[live]).max()) <= len(seg_rows) and int(item_row[live].min()) >= 0
             ids, _ = ops.seq_rerank(index.rows(), q_dev, I_all, torch.from_numpy(item_row[live]).to(dev),
-                                    torch.from_numpy(item_len[live]).to(dev), top=10)
+                                    torch.from_numpy(item_len[live]).to(dev), top=10, max_len=int(item_len[live].max()))
         pred[live] = ids.cpu().numpy()
     print(f"Reranked {int(live.sum()):,} (test id, length) items in {time.time() - t0:>4.2f} sec.")
     pred = pred.reshape(n_test, n_len, 10)

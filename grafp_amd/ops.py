@@ -865,13 +865,15 @@ def merge_topk(part_d, part_i):
     return out_d, out_i
 
 
-def seq_rerank(index_rows, q_rows, topk_ids, item_row, item_len, top=10, shard=None):
+def seq_rerank(index_rows, q_rows, topk_ids, item_row, item_len, top=10, shard=None, max_len=None):
     """Sequence-level rerank of batched segment-search results (eval.py:272-290, one workgroup per item).
     index_rows (n,128) f32 resident database, q_rows (n_q,128) f32, topk_ids (n_q,k) int64, item_row (n_items) int64
     first query row of each item, item_len (n_items) int32 segments per item.
     Returns (ids int64 (n_items, top) best first, -1 padded; scores f32 (n_items, top), -inf padded).
     shard = (row_base, n_total, id_lo, id_hi): index_rows holds global rows [row_base, row_base + len) of an n_total-row
-    index and only candidates starting in [id_lo, id_hi) are scored (dist.ShardedFlatL2Index.rerank merges shards)."""
+    index and only candidates starting in [id_lo, id_hi) are scored (dist.ShardedFlatL2Index.rerank merges shards).
+    max_len: the longest item (segments), an upper bound is fine; the caller then also vouches that every item lies
+    inside q_rows (the kernel clamps nothing)."""
     _require_gpu(index_rows, q_rows, topk_ids, item_row, item_len)
     index_rows, q_rows = _f32c(index_rows), _f32c(q_rows)
     topk_ids = topk_ids.to(torch.int64).contiguous()
@@ -882,9 +884,13 @@ def seq_rerank(index_rows, q_rows, topk_ids, item_row, item_len, top=10, shard=N
     out_s = torch.empty((n_items, top), dtype=torch.float32, device=index_rows.device)
     if n_items == 0:
         return out_i, out_s
-    max_len = int(item_len.max().item())
-    if int((item_row + item_len.to(torch.int64)).max().item()) > q_rows.shape[0] or int(item_row.min().item()) < 0:
-        raise ValueError("seq_rerank: an item reaches outside q_rows")
+    if max_len is None:
+        # convenience path with three host synchronisations (length bound + range check); callers that know the longest
+        # sequence pass it (eval.py, dist.py, bench.py do) and stay asynchronous / graph-capturable like the other ops
+        max_len = int(item_len.max().item())
+        if int((item_row + item_len.to(torch.int64)).max().item()) > q_rows.shape[0] or int(item_row.min().item()) < 0:
+            raise ValueError("seq_rerank: an item reaches outside q_rows")
+    max_len = int(max_len)
     with _timed("seq_rerank", (n_items, max_len, topk_ids.shape[1])):
         if shard is None:
             check(lib.grafp_seq_rerank_f32(_p(index_rows), index_rows.shape[0], _p(q_rows), q_rows.shape[0],

@@ -69,7 +69,17 @@ class Trainer:
         if self.world > 1:
             raise RuntimeError("step_graph: single-process only (use step() under data parallelism)")
         if self._graph is None:
+            if getattr(self.augment, "seed", None) is not None:
+                raise RuntimeError("step_graph: a private augmentation generator (aug_seed) is eager-only -- its draws "
+                                   "would be frozen into the graph; use the default device generator")
             sx_i, sx_j = x_i.clone(), x_j.clone()
+            # the warm-up steps (allocator / library warm-up, as torch.cuda.graphs asks) and the capture itself must
+            # not count as training: weights, BatchNorm statistics and optimizer state are put back afterwards, so the
+            # first call is ONE step like every later one
+            with torch.no_grad():
+                keep = [t.detach().clone() for t in list(self.model.parameters()) + list(self.model.buffers())]
+                opt_keep = {p: {k: v.detach().clone() for k, v in st.items() if torch.is_tensor(v)}
+                            for p, st in self.opt.state.items()}
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -79,6 +89,13 @@ class Trainer:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 loss = self.step(sx_i, sx_j)
+            with torch.no_grad():
+                for t, v in zip(list(self.model.parameters()) + list(self.model.buffers()), keep):
+                    t.copy_(v)
+                for p, st in self.opt.state.items():     # Adam moments and step counters: as before the warm-up
+                    for k, v in st.items():
+                        if torch.is_tensor(v):
+                            v.copy_(opt_keep[p][k]) if p in opt_keep else v.zero_()
             self._graph = (graph, sx_i, sx_j, loss)
             graph.replay()                     # capture only records: this runs the step on the batch
             return loss.clone()

@@ -183,6 +183,12 @@ int grafp_bn_bwd_1pass(const void *x, const void *dz, int dtype, int C, int64_t 
                        float *dpre_bias /* (C) or NULL */, void *ws, size_t ws_bytes, int32_t *sync,
                        grafp_stream_t stream);
 
+/* Test hooks of the single-pass BatchNorm (no reference counterpart): the number of polls after which a workgroup stops
+ * waiting for its row-mates and recomputes their partial sums itself (returns the previous value; < 0 only reads it;
+ * 0 = never wait), and a kernel that merely occupies `blocks` x `threads` CU slots for `clocks` shader cycles. */
+int grafp_bn_debug_spin_limit(int polls);
+int grafp_debug_occupy(int blocks, int threads, int64_t clocks, grafp_stream_t stream);
+
 /* ---- K9 forward / data gradient: the 1x1 convolution itself as a streaming bf16 GEMM, BatchNorm folded in ----
  * y[r][m] = sum_k w[r][k] * f(x[k][m]) for every Conv2d(1x1) of the encoder (encoder/gcn_lib/torch_vertex.py:152-162,
  * torch_nn.py:56-60, encoder/graph_encoder.py:21-24,52-55) and, with w transposed by the caller, its data gradient

@@ -80,6 +80,52 @@ def _worker(rank, world, port, out):
             ok &= bool(torch.allclose(p.grad, want, rtol=1e-6, atol=1e-7))
             ok &= p.grad.data_ptr() >= sync.flat.data_ptr() and p.grad.data_ptr() < sync.flat.data_ptr() + 4 * sync.flat.numel()
         res[f"gradsync_{it}"] = ok
+    # ---- a step that dies mid-backward (every rank: same place) must not poison the next one: zero() resets the hook
+    #      counters and waits for the collectives that already fired
+    class Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t): return t.clone()
+        @staticmethod
+        def backward(ctx, g): raise RuntimeError("boom")
+    sync.zero()
+    x = torch.from_numpy(hash_normalish(f"dist:xb{rank}", (5, 8)))
+    try:
+        net[3](Boom.apply(net[2](net[1](net[0](x))))).square().sum().backward()    # the last layer's bucket fires first
+        raised = False
+    except RuntimeError:
+        raised = True
+    sync.zero()
+    net(x).square().sum().backward()
+    shadow.zero_grad(); shadow(x).square().sum().backward()
+    local = [p.grad.clone() for p in shadow.parameters()]
+    sync.finish()
+    ok = raised
+    for p, g in zip(net.parameters(), local):
+        want = g.clone(); dist.all_reduce(want)
+        ok &= bool(torch.allclose(p.grad, want, rtol=1e-6, atol=1e-7))
+    res["gradsync_after_failed_backward"] = ok
+    # ---- a parameter that takes no part in a step contributes zero, and ONLY its slice is cleared: the other members
+    #      of its bucket keep what the flat buffer already holds for them (accumulation without zero())
+    sync2 = gdist.GradSync(list(net.parameters()), n_buckets=1, overlap=False)
+    for p in net.parameters():
+        p.grad = None
+    net[0](x).square().sum().backward()                                             # only the first layer gets gradients
+    g0 = [net[0].weight.grad.clone(), net[0].bias.grad.clone()]
+    sync2.finish()
+    ok = True
+    for p, g in zip(net[0].parameters(), g0):
+        want = g.clone(); dist.all_reduce(want)
+        ok &= bool(torch.allclose(p.grad, want, rtol=1e-6, atol=1e-7))
+    ok &= all(float(p.grad.abs().max()) == 0.0 for p in list(net[2].parameters()) + list(net[3].parameters()))
+    net[0](x).square().sum().backward()          # accumulates INTO the flat views; the untouched layers stay as they are
+    held = [p.grad.clone() for p in net[0].parameters()]
+    for p in list(net[2].parameters()) + list(net[3].parameters()):
+        p.grad = None
+    sync2.finish()
+    for p, h in zip(net[0].parameters(), held):
+        want = h.clone(); dist.all_reduce(want)
+        ok &= bool(torch.allclose(p.grad, want, rtol=1e-6, atol=1e-7))
+    res["gradsync_partial_step"] = ok
     # ---- sharded exact search: local top-k + all-gather + merge == unsharded
     db = hash_normalish("dist:db", (1001, 128)); q = db[5:30] + 0.05 * hash_normalish("dist:q", (25, 128))
 
@@ -115,7 +161,8 @@ def test_world_size_2_gloo():
         res = dict(out)
     assert set(res) == {0, 1}
     for rank, r in res.items():
-        assert r["loss_ok"] and r["grad_ok"] and r["gradsync_0"] and r["gradsync_1"] and r["search_ok"] and r["search_local_ok"], (rank, r)
+        assert r["loss_ok"] and r["grad_ok"] and r["gradsync_0"] and r["gradsync_1"] and r["search_ok"] and r["search_local_ok"] and \
+            r["gradsync_after_failed_backward"] and r["gradsync_partial_step"], (rank, r)
     assert res[0]["shard_rows"] == (0, 501) and res[1]["shard_rows"] == (501, 1001)
 
 

@@ -1,6 +1,8 @@
 """GPU parity tests: every HIP kernel, called through the C ABI (grafp_amd.ops -> libgrafp_hip.so),
 against the oracle on the same seeded inputs.  Bit-exact for index-valued results; stated tolerances for
 floating point.  Run with `pytest -m gpu` on an MI355X."""
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -832,3 +834,44 @@ def test_augmentation_ragged_banks_equal_padded(dev):
     c = ops.mix_snr(xd, fd, T(lens), T(idx), T(off), T(snr), T(starts)); d = ops.mix_snr(xd, pd, T(lens), T(idx), T(off), T(snr))
     assert torch.equal(c, d)
     np.testing.assert_allclose(c.cpu().numpy(), on.mix_snr(x, flat, lens, idx, off, snr, starts), rtol=0, atol=2e-6 * np.abs(x).max())
+
+
+def test_bn_single_pass_never_depends_on_absent_row_mates(dev):
+    """The rendezvous of bn_fwd1 / bn_bwd1 is bounded and falls back to recomputing the missing partial sums (it used
+    to trap): (1) with a spin limit of 0 every workgroup fills in whatever is not yet published -- results must be the
+    same BITS as the normal run; (2) the same while a second stream holds 15/16 of the chip's wave slots for tens of
+    milliseconds (stand-in for collective kernels occupying CUs during backward), with a short spin limit."""
+    from grafp_amd import ops
+    from grafp_amd._lib import check, lib
+    C, M = 64, 2 * 256 * 1024
+    gen = torch.Generator(device=dev).manual_seed(5)
+    x = (torch.randn(C, M, device=dev, generator=gen) * 2 + 1).to(torch.bfloat16)
+    dz = torch.randn(C, M, device=dev, generator=gen).to(torch.bfloat16)
+    gamma = torch.rand(C, device=dev, generator=gen) + 0.5
+    beta = torch.randn(C, device=dev, generator=gen)
+
+    def run():
+        xg = x.clone().requires_grad_(True)
+        g = gamma.clone().requires_grad_(True)
+        rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        z = ops.bn_act(xg, g, beta, rm, rv, True, act=ops.ACT_RELU, groups=2)
+        z.backward(dz)
+        torch.cuda.synchronize()
+        return z.detach(), xg.grad, g.grad, rm
+
+    want = run()
+    old = lib.grafp_bn_debug_spin_limit(0)
+    try:
+        got = run()
+        for a, b in zip(got, want):
+            assert torch.equal(a, b)
+        lib.grafp_bn_debug_spin_limit(16)
+        side = torch.cuda.Stream()
+        for blocks in (256, 480):
+            check(lib.grafp_debug_occupy(blocks, 1024, 60_000_000, ctypes.c_void_p(side.cuda_stream)), "occupy")
+            got = run()
+            side.synchronize()
+            for a, b in zip(got, want):
+                assert torch.equal(a, b)
+    finally:
+        lib.grafp_bn_debug_spin_limit(old)
