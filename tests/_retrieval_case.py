@@ -5,28 +5,36 @@ import numpy as np
 import torch
 
 
-def synth_track(seconds, seed, fs=16000):
-    """A track with slowly changing spectral content: eight amplitude-modulated partials with random walks in frequency
-    over a noise floor -- enough structure that 1 s segments are distinguishable but neighbouring segments are similar."""
-    rng = np.random.RandomState(seed)
+def synth_tracks(n, seconds, seed, dev, fs=16000):
+    """n tracks (n, T) f32 on `dev` with slowly changing spectral content: five amplitude-modulated partials with random
+    walks in frequency over a noise floor -- enough structure that 1 s segments are distinguishable while neighbouring
+    segments stay similar.  The random knots come from a CPU generator (reproducible), the synthesis runs on the device."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(seed)
     T = int(seconds * fs)
-    x = (0.02 * rng.standard_normal(T)).astype(np.float32)
-    grid = np.arange(T, dtype=np.float32)
+    x = 0.02 * torch.randn(n, T, generator=g).to(dev)
     for _ in range(5):
-        f0 = 100.0 + 3500.0 * rng.rand()
-        knots = np.linspace(0, T - 1, T // 800 + 2)
-        f = np.interp(grid, knots, f0 + np.cumsum(rng.standard_normal(knots.size)) * 6.0)
-        eknots = np.linspace(0, T - 1, T // 4000 + 2)
-        env = np.interp(grid, eknots, rng.rand(eknots.size)).astype(np.float32)
-        phase = (2 * np.pi / fs) * np.cumsum(f) + 6.28 * rng.rand()          # float64: the phase must not drift
-        x += 0.12 * env * np.sin(phase).astype(np.float32)
-    return torch.from_numpy(x)
+        f0 = 100.0 + 3500.0 * torch.rand(n, 1, generator=g)
+        walk = f0 + torch.cumsum(torch.randn(n, T // 800 + 2, generator=g), 1) * 6.0
+        env = torch.rand(n, T // 4000 + 2, generator=g)
+        ph0 = 6.28 * torch.rand(n, 1, generator=g)
+        f = F.interpolate(walk[:, None].to(dev, torch.float64), size=T, mode="linear", align_corners=True)[:, 0]
+        e = F.interpolate(env[:, None].to(dev), size=T, mode="linear", align_corners=True)[:, 0]
+        phase = (2 * np.pi / fs) * torch.cumsum(f, 1) + ph0.to(dev, torch.float64)     # float64: the phase must not drift
+        x += 0.12 * e * torch.sin(phase).float()
+    return x
+
+
+def synth_track(seconds, seed, fs=16000):
+    return synth_tracks(1, seconds, seed, torch.device("cpu"), fs)[0]
 
 
 def add_noise(x, snr_db, seed):
-    g = torch.Generator().manual_seed(seed)
-    n = torch.randn(x.shape, generator=g)
-    return x + n * (x.pow(2).mean().sqrt() / n.pow(2).mean().sqrt()) * 10.0 ** (-snr_db / 20.0)
+    """x (..., T) + white noise at `snr_db` per row; the noise is drawn on x's device from a seeded generator."""
+    g = torch.Generator(device=x.device).manual_seed(seed)
+    n = torch.randn(x.shape, generator=g, device=x.device)
+    rms = lambda a: a.pow(2).mean(dim=-1, keepdim=True).sqrt()
+    return x + n * (rms(x) / rms(n)) * 10.0 ** (-snr_db / 20.0)
 
 
 def segments(tracks, cfg, dev):
@@ -49,23 +57,22 @@ def build_case(dev, n_tracks=24, seconds=20, train_steps=40, snrs=(0, 10), n_tes
         cfg["overlap"] = overlap          # hop between database segments (the reference's config: 0.9 = 0.1 s)
     torch.manual_seed(seed)
     model = build_model(cfg, device=dev)
-    db_tracks = [synth_track(seconds, 1000 + i) for i in range(n_tracks)]
-    dummy_tracks = [synth_track(seconds, 5000 + i) for i in range(n_tracks)]
+    db_tracks = synth_tracks(n_tracks, seconds, 1000 + seed, dev)
+    dummy_tracks = synth_tracks(n_tracks, seconds, 5000 + seed, dev)
     # a short training run on 1 s crops of the corpus (view j = the noisy crop): the net stops being a random projection
     tr = Trainer(cfg, model, dev, amp_dtype=torch.bfloat16, lr=2e-4)
     g = torch.Generator().manual_seed(seed + 1)
-    pool = torch.stack(db_tracks + dummy_tracks)
+    pool = torch.cat([db_tracks, dummy_tracks])
     for it in range(train_steps):
         ti = torch.randint(0, pool.shape[0], (64,), generator=g)
         off = torch.randint(0, pool.shape[1] - 16000, (64,), generator=g)
         x_i = torch.stack([pool[a, b:b + 16000] for a, b in zip(ti.tolist(), off.tolist())])
-        x_j = torch.stack([add_noise(c, 5.0, 77 * it + k) for k, c in enumerate(x_i)])
-        tr.step(x_i.to(dev), x_j.to(dev))
+        tr.step(x_i, add_noise(x_i, 5.0, 77 * it))
     model.eval()
     case = {"model": model, "cfg": cfg, "snrs": snrs, "lens": [1, 3, 5, 9],
             "db": segments(db_tracks, cfg, dev), "dummy": segments(dummy_tracks, cfg, dev)}
     for snr in snrs:
-        case[f"query{snr}"] = segments([add_noise(x, float(snr), 900 + i) for i, x in enumerate(db_tracks)], cfg, dev)
+        case[f"query{snr}"] = segments(add_noise(db_tracks, float(snr), 900), cfg, dev)
     n_db = case["db"].shape[0]
     rng = np.random.RandomState(seed)
     case["test_ids"] = np.sort(rng.permutation(n_db - max(case["lens"]))[:n_test])

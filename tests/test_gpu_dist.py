@@ -102,6 +102,45 @@ def test_two_ranks_match_one_process(tmp_path):
     assert (wid[:, 0].cpu().reshape(4, 3) == starts[:, None]).all()          # planted runs found, across the boundary
 
 
+def test_two_ranks_at_128_pairs_per_rank(tmp_path):
+    """The per-GPU shape of BASELINE config 3 (128 pairs per rank) on two ranks: global-negative loss shares, summed
+    gradients and their norm against ONE process pushing the two shards through the model one after the other."""
+    from grafp_amd.simclr.ntxent import ntxent_loss
+    from grafp_amd.train import Trainer, build_model, synthetic_batch
+    from grafp_amd.util import load_config
+    B = 256
+    out = str(tmp_path / "w2big")
+    _launch(2, out, B)
+    got = [torch.load(f"{out}.{r}.pt", weights_only=False) for r in range(2)]
+    device = torch.device("cuda:0")
+    cfg = load_config()
+    cfg["bsz_train"] = B
+    torch.manual_seed(1234)
+    model = build_model(cfg, device=device)
+    trainer = Trainer(cfg, model, device, amp_dtype=None)
+    x_i, x_j = synthetic_batch(B, 7, device)
+    model.train()
+    zs_i, zs_j = [], []
+    for lo in (0, B // 2):
+        with torch.no_grad():
+            X_i, X_j = trainer.augment(x_i[lo:lo + B // 2], x_j[lo:lo + B // 2])
+        _, _, z_i, z_j = model(X_i, X_j)
+        zs_i.append(z_i); zs_j.append(z_j)
+    loss = ntxent_loss(torch.cat(zs_i), torch.cat(zs_j), cfg)
+    loss.backward()
+    for r in range(2):
+        assert torch.allclose(got[r]["z_i"], zs_i[r].detach().cpu(), rtol=0, atol=1e-6)
+    loss_v = float(loss.detach())
+    assert abs(got[0]["loss_share"] + got[1]["loss_share"] - loss_v) <= 1e-5 * max(1.0, abs(loss_v))
+    params = dict(model.named_parameters())
+    for name, g in got[0]["grads"].items():
+        want = params[name].grad.detach().float().cpu()
+        assert (g - want).norm() / want.norm().clamp_min(1e-12) < 2e-4, name
+        assert torch.equal(g, got[1]["grads"][name])
+    want_norm = torch.sqrt(sum((p.grad.float() ** 2).sum() for p in model.parameters() if p.grad is not None)).item()
+    assert abs(got[0]["grad_norm"] - want_norm) <= 2e-4 * want_norm
+
+
 def test_bench_two_ranks_one_gpu(tmp_path):
     """bench.py's N > 1 path end to end (barriers, MAX over ranks, rank-0 JSON line, sharded retrieval leg) with both
     ranks on cuda:0."""
@@ -126,4 +165,4 @@ def test_bench_two_ranks_one_gpu(tmp_path):
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
     assert line["config"]["global_batch"] == 32 and line["roofline"]["frac"] > 0
     rs = line["retrieval_sharded"]                 # config-5 shape: one 1.25 M-row shard per rank, planted queries
-    assert rs["n_gpus"] == 2 and rs["nq"] == 4096 and rs["top1_hit_rate"] == 1.0 and rs["qps"] > 0
+    assert rs["n_gpus"] == 2 and rs["nq"] == 4096 and 0.5 < rs["top1_hit_rate"] < 1.0 and rs["qps"] > 0   # informative sigma

@@ -144,7 +144,8 @@ def test_max_relative_golden(dev):
 
 # =============================================================== NT-Xent
 @pytest.mark.parametrize("B,D,tau", [(2, 128, 0.05), (8, 128, 0.05), (32, 128, 0.05), (256, 128, 0.05),
-                                      (100, 128, 0.05), (33, 32, 0.5), (70, 64, 0.1)])
+                                      (100, 128, 0.05), (33, 32, 0.5), (70, 64, 0.1),
+                                      (1024, 128, 0.05)])           # BASELINE config 3: 2048 rows of negatives
 def test_ntxent_vs_oracle(dev, B, D, tau):
     """Tolerance: loss 2e-5 relative, gradients 1e-4 relative + 1e-5 of the largest gradient entry (f32
     exp/log, different summation order)."""
@@ -174,12 +175,13 @@ def test_ntxent_reference_goldens(dev):
         np.testing.assert_allclose(b.grad.cpu().numpy(), g[f"dzj_{B}"], rtol=1e-4, atol=1e-7)
 
 
-def test_ntxent_local_rows_global_columns(dev):
+@pytest.mark.parametrize("B,R", [(96, 3), (1024, 8)])      # (1024, 8): BASELINE config 3, 128 local rows x 2048 columns
+def test_ntxent_local_rows_global_columns(dev, B, R):
     """The data-parallel form: shares of the loss add up to the global loss; local gradients are the
     corresponding slices of the global gradient (no backward collective needed)."""
     from grafp_amd import ops
-    B, D, R = 96, 128, 3
-    zi = hash_normalish("gpu:nt.dp.zi", (B, D)); zj = hash_normalish("gpu:nt.dp.zj", (B, D))
+    D = 128
+    zi = hash_normalish(f"gpu:nt.dp.zi{B}", (B, D)); zj = zi + 1.5 * hash_normalish(f"gpu:nt.dp.zj{B}", (B, D))
     zi /= np.linalg.norm(zi, axis=1, keepdims=True); zj /= np.linalg.norm(zj, axis=1, keepdims=True)
     zi_all, zj_all = t(zi).to(dev), t(zj).to(dev)
     a = zi_all.clone().requires_grad_(True); b = zj_all.clone().requires_grad_(True)

@@ -376,3 +376,38 @@ def test_trainer_with_device_augmentation_eager_and_graph(dev):
     losses = [float(tr.step_graph(x_i, x_j)) for _ in range(3)]
     assert np.isfinite(l0) and all(np.isfinite(v) for v in losses)
     assert len(set(losses)) > 1                      # new noise draws (and new weights) on every replay
+
+
+def test_full_step_at_config2_size(dev):
+    """BASELINE config 2 at its real size (256 pairs = 512 clip-views, bf16): one full step through Trainer.step --
+    finite loss and gradients, every one of the 12 k-NN graphs bit-exact against the C oracle on sampled clips (the
+    decision is re-made from the features the HIP path itself fed the graph kernel), weights move."""
+    from grafp_amd import ops
+    from grafp_amd.train import Trainer, build_model, synthetic_batch
+    from grafp_amd.util import load_config
+    from oracle import native
+    cfg = load_config(); cfg["bsz_train"] = 256
+    torch.manual_seed(3)
+    model = build_model(cfg, device=dev)
+    tr = Trainer(cfg, model, dev, amp_dtype=torch.bfloat16)
+    x_i, x_j = synthetic_batch(256, seed=9, device=dev)
+    seen, orig = [], ops.knn_graph
+    clips = [0, 17, 255, 256, 300, 511]
+
+    def rec(x, k, normalize=True, layout="bcn", index_dtype=torch.int64, prefilter=None):
+        idx = orig(x, k, normalize, layout, index_dtype, prefilter)
+        xs = x.detach()[:, clips].float().permute(1, 0, 2) if layout == "cbn" else x.detach()[clips].float()
+        seen.append((xs.cpu().numpy(), idx[clips].cpu().numpy().astype(np.int64)))
+        return idx
+    ops.knn_graph = rec
+    try:
+        w0 = model.encoder.backbone[0][1].fc1[0].weight.detach().clone()
+        loss = tr.step(x_i, x_j)
+    finally:
+        ops.knn_graph = orig
+    assert np.isfinite(float(loss)) and 0.0 < float(loss) < 20.0
+    assert len(seen) == 12
+    for feats, idx in seen:
+        np.testing.assert_array_equal(native.knn_graph(feats, 3), idx)
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+    assert not torch.equal(model.encoder.backbone[0][1].fc1[0].weight.detach(), w0)
