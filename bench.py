@@ -456,6 +456,33 @@ def main():
                         model.embed(segs)
                     torch.cuda.synchronize()
                 fp[f"segments_per_s_{tag}"] = round(3 * segs.shape[0] / (time.perf_counter() - t0), 1)
+            # ... and END TO END as create_dummy_db drives it: 64 thirty-second tracks resident in HBM ->
+            # log-mel -> overlapping 1 s segments -> packed model calls -> HBM -> (pinned) pages of the output memmap
+            import shutil
+            import tempfile
+            from grafp_amd import fpdb
+            from grafp_amd.modules.transformations import GPUTransformNeuralfp
+            aug_eval = GPUTransformNeuralfp(cfg, None, None, train=False)
+            gen = torch.Generator(device=device).manual_seed(11)
+            tracks = 0.1 * torch.randn(64, 1, 30 * cfg["fs"], generator=gen, device=device)
+            out_dir = tempfile.mkdtemp(prefix="grafp_fp_")
+            try:
+                for tag, amp_dt in (("f32", None), ("bf16", torch.bfloat16)):
+                    ctx = torch.autocast("cuda", dtype=amp_dt) if amp_dt is not None else contextlib.nullcontext()
+                    with ctx, contextlib.redirect_stdout(sys.stderr):
+                        fpdb.create_dummy_db(list(tracks[:4]), aug_eval, model, out_dir, fname="warm", verbose=False,
+                                             max_segments=1024)
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        fpdb.create_dummy_db(list(tracks), aug_eval, model, out_dir, fname=f"db_{tag}", verbose=False,
+                                             max_segments=1024)
+                        dt = time.perf_counter() - t0
+                    n_seg = os.path.getsize(os.path.join(out_dir, f"db_{tag}.mm")) // 512
+                    fp[f"end_to_end_segments_per_s_{tag}"] = round(n_seg / dt, 1)
+                fp["end_to_end"] = (f"{n_seg} segments of 64 x 30 s tracks: waveform in HBM -> log-mel -> segments -> "
+                                    "model (eval, 1024-segment calls) -> direct DMA into the output memmap, file closed")
+            finally:
+                shutil.rmtree(out_dir, ignore_errors=True)
             line["fingerprinting"] = fp
             model.train()
             line["retrieval"] = retrieval_probe(device, cpu_check=not args.no_cpu_baseline)

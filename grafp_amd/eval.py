@@ -29,11 +29,71 @@ def get_index(index_type, train_data, train_data_shape, use_gpu=True, max_nitem_
     return index
 
 
+class PartedRows:
+    """Read-only view of a database written as `<fname>.part<r>.mm` slices (fpdb.create_dummy_db with world > 1): the
+    rows are the parts' rows in rank order.  Supports what eval.py does with a memmap -- len, shape, a[lo:hi],
+    a[int_array], np.asarray(a) -- and `part_rows(r)` for a rank that only wants its own slice."""
+
+    def __init__(self, parts):
+        self.parts = parts
+        self.offsets = np.concatenate([[0], np.cumsum([len(p) for p in parts])]).astype(np.int64)
+        self.shape = (int(self.offsets[-1]), int(parts[0].shape[1]) if parts else 0)
+        self.dtype = np.dtype("float32")
+
+    def __len__(self):
+        return self.shape[0]
+
+    def part_rows(self, r):
+        return self.parts[r]
+
+    def _rows(self, idx):
+        idx = np.asarray(idx, dtype=np.int64)
+        out = np.empty((idx.size, self.shape[1]), dtype=np.float32)
+        which = np.searchsorted(self.offsets, idx, side="right") - 1
+        for r in np.unique(which):
+            sel = which == r
+            out[sel] = self.parts[r][idx[sel] - self.offsets[r]]
+        return out
+
+    def __getitem__(self, key):
+        if isinstance(key, slice):
+            lo, hi, step = key.indices(len(self))
+            if step != 1:
+                return self._rows(np.arange(lo, hi, step))
+            chunks = []
+            for r, p in enumerate(self.parts):
+                a, b = max(lo, self.offsets[r]), min(hi, self.offsets[r + 1])
+                if a < b:
+                    chunks.append(np.asarray(p[a - self.offsets[r]:b - self.offsets[r]]))
+            return np.concatenate(chunks, axis=0) if chunks else np.empty((0, self.shape[1]), np.float32)
+        if isinstance(key, (int, np.integer)):
+            return self._rows([int(key) % len(self)])[0]
+        return self._rows(key)
+
+    def __array__(self, dtype=None, copy=None):
+        a = self[0:len(self)]
+        return a if dtype is None else a.astype(dtype, copy=False)
+
+
 def load_memmap_data(source_dir, fname, append_extra_length=None, shape_only=False, display=True):
-    """`<fname>_shape.npy` + `<fname>.mm` (float32 memmap) -> (data, shape); NaNs are zeroed in place."""
+    """`<fname>_shape.npy` + `<fname>.mm` (float32 memmap) -> (data, shape); NaNs are zeroed in place.  A database
+    written in the shard-aware layout (`<fname>_parts.npy` + `<fname>.part<r>.mm`) comes back as PartedRows."""
     data_shape = np.load(os.path.join(source_dir, fname + "_shape.npy"))
     if shape_only:
         return data_shape
+    parts_file = os.path.join(source_dir, fname + "_parts.npy")
+    if os.path.exists(parts_file) and not os.path.exists(os.path.join(source_dir, fname + ".mm")):
+        rows = np.load(parts_file)
+        parts = []
+        for r, n in enumerate(rows):
+            pm = np.memmap(os.path.join(source_dir, f"{fname}.part{r}.mm"), dtype="float32", mode="r+",
+                           shape=(int(n), int(data_shape[1]))) if n else np.empty((0, int(data_shape[1])), np.float32)
+            if n:
+                pm[np.isnan(pm)] = 0.0
+            parts.append(pm)
+        if display:
+            print(f"Load {int(rows.sum()):,} items from {len(rows)} part files of {fname}.")
+        return PartedRows(parts), data_shape
     if append_extra_length:
         data_shape[0] += append_extra_length
     path = os.path.join(source_dir, fname + ".mm")

@@ -411,3 +411,45 @@ def test_full_step_at_config2_size(dev):
         np.testing.assert_array_equal(native.knn_graph(feats, 3), idx)
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
     assert not torch.equal(model.encoder.backbone[0][1].fc1[0].weight.detach(), w0)
+
+
+@pytest.mark.parametrize("staging", ["0", "1"])
+def test_db_writers_device_stream_and_part_files(dev, tmp_path, monkeypatch, staging):
+    """fingerprints go from HBM straight into the (pinned) pages of the output memmap, or -- staging = 1 --
+    through two pinned staging slots (small windows and slots here, so that window changes, both slots and the file
+    growth are exercised); the shard-aware layout (one part file per rank, contiguous track ranges) reads back as the
+    same rows through load_memmap_data and as per-rank slices."""
+    monkeypatch.setenv("GRAFP_FPDB_STAGING", staging)
+    from grafp_amd import fpdb
+    from grafp_amd.eval import PartedRows, load_memmap_data
+    from grafp_amd.modules.transformations import GPUTransformNeuralfp
+    cfg, model = _filled_model(dev)
+    model.eval()
+    aug = GPUTransformNeuralfp(cfg, None, None, train=False)
+    tracks = [torch.from_numpy(0.1 * hash_normalish(f"dbp:{i}", (1, 16000 * 3 + 700 * i))) for i in range(5)]
+    old_slot, old_grow = fpdb._MemmapAppender.__init__.__defaults__, fpdb._MemmapAppender.GROW_ROWS
+    fpdb._MemmapAppender.__init__.__defaults__ = (16,)          # 16-row staging slots: several per track
+    fpdb._MemmapAppender.GROW_ROWS = 64                          # the sparse file grows a few times
+    try:
+        fpdb.create_dummy_db(tracks, augment=aug, model=model, output_root_dir=str(tmp_path), fname="whole", verbose=False)
+        for r in range(2):
+            fpdb.create_dummy_db(tracks, augment=aug, model=model, output_root_dir=str(tmp_path), fname="parted",
+                                 verbose=False, rank=r, world=2)
+        fpdb.write_parts_manifest(str(tmp_path), "parted", 2)
+    finally:
+        fpdb._MemmapAppender.__init__.__defaults__ = old_slot
+        fpdb._MemmapAppender.GROW_ROWS = old_grow
+    whole, shape = load_memmap_data(str(tmp_path), "whole", display=False)
+    parted, pshape = load_memmap_data(str(tmp_path), "parted", display=False)
+    with torch.no_grad():
+        want = torch.cat([model.embed(aug(t.to(dev), None)[0])[1] for t in tracks]).cpu().numpy()
+    assert tuple(shape) == tuple(pshape) == want.shape and isinstance(parted, PartedRows)
+    assert os.path.getsize(tmp_path / "whole.mm") == want.size * 4            # truncated to the rows written
+    np.testing.assert_array_equal(np.asarray(whole), want)
+    np.testing.assert_array_equal(np.asarray(parted), want)
+    np.testing.assert_array_equal(parted[5:want.shape[0] - 3], want[5:-3])
+    pick = np.array([0, want.shape[0] - 1, 7, 7, 30])
+    np.testing.assert_array_equal(parted[pick], want[pick])
+    lo, hi = fpdb.track_range(len(tracks), 0, 2)
+    n0 = sum((1 + t.shape[1] // 512 - 32) // 3 + 1 for t in tracks[lo:hi])
+    assert len(parted.part_rows(0)) == n0 and len(parted.part_rows(1)) == want.shape[0] - n0
