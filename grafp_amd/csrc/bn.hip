@@ -584,7 +584,7 @@ __global__ __launch_bounds__(BN1_THREADS) void bn_fwd1_kernel(const T *__restric
     if (tid == 0) bn1_rearm(checkout, S, counter, slots_row);
 }
 
-template <typename T>
+template <typename T, int ITEMS>
 __global__ __launch_bounds__(BN1_THREADS) void bn_bwd1_kernel(const T *__restrict__ x, const T *__restrict__ dz,
                                                              int64_t M, int64_t Mg, int Sg, int G,
                                                              const float *__restrict__ pre_bias,
@@ -596,7 +596,7 @@ __global__ __launch_bounds__(BN1_THREADS) void bn_bwd1_kernel(const T *__restric
                                                              int *__restrict__ sync, T *__restrict__ dx,
                                                              float *__restrict__ dgamma, float *__restrict__ dbeta,
                                                              float *__restrict__ dpre_bias, int spin_limit) {
-    constexpr int W = BnIO<T>::W, ITEMS = BN1_ITEMS_BWD, CHUNK = BN1_THREADS * ITEMS * W;
+    constexpr int W = BnIO<T>::W, CHUNK = BN1_THREADS * ITEMS * W;
     __shared__ float2 scratch[BN1_THREADS / 64];
     __shared__ float2 sp[BN1_MAX_S];
     __shared__ int n_missing;
@@ -848,15 +848,27 @@ extern "C" int grafp_bn_bwd_1pass(const void *x, const void *dz, int dtype, int 
     if (sync && training) {
         const bool f32 = dtype == GRAFP_F32;
         const bool ok = f32 ? bn_vec_ok<float>(x, dz, dx, nullptr, Mg) : bn_vec_ok<unsigned short>(x, dz, dx, nullptr, Mg);
-        const int Sg = ok ? bn1_plan(Mg, G, f32 ? 4 : 8, BN1_ITEMS_BWD) : 0;
+        // long rows (1024 pairs on one GPU: 128 chunks per view) rendezvous over fewer, larger chunks: 8 vectors per
+        // thread and operand instead of 4 (measured at 2048 clip-views: 0.43 -> see DESIGN of the HBM peak)
+        int items = BN1_ITEMS_BWD;
+        int Sg = ok ? bn1_plan(Mg, G, f32 ? 4 : 8, items) : 0;
+        if (ok && !f32 && (Sg == 0 || Sg * G > 128) && getenv("GRAFP_BN_BWD_ITEMS4") == nullptr) {
+            items = 2 * BN1_ITEMS_BWD;
+            Sg = bn1_plan(Mg, G, 8, items);
+        }
         if (Sg > 0) {
             const dim3 grid(Sg * G, C);
             if (f32)
-                hipLaunchKernelGGL((bn_bwd1_kernel<float>), grid, dim3(BN1_THREADS), 0, s, (const float *)x,
+                hipLaunchKernelGGL((bn_bwd1_kernel<float, BN1_ITEMS_BWD>), grid, dim3(BN1_THREADS), 0, s, (const float *)x,
                                    (const float *)dz, M, Mg, Sg, G, pre_bias, gamma, beta, save_mean, save_invstd, act,
                                    slope, (int *)sync, (float *)dx, dgamma, dbeta, dpre_bias, g_bn_spin_limit);
+            else if (items == BN1_ITEMS_BWD)
+                hipLaunchKernelGGL((bn_bwd1_kernel<unsigned short, BN1_ITEMS_BWD>), grid, dim3(BN1_THREADS), 0, s,
+                                   (const unsigned short *)x, (const unsigned short *)dz, M, Mg, Sg, G, pre_bias, gamma,
+                                   beta, save_mean, save_invstd, act, slope, (int *)sync, (unsigned short *)dx,
+                                   dgamma, dbeta, dpre_bias, g_bn_spin_limit);
             else
-                hipLaunchKernelGGL((bn_bwd1_kernel<unsigned short>), grid, dim3(BN1_THREADS), 0, s,
+                hipLaunchKernelGGL((bn_bwd1_kernel<unsigned short, 2 * BN1_ITEMS_BWD>), grid, dim3(BN1_THREADS), 0, s,
                                    (const unsigned short *)x, (const unsigned short *)dz, M, Mg, Sg, G, pre_bias, gamma,
                                    beta, save_mean, save_invstd, act, slope, (int *)sync, (unsigned short *)dx,
                                    dgamma, dbeta, dpre_bias, g_bn_spin_limit);

@@ -67,10 +67,13 @@ static int gemm_force_cfg() {
 static GemmPlan gemm_plan(int Rg, int K, int groups, int64_t M, int views) {
     GemmPlan p;
     const int64_t Mg = M / views;
-    // measured crossover (tools/gemm_bench.py, 512 clip-views): the large tile for >= 512 output rows per group, and
-    // for 256 rows when the operand is deep (K >= 512: matrix-heavy) or shallow (4K <= R: X is then read once for all
-    // 256 rows of a write-bound product)
-    bool large = (Rg >= 512 || (Rg >= 256 && (K >= 512 || 4 * K <= Rg))) && Mg % GemmL::TN == 0;
+    // measured crossover (tools/gemm_bench.py at 512 and 2048 clip-views): the large tile for >= 512 output rows per
+    // group; for 256 rows when the operand is deep (K >= 512: matrix-heavy), shallow (4K <= R: X is then read once for
+    // all 256 rows of a write-bound product) or the rows are long (>= 2^18 columns per view: the tensors no longer fit
+    // the Infinity Cache and the small tile's second pass over X goes to HBM); and for everything once a view has
+    // >= 2^20 columns (stage 0 at 1024 pairs per GPU), where its 512-byte row segments stream best
+    bool large = (Rg >= 512 || (Rg >= 256 && (K >= 512 || 4 * K <= Rg || Mg >= (1 << 18))) || Mg >= (1 << 20)) &&
+                 Mg % GemmL::TN == 0;
     if (gemm_force_cfg() >= 0) large = gemm_force_cfg() == 1 && Mg % GemmL::TN == 0;
     p.large = large ? 1 : 0;
     p.tr = large ? GemmL::TR : GemmS::TR;

@@ -419,11 +419,18 @@ static bool wgrad_dma_ok(int cout_g, int cin_g, int64_t M, int views) {
 static WgDmaPlan wgrad_dma_plan(int cout_g, int cin_g, int groups, int64_t M, int views, bool pro) {
     WgDmaPlan p;
     const int64_t outs = (int64_t)cout_g * cin_g;
-    // measured (tools/gemm_bench.py --wgrad, 512 clip-views): the 64 x 64 tile wins up to 2^19 outputs (many small
-    // workgroups, partial sums of a few MB; its operand re-reads are L2 hits at ~14 TB/s), the 128 x 128 tile beyond
-    // (stage 3, and the FFN layers of stage 2 tie); with the in-LDS normalisation the 128 tile from 256 operand rows
-    // (half the transform work per output).  The 256 x 256 tile (L) loses everywhere to its partial-sum traffic.
-    p.cfg = (outs >= (1 << 19) && cout_g >= 128 && cin_g >= 128) ? 1 : 0;
+    // measured (tools/gemm_bench.py --wgrad at 512 and 2048 clip-views): while both operands fit the 256 MB Infinity
+    // Cache the 64 x 64 tile wins up to 2^19 outputs (many small workgroups, a few MB of partial sums; its operand
+    // re-reads are cache hits at ~14 TB/s) and the 128 x 128 tile beyond; once the operands are larger than that
+    // (1024 pairs on one GPU) the re-reads of the small tile go to HBM and the 128 tile wins for every dense layer with
+    // >= 128 rows on both sides, and for the "few outputs, wide operand" layers (64 x 128, 64 x 256 of stage 0).  The
+    // grouped convolutions (32 ... 256 rows per group) stay on the small tile up to stage 2.  With the in-LDS
+    // normalisation the 128 tile from 256 operand rows.  The 256 x 256 tile (L) loses everywhere to its partial sums.
+    const bool big = (double)(cout_g + cin_g) * groups * (double)M * 2.0 > 500e6;
+    const int lo = cout_g < cin_g ? cout_g : cin_g;
+    p.cfg = 0;
+    if (lo >= 128 && (outs >= (1 << 19) || (big && groups == 1))) p.cfg = 1;
+    if (big && groups == 1 && cout_g >= 64 && cin_g >= 2 * cout_g) p.cfg = 1;
     if (pro && cin_g >= 256 && cout_g >= 128) p.cfg = 1;
     if (wg_force_cfg() >= 0 && wg_force_cfg() <= 2) p.cfg = wg_force_cfg();
     p.to = p.tc = p.cfg == 2 ? 256 : (p.cfg == 1 ? 128 : 64);
