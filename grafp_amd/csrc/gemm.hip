@@ -31,7 +31,11 @@ namespace grafp {
 constexpr int GM_KC = 32;                      // contraction per chunk
 constexpr int GM_OUT_BYTES = 32 * 128;         // per-wave output staging: 32 rows (r) x 64 m bf16
 constexpr int GM_DMA_PER_CHUNK = 4;            // LDS-DMA instructions per wave and chunk (2 W + 2 X) in both configs
-constexpr int GM_STORES_PER_RT = 4;            // 16-byte store instructions per wave and 32-row output tile
+constexpr int GM_STORES_PER_RT = 4;
+#ifndef GM_NT
+#define GM_NT 1
+#endif
+constexpr bool NT_STORE = GM_NT != 0;   // streaming (nt) stores of Y            // 16-byte store instructions per wave and 32-row output tile
 
 // Tile configurations: WR x WM waves, each wave RT x 2 MFMA tiles (32 RT rows x 64 columns).
 //   S: 2 x 2 waves, RT 2 -> 128 x 128 tile, 4 waves, 2 workgroups per CU: the streaming shapes (stages 0-1), where what
@@ -324,7 +328,10 @@ __global__ __launch_bounds__(CFG::THREADS) void conv1x1_gemm_kernel(
                         const int row = it * 8 + (lane >> 3), p16 = lane & 7;
                         const uint4 v = *reinterpret_cast<const uint4 *>(my_out + row * 128 + ((p16 ^ (row & 7)) << 4));
                         const int r = r0 + wr * 32 * RT + ri * 32 + row;
-                        *reinterpret_cast<uint4 *>(Y + (size_t)r * M + mcol + p16 * 8) = v;
+                        typedef unsigned gm_u4 __attribute__((ext_vector_type(4)));
+                        const gm_u4 vv = {v.x, v.y, v.z, v.w};
+                        if (NT_STORE) __builtin_nontemporal_store(vv, reinterpret_cast<gm_u4 *>(Y + (size_t)r * M + mcol + p16 * 8));
+                        else *reinterpret_cast<uint4 *>(Y + (size_t)r * M + mcol + p16 * 8) = v;
                     }
                 }
             }
