@@ -20,11 +20,29 @@ from .ops import FlatL2Index
 
 
 def get_index(index_type, train_data, train_data_shape, use_gpu=True, max_nitem_train=2e7, n_centroids=64):
-    """Returns an (empty) exact-L2 index of dimension train_data_shape[1].  No training step exists."""
+    """eval.py:9-123.  'l2' -> the exact brute-force index (ops.FlatL2Index); 'ivfpq' -> the IVF-PQ index of the
+    published protocol (grafp_amd.ivfpq.IVFPQIndex: n_centroids lists, 64 x 8-bit codes, trained on at most
+    max_nitem_train rows of train_data with a seeded k-means, nprobe = 20); every other faiss type ('ivf', 'ivfpq-rr',
+    'lsh', 'hnsw': approximations of the same search) is served by the exact index, a superset in accuracy.
+    GRAFP_EXACT_INDEX=1 serves 'ivfpq' exactly too."""
     mode = str(index_type).lower()
+    d = int(train_data_shape[1])
+    if mode == "ivfpq" and os.environ.get("GRAFP_EXACT_INDEX", "0") != "1":
+        from .ivfpq import IVFPQIndex
+        index = IVFPQIndex(d, nlist=int(n_centroids), M=64 if d % 64 == 0 else d, nbits=8)
+        n = len(train_data)
+        if n > max_nitem_train:
+            print("Training index using {:>3.2f} % of data...".format(100.0 * max_nitem_train / n))
+            sel = np.sort(np.random.permutation(n)[:int(max_nitem_train)])
+            index.train(np.asarray(train_data[sel]))
+        else:
+            print("Training index...")
+            index.train(np.asarray(train_data[0:n]))
+        index.nprobe = 20
+        return index
     if mode != "l2":
         print(f"index_type '{mode}' is served by exact brute-force L2 search on the GPU")
-    index = FlatL2Index(int(train_data_shape[1]))
+    index = FlatL2Index(d)
     index.nprobe = 20
     return index
 

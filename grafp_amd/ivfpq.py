@@ -1,0 +1,158 @@
+"""IVF-PQ index: the index of the published evaluation protocol, /root/reference/eval.py:65-69
+`faiss.IndexIVFPQ(IndexFlatL2(d), d, n_centroids=64, code_sz=64, nbits=8)`, `nprobe = 20` (:122) -- the default
+`index_type` of test_fp.py:276.  faiss==1.7.2 is not vendored and not installable; its published algorithm is restated
+(inverted file over a k-means coarse quantiser, product quantisation of the RESIDUALS with M sub-quantisers of 2^nbits
+codewords, asymmetric distance computation at search time) and the two k-means are pinned to a seeded Lloyd iteration
+of our own, so results are reproducible but only STATISTICALLY comparable with faiss (its k-means initialisation is not
+reproducible without faiss).  Training and encoding are dense algebra on the device; the search scans the probed
+lists with the hand-written kernel of csrc/ivfpq.hip.
+
+Same surface as ops.FlatL2Index / the subset of faiss eval.py uses: d, ntotal, nprobe, train(x), add(x), search(q, k),
+plus rows() (the raw vectors, which the sequence rerank reads: the reference keeps them in a memmap, eval.py:214-232).
+Exact search remains the faster and more accurate index on this GPU; this one exists so that the
+published protocol can be followed to the letter.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from ._lib import check, lib
+
+_vp = ctypes.c_void_p
+
+
+def kmeans(x, k, niter=25, seed=1234, chunk=1 << 14):
+    """Seeded Lloyd k-means on the device.  x (n, d) or batched (G, n, d) f32 -> centroids (k, d) / (G, k, d).
+    Initial centroids = k distinct training points (seeded permutation, the same for every batch entry); an empty
+    cluster keeps its previous centroid.  Deterministic for a given device, seed and input."""
+    squeeze = x.dim() == 2
+    x = x[None] if squeeze else x
+    G, n, d = x.shape
+    gen = torch.Generator().manual_seed(int(seed))
+    perm = torch.randperm(n, generator=gen)[:k].to(x.device)
+    if perm.numel() < k:                                            # fewer points than centroids: repeat
+        perm = perm.repeat((k + perm.numel() - 1) // perm.numel())[:k]
+    cent = x[:, perm].clone()
+    for _ in range(niter):
+        sums = torch.zeros_like(cent)
+        cnt = torch.zeros((G, k), dtype=torch.float32, device=x.device)
+        c2 = (cent * cent).sum(-1)                                  # (G, k)
+        for lo in range(0, n, chunk):
+            xb = x[:, lo:lo + chunk]
+            dist = c2[:, None, :] - 2.0 * torch.bmm(xb, cent.transpose(1, 2))        # + |x|^2: constant per row
+            a = dist.argmin(dim=2)                                  # (G, nb)
+            # cluster sums as a one-hot product: a fixed summation order (scatter_add's atomics are not reproducible)
+            oh = torch.nn.functional.one_hot(a, k).to(torch.float32)                 # (G, nb, k)
+            sums += torch.bmm(oh.transpose(1, 2), xb)
+            cnt += oh.sum(dim=1)
+        cent = torch.where(cnt[:, :, None] > 0, sums / cnt.clamp_min(1.0)[:, :, None], cent)
+    return cent[0] if squeeze else cent
+
+
+class IVFPQIndex:
+    def __init__(self, d=128, nlist=64, M=64, nbits=8, device=None, seed=1234, niter=25, max_points_per_centroid=256):
+        if nbits != 8:
+            raise NotImplementedError("IVFPQIndex: 8-bit codes (the reference's setting)")
+        if d % M:
+            raise ValueError("IVFPQIndex: d must be a multiple of M")
+        if not torch.cuda.is_available():
+            raise RuntimeError("IVFPQIndex needs a HIP device: there is no CPU fallback")
+        self.d, self.nlist, self.M, self.dsub = int(d), int(nlist), int(M), d // M
+        self.device = torch.device(device if device is not None else "cuda")
+        self.seed, self.niter, self.max_ppc = seed, niter, max_points_per_centroid
+        self.nprobe = 1                                   # faiss default; eval.get_index sets 20
+        self.is_trained = False
+        self.centroids = self.codebooks = None            # (nlist, d), (M, 256, dsub)
+        self._raw, self._codes, self._assign = [], [], []
+        self._sorted = None
+        self.ntotal = 0
+
+    # ---- training: coarse k-means, then one k-means per sub-space on the residuals (by_residual = True) ---------------
+    def train(self, x):
+        x = torch.as_tensor(np.ascontiguousarray(x) if isinstance(x, np.ndarray) else x).to(self.device, torch.float32)
+        x = x.reshape(-1, self.d)
+        cap = self.max_ppc * max(self.nlist, 256)
+        if x.shape[0] > cap:                              # faiss subsamples its training set the same way
+            gen = torch.Generator().manual_seed(self.seed + 1)
+            x = x[torch.randperm(x.shape[0], generator=gen)[:cap].to(self.device)]
+        self.centroids = kmeans(x, self.nlist, self.niter, self.seed).contiguous()
+        res = x - self.centroids[self._assign_lists(x)]
+        sub = res.reshape(-1, self.M, self.dsub).permute(1, 0, 2).contiguous()          # (M, n, dsub)
+        self.codebooks = kmeans(sub, 256, self.niter, self.seed + 2, chunk=1 << 14).contiguous()
+        self.is_trained = True
+
+    def _assign_lists(self, x):
+        c = self.centroids
+        return ((c * c).sum(1)[None, :] - 2.0 * x @ c.t()).argmin(dim=1)
+
+    def encode(self, x):
+        """x (n, d) on the device -> (list id (n) int64, codes (n, M) uint8)."""
+        a = self._assign_lists(x)
+        sub = (x - self.centroids[a]).reshape(-1, self.M, self.dsub).permute(1, 0, 2)     # (M, n, dsub)
+        cb = self.codebooks
+        dist = (cb * cb).sum(-1)[:, None, :] - 2.0 * torch.bmm(sub, cb.transpose(1, 2))  # (M, n, 256)
+        return a, dist.argmin(dim=2).t().contiguous().to(torch.uint8)
+
+    def add(self, x, chunk=1 << 16):
+        if not self.is_trained:
+            raise RuntimeError("IVFPQIndex.add before train")
+        x = torch.as_tensor(np.ascontiguousarray(x) if isinstance(x, np.ndarray) else x).reshape(-1, self.d)
+        for lo in range(0, x.shape[0], chunk):
+            xb = x[lo:lo + chunk].to(self.device, torch.float32)
+            a, codes = self.encode(xb)
+            self._raw.append(xb)
+            self._assign.append(a)
+            self._codes.append(codes)
+        self.ntotal += x.shape[0]
+        self._sorted = None
+
+    def _materialise(self):
+        if self._sorted is None:
+            raw = torch.cat(self._raw) if len(self._raw) != 1 else self._raw[0]
+            a, codes = torch.cat(self._assign), torch.cat(self._codes)
+            order = torch.argsort(a, stable=True)                                     # insertion order inside a list
+            counts = torch.bincount(a, minlength=self.nlist)
+            start = torch.zeros(self.nlist + 1, dtype=torch.int64, device=self.device)
+            start[1:] = torch.cumsum(counts, 0)
+            self._raw, self._assign, self._codes = [raw], [a], [codes]
+            self._sorted = (codes[order].contiguous(), order.contiguous(), start.contiguous(), counts)
+        return self._sorted
+
+    def rows(self):
+        self._materialise()
+        return self._raw[0]
+
+    # ---- search: nprobe nearest lists, asymmetric distances of their codes (csrc/ivfpq.hip), top-k --------------------
+    def search(self, q, k, max_queries_per_launch=256):
+        as_numpy = isinstance(q, np.ndarray)
+        qt = torch.as_tensor(np.ascontiguousarray(q) if as_numpy else q).to(self.device, torch.float32).reshape(-1, self.d)
+        nq = qt.shape[0]
+        D = torch.full((nq, k), float("inf"), device=self.device)
+        I = torch.full((nq, k), -1, dtype=torch.int64, device=self.device)
+        if self.ntotal and nq:
+            codes, ids, start, counts = self._materialise()
+            nprobe = max(1, min(int(self.nprobe), self.nlist))
+            c = self.centroids
+            coarse = (c * c).sum(1)[None, :] - 2.0 * qt @ c.t()
+            probe = torch.topk(coarse, nprobe, dim=1, largest=False).indices.to(torch.int32).contiguous()
+            stream = _vp(torch.cuda.current_stream().cuda_stream)
+            for lo in range(0, nq, max_queries_per_launch):
+                pb = probe[lo:lo + max_queries_per_launch]
+                qb = qt[lo:lo + max_queries_per_launch].contiguous()
+                lens = counts[pb.long()]                                                  # (nb, nprobe)
+                ostart = (torch.cumsum(lens, 1) - lens).contiguous()
+                stride = max(int(lens.sum(1).max().item()), 1)
+                dist = torch.full((qb.shape[0], stride), float("inf"), device=self.device)
+                pos = torch.full((qb.shape[0], stride), -1, dtype=torch.int32, device=self.device)
+                check(lib.grafp_ivfpq_scan_f32(_vp(qb.data_ptr()), qb.shape[0], self.d, _vp(c.data_ptr()), self.nlist,
+                                               _vp(self.codebooks.data_ptr()), self.M, _vp(codes.data_ptr()),
+                                               _vp(start.data_ptr()), _vp(pb.data_ptr()), nprobe, _vp(ostart.data_ptr()),
+                                               stride, _vp(dist.data_ptr()), _vp(pos.data_ptr()), stream), "ivfpq_scan")
+                kk = min(k, stride)
+                dv, di = torch.topk(dist, kk, dim=1, largest=False)
+                pv = torch.gather(pos, 1, di).long()
+                found = pv >= 0
+                D[lo:lo + qb.shape[0], :kk] = torch.where(found, dv, torch.full_like(dv, float("inf")))
+                I[lo:lo + qb.shape[0], :kk] = torch.where(found, ids[pv.clamp_min(0)], torch.full_like(pv, -1))
+        return (D.cpu().numpy(), I.cpu().numpy()) if as_numpy else (D, I)

@@ -183,6 +183,20 @@ int grafp_bn_bwd_1pass(const void *x, const void *dz, int dtype, int C, int64_t 
                        float *dpre_bias /* (C) or NULL */, void *ws, size_t ws_bytes, int32_t *sync,
                        grafp_stream_t stream);
 
+/* ---- IVF-PQ parity index: asymmetric-distance scan ----------------------------------------------------------------
+ * The index of the published protocol, faiss.IndexIVFPQ(IndexFlatL2(d), d, 64, 64, 8) with nprobe = 20
+ * (eval.py:65-69,122; faiss==1.7.2 itself is not vendored -- its published algorithm is restated).  For query i and
+ * its probe slot s (list probe[i][s], < 0 = skip) every code of that list gets
+ *   out_dist[i*row_stride + out_start[i][s] + j] = sum_m || (q_i - centroid)_m - codebook[m][code_j[m]] ||^2
+ *   out_pos [i*row_stride + out_start[i][s] + j] = list_start[list] + j          (row of the list-ordered code array)
+ * centroids (nlist, d) f32, codebooks (M, 256, d/M) f32, codes (n, M) uint8 in list order (16-byte aligned),
+ * list_start (nlist + 1) int64, probe (nq, nprobe) int32, out_start (nq, nprobe) int64.  The caller selects the top-k
+ * of each row and maps positions to ids (grafp_amd/ivfpq.py). */
+int grafp_ivfpq_scan_f32(const float *q, int nq, int d, const float *centroids, int nlist, const float *codebooks,
+                         int M, const uint8_t *codes, const int64_t *list_start, const int32_t *probe, int nprobe,
+                         const int64_t *out_start, int64_t row_stride, float *out_dist, int32_t *out_pos,
+                         grafp_stream_t stream);
+
 /* Test hooks of the single-pass BatchNorm (no reference counterpart): the number of polls after which a workgroup stops
  * waiting for its row-mates and recomputes their partial sums itself (returns the previous value; < 0 only reads it;
  * 0 = never wait), and a kernel that merely occupies `blocks` x `threads` CU slots for `clocks` shader cycles. */

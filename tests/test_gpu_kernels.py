@@ -877,3 +877,63 @@ def test_bn_single_pass_never_depends_on_absent_row_mates(dev):
                 assert torch.equal(a, b)
     finally:
         lib.grafp_bn_debug_spin_limit(old)
+
+
+# =============================================================== IVF-PQ parity index
+def test_ivfpq_index_vs_oracle_and_exact(dev):
+    """grafp_amd.ivfpq.IVFPQIndex (seeded k-means on the device, HIP asymmetric-distance scan) against the numpy
+    restatement given the SAME quantisers: identical codes (outside near-ties), identical search results; and against
+    the exact index statistically: recall of the true nearest neighbour among its top-20."""
+    from grafp_amd.ivfpq import IVFPQIndex
+    from grafp_amd.ops import FlatL2Index
+    from oracle import ivfpq as oq
+    rng = np.random.RandomState(3)
+    n, d = 6000, 128
+    base = rng.randn(40, d).astype(np.float32)
+    x = (base[rng.randint(0, 40, n)] + 0.35 * rng.randn(n, d)).astype(np.float32)       # clustered, like fingerprints
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    idx = IVFPQIndex(d, nlist=16, M=64)
+    idx.train(x)
+    idx2 = IVFPQIndex(d, nlist=16, M=64)
+    idx2.train(x)
+    assert torch.equal(idx.centroids, idx2.centroids) and torch.equal(idx.codebooks, idx2.codebooks)   # seeded
+    idx.add(x[:2500]); idx.add(x[2500:])
+    idx.nprobe = 5
+    cent, books = idx.centroids.cpu().numpy(), idx.codebooks.cpu().numpy()
+    a_o, codes_o = oq.encode(x, cent, books)
+    a_g, codes_g = torch.cat(idx._assign).cpu().numpy(), torch.cat(idx._codes).cpu().numpy()
+    assert (a_g == a_o).mean() > 0.999 and (codes_g == codes_o).mean() > 0.999          # f32 vs f64 near-ties only
+    q = (x[::60] + 0.05 * rng.randn(100, d)).astype(np.float32)
+    D, I = idx.search(q, 20)
+    Do, Io = oq.search(q, a_g, codes_g, cent, books, 5, 20)                               # the index's own codes
+    np.testing.assert_allclose(D, Do, rtol=2e-4, atol=2e-5)
+    assert (I == Io).mean() > 0.99
+    # torch tensors in, tensors out; k larger than a probe's content
+    Dt, It = idx.search(torch.from_numpy(q[:3]).to(dev), 4)
+    assert Dt.is_cuda and torch.equal(It.cpu(), torch.from_numpy(I[:3, :4]))
+    # against the exact index: the planted neighbour is found
+    ex = FlatL2Index(d)
+    ex.add(x)
+    _, Ie = ex.search(q, 1)
+    assert (I == Ie[:, :1]).any(axis=1).mean() > 0.9
+    idx.nprobe = 16                                                                       # all lists: PQ error only
+    _, Iall = idx.search(q, 20)
+    assert (Iall == Ie[:, :1]).any(axis=1).mean() > 0.97
+    assert idx.rows().shape == (n, d) and idx.ntotal == n
+
+
+def test_eval_faiss_with_the_ivfpq_index(dev, tmp_path, monkeypatch):
+    """eval_faiss(index_type='ivfpq') -- the default of the reference's test_fp.py -- runs the protocol's index (64
+    lists, 64 x 8-bit codes, nprobe 20) and its hit-rate table stays close to the exact index's on the golden case."""
+    from _common import eval_case, golden, write_eval_case
+    from grafp_amd.eval import eval_faiss
+    g = golden("eval_faiss.npz")
+    case = eval_case()
+    write_eval_case(str(tmp_path), case)
+    np.save(tmp_path / "ids.npy", case["test_ids"])
+    kw = dict(test_ids=str(tmp_path / "ids.npy"), test_seq_len=case["test_seq_len"], k_probe=case["k_probe"])
+    approx = eval_faiss(str(tmp_path), index_type="ivfpq", n_centroids=8, **kw)
+    assert approx.shape == g["hit_rates"].shape
+    assert np.abs(approx - g["hit_rates"]).max() <= 10.0 and approx[3].min() >= g["hit_rates"][3].min() - 10.0   # 40 ids: 2.5 pt each
+    monkeypatch.setenv("GRAFP_EXACT_INDEX", "1")
+    np.testing.assert_array_equal(eval_faiss(str(tmp_path), index_type="ivfpq", **kw), g["hit_rates"])

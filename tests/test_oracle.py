@@ -394,3 +394,30 @@ def test_augment_oracle_matches_definitions():
         got_snr = 20 * np.log10(np.sqrt((x[b].astype(np.float64) ** 2).mean()) / np.sqrt((added ** 2).mean()))
         assert abs(got_snr - snr[b]) < 1e-3
         assert np.corrcoef(added, n)[0, 1] > 0.999999
+
+
+def test_ivfpq_restatement_is_the_distance_to_the_dequantised_vector():
+    """Pins oracle/ivfpq.py to the published definition: the asymmetric distance of a code equals the exact squared
+    distance between the query and the vector the code reconstructs to; codes are the nearest codewords of the residual."""
+    from oracle import ivfpq
+    rng = np.random.RandomState(0)
+    d, M, nlist = 16, 8, 5
+    x = rng.randn(300, d).astype(np.float32)
+    cent = x[rng.permutation(300)[:nlist]].copy()
+    books = rng.randn(M, 256, d // M).astype(np.float32) * 0.5
+    a, codes = ivfpq.encode(x, cent, books)
+    assert a.shape == (300,) and codes.shape == (300, M) and codes.dtype == np.uint8
+    rec = ivfpq.reconstruct(a, codes, cent, books)
+    # no other codeword of any sub-space is closer to the residual than the chosen one
+    res = (x - cent[a]).reshape(300, M, d // M)
+    for m in (0, 3, 7):
+        dall = ((res[:, m, None, :] - books[m][None]) ** 2).sum(-1)
+        assert (dall.min(axis=1) >= ((res[:, m] - books[m][codes[:, m]]) ** 2).sum(-1) - 1e-9).all()
+    q = rng.randn(7, d).astype(np.float32)
+    D, I = ivfpq.search(q, a, codes, cent, books, nprobe=nlist, k=10)               # all lists probed: exhaustive
+    exact = ((q[:, None, :].astype(np.float64) - rec[None]) ** 2).sum(-1)
+    order = np.argsort(exact, axis=1, kind="stable")[:, :10]
+    np.testing.assert_allclose(D, np.take_along_axis(exact, order, axis=1), rtol=1e-9, atol=1e-9)
+    assert (I == order).mean() > 0.98                                               # ties aside
+    D2, I2 = ivfpq.search(q, a, codes, cent, books, nprobe=2, k=10)                   # fewer lists: a subset, never better
+    assert (D2[:, 0] >= D[:, 0] - 1e-12).all() and ((I2 >= 0).sum(1) <= 10).all()
