@@ -314,6 +314,7 @@ def main():
     if world > 1 and B != 256 and args.batch_per_gpu is None:
         # the weak-scaling variant beside the headline: 256 pairs per GPU (BASELINE config 2 on every GPU)
         cfg_w = dict(cfg, bsz_train=256 * world)
+        trainer.sync.close()                                   # its gradient hooks must not fire in the next trainer's steps
         tw = Trainer(cfg_w, model, device, amp_dtype=amp)
         xw_i, xw_j = synthetic_batch(256, seed=300 + rank, device=device)
         for _ in range(2):
@@ -322,6 +323,7 @@ def main():
         dt = max_over_ranks(dt) / max(3, args.steps // 2)
         weak = {"value": round(256 * world / dt, 2), "unit": "clips/s", "ms_per_step": round(dt * 1e3, 3),
                 "global_batch": 256 * world, "scaling": "weak", "note": "256 pairs per GPU, global negatives"}
+        tw.sync.close()
         del tw, xw_i, xw_j
 
     sharded = None

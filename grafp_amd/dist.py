@@ -135,6 +135,16 @@ class GradSync:
                 h.wait()
             self._handles, self._left, self._fired = [], list(self._size), [False] * len(self.bounds)
 
+    def close(self):
+        """Detach the autograd hooks (a second GradSync over the same parameters -- another Trainer on the same model --
+        must not find this one still listening) and wait for anything in flight."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        for h in self._handles:
+            h.wait()
+        self._handles = []
+
     def _pack(self, b):
         """Bucket b's gradients -> its slice of the flat buffer: one multi-tensor copy.  A parameter that took no part
         in this step (grad None) contributes zero: ONLY its own slice is cleared -- members whose .grad already is

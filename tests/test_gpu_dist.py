@@ -152,7 +152,8 @@ def test_bench_two_ranks_one_gpu(tmp_path):
                    MASTER_PORT="29654", GRAFP_LOCAL_DEVICE="0", GRAFP_DIST_BACKEND="gloo",
                    HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
-                                       "--warmup", "1", "--batch-per-gpu", "16", "--no-cpu-baseline"],
+                                       "--warmup", "1", "--global-batch", "32", "--kernel-steps", "1",
+                                       "--no-cpu-baseline"],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     logs = []
     for p in procs:
@@ -162,7 +163,9 @@ def test_bench_two_ranks_one_gpu(tmp_path):
     lines = [ln for ln in logs[0].splitlines() if ln.startswith("{")]
     assert len(lines) == 1 and not any(ln.startswith("{") for ln in logs[1].splitlines())
     line = json.loads(lines[0])
-    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0      # the global batch is split
     assert line["config"]["global_batch"] == 32 and line["roofline"]["frac"] > 0
+    w = line["weak_scaling_256_per_gpu"]                                                   # ... and 256 pairs per rank beside it
+    assert w["global_batch"] == 512 and w["scaling"] == "weak" and w["value"] > 0
     rs = line["retrieval_sharded"]                 # config-5 shape: one 1.25 M-row shard per rank, planted queries
     assert rs["n_gpus"] == 2 and rs["nq"] == 4096 and 0.5 < rs["top1_hit_rate"] < 1.0 and rs["qps"] > 0   # informative sigma
