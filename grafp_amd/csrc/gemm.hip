@@ -376,17 +376,11 @@ __device__ __forceinline__ void gm_chan(float &n, float &mean, float &m2, float 
         n = nn;
     }
 }
-__global__ __launch_bounds__(512) void bn_finalize_kernel(const float *__restrict__ part, int C, int views, int P,
-                                                          int wm, int tiles_range, int col_tiles_view, int64_t Mg,
-                                                          const float *__restrict__ pre_bias,
-                                                          const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                          float eps, float momentum, float *__restrict__ running_mean,
-                                                          float *__restrict__ running_var, float *__restrict__ save_mean,
-                                                          float *__restrict__ save_invstd, float2 *__restrict__ tab) {
-    __shared__ float2 s_stat[8];                 // (mean + bias, unbiased variance) per view
-    const int c = blockIdx.x, lane = threadIdx.x & 63, v = threadIdx.x >> 6;
-    const float pb = pre_bias ? pre_bias[c] : 0.0f;
-    float n = 0.0f, mean = 0.0f, m2 = 0.0f;
+// (count, mean, M2) of row c, view v from its P partials: every lane of the calling WAVE returns the same values
+__device__ __forceinline__ void gm_row_stats(const float *__restrict__ part, int c, int v, int views, int P, int wm,
+                                             int tiles_range, int col_tiles_view, int lane, float &n, float &mean,
+                                             float &m2) {
+    n = 0.0f, mean = 0.0f, m2 = 0.0f;
     for (int p = lane; p < P; p += 64) {
         const float *pp = part + (((size_t)c * views + v) * P + p) * 3;
         const int range = p / wm;
@@ -407,6 +401,20 @@ __global__ __launch_bounds__(512) void bn_finalize_kernel(const float *__restric
             gm_chan(n, mean, m2, nb, mb, m2b);
         }
     }
+}
+
+__global__ __launch_bounds__(512) void bn_finalize_kernel(const float *__restrict__ part, int C, int views, int P,
+                                                          int wm, int tiles_range, int col_tiles_view, int64_t Mg,
+                                                          const float *__restrict__ pre_bias,
+                                                          const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                          float eps, float momentum, float *__restrict__ running_mean,
+                                                          float *__restrict__ running_var, float *__restrict__ save_mean,
+                                                          float *__restrict__ save_invstd, float2 *__restrict__ tab) {
+    __shared__ float2 s_stat[8];                 // (mean + bias, unbiased variance) per view
+    const int c = blockIdx.x, lane = threadIdx.x & 63, v = threadIdx.x >> 6;
+    const float pb = pre_bias ? pre_bias[c] : 0.0f;
+    float n, mean, m2;
+    gm_row_stats(part, c, v, views, P, wm, tiles_range, col_tiles_view, lane, n, mean, m2);
     if (lane == 0) {
         const float var = fmaxf(m2 / n, 0.0f);
         const float meanf = mean + pb;                              // statistics of y + conv bias
@@ -448,23 +456,84 @@ __global__ __launch_bounds__(64) void bn_eval_tab_kernel(int C, int views, const
     }
 }
 
-// z = act(y * scale + shift) [+ residual] over rows of bf16 (C, M); 4 x 16-byte vectors in flight per thread
+struct BnStatsArgs {            // what bn_finalize_kernel takes, for the affine kernel that finalises by itself
+    const float *part, *pre_bias, *gamma, *beta;
+    float *running_mean, *running_var, *save_mean, *save_invstd;
+    float2 *tab;
+    int P, wm, tiles_range, col_tiles_view;
+    float eps, momentum;
+};
+
+// z = act(y * scale + shift) [+ residual] over rows of bf16 (C, M); 4 x 16-byte vectors in flight per thread.
+// STATS: no table comes in -- every workgroup combines the GEMM's partial sums of its (row, view) itself (one wave, a
+// few microseconds, with the workgroup's first batch of vectors already requested), the first workgroup of a view
+// saves mean / invstd / table, the first of a row advances the running statistics: no separate bn_finalize launch.
+template <bool STATS>
 __global__ __launch_bounds__(256) void bn_affine_bf16_kernel(const unsigned short *__restrict__ y, int64_t M, int64_t Mg,
                                                              int views, int chunks_view, int64_t chunk,
-                                                             const float2 *__restrict__ tab,
+                                                             const float2 *__restrict__ tab, BnStatsArgs st,
                                                              const unsigned short *__restrict__ residual, int act,
                                                              float slope, unsigned short *__restrict__ out) {
     const int c = blockIdx.y, s = blockIdx.x, tid = threadIdx.x;
     const int v = s / chunks_view, sl = s - v * chunks_view;
-    const float2 ss = tab[(size_t)c * views + v];
     const unsigned short *row = y + (size_t)c * M, *rrow = residual ? residual + (size_t)c * M : nullptr;
     unsigned short *orow = out + (size_t)c * M;
     const int64_t vend = (int64_t)(v + 1) * Mg;
     const int64_t lo = (int64_t)v * Mg + (int64_t)sl * chunk, hi = (lo + chunk < vend) ? lo + chunk : vend;
     constexpr int U = 4;
     const int64_t step = 256 * 8;
-    auto one = [&](const uint4 &rx, const uint4 &rr, unsigned short *dst) {
-        const unsigned w[4] = {rx.x, rx.y, rx.z, rx.w}, q[4] = {rr.x, rr.y, rr.z, rr.w};
+    int64_t m = lo + (int64_t)tid * 8;
+    uint4 rx[U], rr[U];
+    bool full = m + (U - 1) * step + 8 <= hi;
+    auto fetch = [&]() {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            rx[u] = *reinterpret_cast<const uint4 *>(row + m + u * step);
+            rr[u] = rrow ? *reinterpret_cast<const uint4 *>(rrow + m + u * step) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    if (full) fetch();                                        // in flight while the statistics are combined
+    float2 ss;
+    if (STATS) {
+        __shared__ float2 s_ss, s_stat[4];
+        const int wave = tid >> 6, lane = tid & 63;
+        const bool row_leader = s == 0;                       // view 0, chunk 0: also owns the running statistics
+        const int vv = row_leader ? wave : v;                 // the leader's waves take one view each
+        if (row_leader ? wave < views : wave == 0) {
+            const float pb = st.pre_bias ? st.pre_bias[c] : 0.0f;
+            float n, mean, m2;
+            gm_row_stats(st.part, c, vv, views, st.P, st.wm, st.tiles_range, st.col_tiles_view, lane, n, mean, m2);
+            if (lane == 0) {
+                const float var = fmaxf(m2 / n, 0.0f);
+                const float meanf = mean + pb;
+                const float invstd = 1.0f / sqrtf(var + st.eps);
+                const float g = st.gamma[c] * invstd;
+                const float2 t = make_float2(g, st.beta[c] + (pb - meanf) * g);
+                if (vv == v) s_ss = t;
+                if (row_leader) s_stat[vv] = make_float2(meanf, Mg > 1 ? m2 / (n - 1.0f) : var);
+                if (sl == 0 && vv == v) {
+                    st.save_mean[c * views + v] = meanf;
+                    st.save_invstd[c * views + v] = invstd;
+                    st.tab[(size_t)c * views + v] = t;
+                }
+            }
+        }
+        __syncthreads();
+        ss = s_ss;
+        if (row_leader && tid == 0 && st.running_mean) {
+            float rm = st.running_mean[c], rv = st.running_var[c];
+            for (int u = 0; u < views; ++u) {
+                rm = (1.0f - st.momentum) * rm + st.momentum * s_stat[u].x;
+                rv = (1.0f - st.momentum) * rv + st.momentum * s_stat[u].y;
+            }
+            st.running_mean[c] = rm;
+            st.running_var[c] = rv;
+        }
+    } else {
+        ss = tab[(size_t)c * views + v];
+    }
+    auto one = [&](const uint4 &ax, const uint4 &ar, unsigned short *dst) {
+        const unsigned w[4] = {ax.x, ax.y, ax.z, ax.w}, q[4] = {ar.x, ar.y, ar.z, ar.w};
         unsigned o[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -479,21 +548,17 @@ __global__ __launch_bounds__(256) void bn_affine_bf16_kernel(const unsigned shor
         const u4 t = {o[0], o[1], o[2], o[3]};
         __builtin_nontemporal_store(t, reinterpret_cast<u4 *>(dst));
     };
-    int64_t m = lo + (int64_t)tid * 8;
-    for (; m + (U - 1) * step + 8 <= hi; m += U * step) {
-        uint4 rx[U], rr[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            rx[u] = *reinterpret_cast<const uint4 *>(row + m + u * step);
-            rr[u] = rrow ? *reinterpret_cast<const uint4 *>(rrow + m + u * step) : make_uint4(0, 0, 0, 0);
-        }
+    while (full) {
 #pragma unroll
         for (int u = 0; u < U; ++u) one(rx[u], rr[u], orow + m + u * step);
+        m += U * step;
+        full = m + (U - 1) * step + 8 <= hi;
+        if (full) fetch();
     }
     for (; m + 8 <= hi; m += step) {
-        const uint4 rx = *reinterpret_cast<const uint4 *>(row + m);
-        const uint4 rr = rrow ? *reinterpret_cast<const uint4 *>(rrow + m) : make_uint4(0, 0, 0, 0);
-        one(rx, rr, orow + m);
+        const uint4 ax = *reinterpret_cast<const uint4 *>(row + m);
+        const uint4 ar = rrow ? *reinterpret_cast<const uint4 *>(rrow + m) : make_uint4(0, 0, 0, 0);
+        one(ax, ar, orow + m);
     }
 }
 
@@ -583,13 +648,14 @@ extern "C" int grafp_bn_finalize(const float *stats_part, int C, int K, int grou
     return GRAFP_OK;
 }
 
-extern "C" int grafp_bn_affine_bf16(const void *y, int C, int64_t M, int views, const float *tab, const void *residual,
-                                    int act, float slope, void *out, grafp_stream_t stream) {
+static int bn_affine_launch(const void *y, int C, int64_t M, int views, const float *tab, const grafp::BnStatsArgs *st,
+                            const void *residual, int act, float slope, void *out, grafp_stream_t stream) {
     using namespace grafp;
-    GRAFP_REQUIRE(y && tab && out, "bn_affine: null pointer");
-    GRAFP_REQUIRE(C > 0 && M > 0 && views > 0 && M % views == 0 && (M / views) % 8 == 0,
+    GRAFP_REQUIRE(y && out && (tab || st), "bn_affine: null pointer");
+    GRAFP_REQUIRE(C > 0 && C <= 65535 && M > 0 && views > 0 && M % views == 0 && (M / views) % 8 == 0,
                   "bn_affine: bad shape C=%d M=%lld views=%d", C, (long long)M, views);
     GRAFP_REQUIRE((((uintptr_t)y | (uintptr_t)out | (uintptr_t)residual) & 15) == 0, "bn_affine: 16-byte alignment");
+    GRAFP_REQUIRE(act >= 0 && act <= 2, "bn_affine: bad activation %d", act);
     const int64_t Mg = M / views;
     // ~2048 workgroups in total, >= 8192 elements per workgroup
     int chunks_view = (int)((2048 + (int64_t)C * views - 1) / ((int64_t)C * views));
@@ -599,9 +665,38 @@ extern "C" int grafp_bn_affine_bf16(const void *y, int C, int64_t M, int views, 
     int64_t chunk = (Mg + chunks_view - 1) / chunks_view;
     chunk = (chunk + 7) / 8 * 8;
     chunks_view = (int)((Mg + chunk - 1) / chunk);
-    hipLaunchKernelGGL(bn_affine_bf16_kernel, dim3(chunks_view * views, C), dim3(256), 0, (hipStream_t)stream,
-                       (const unsigned short *)y, M, Mg, views, chunks_view, chunk, (const float2 *)tab,
-                       (const unsigned short *)residual, act, slope, (unsigned short *)out);
+    const dim3 grid(chunks_view * views, C);
+    if (st)
+        hipLaunchKernelGGL(bn_affine_bf16_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short *)y,
+                           M, Mg, views, chunks_view, chunk, (const float2 *)nullptr, *st,
+                           (const unsigned short *)residual, act, slope, (unsigned short *)out);
+    else
+        hipLaunchKernelGGL(bn_affine_bf16_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short *)y,
+                           M, Mg, views, chunks_view, chunk, (const float2 *)tab, BnStatsArgs{},
+                           (const unsigned short *)residual, act, slope, (unsigned short *)out);
     GRAFP_CHECK_LAUNCH("bn_affine_bf16_kernel");
     return GRAFP_OK;
+}
+
+extern "C" int grafp_bn_affine_bf16(const void *y, int C, int64_t M, int views, const float *tab, const void *residual,
+                                    int act, float slope, void *out, grafp_stream_t stream) {
+    return bn_affine_launch(y, C, M, views, tab, nullptr, residual, act, slope, out, stream);
+}
+
+extern "C" int grafp_bn_finalize_affine_bf16(const void *y, const float *stats_part, int C, int K, int groups, int64_t M,
+                                             int views, const float *pre_bias, const float *gamma, const float *beta,
+                                             float eps, float momentum, float *running_mean, float *running_var,
+                                             float *save_mean, float *save_invstd, float *tab, const void *residual,
+                                             int act, float slope, void *out, grafp_stream_t stream) {
+    using namespace grafp;
+    GRAFP_REQUIRE(stats_part && gamma && beta && save_mean && save_invstd && tab, "bn_finalize_affine: null pointer");
+    GRAFP_REQUIRE(views >= 1 && views <= 4, "bn_finalize_affine: 1..4 views (one wave each in the row's first workgroup)");
+    GRAFP_REQUIRE(gemm_shape_ok(C, K, groups, M, views), "bn_finalize_affine: shape does not match a conv1x1_gemm launch");
+    const GemmPlan p = gemm_plan(C / groups, K / groups, groups, M, views);
+    BnStatsArgs st;
+    st.part = stats_part; st.pre_bias = pre_bias; st.gamma = gamma; st.beta = beta;
+    st.running_mean = running_mean; st.running_var = running_var; st.save_mean = save_mean; st.save_invstd = save_invstd;
+    st.tab = (float2 *)tab; st.P = p.P; st.wm = p.wm; st.tiles_range = p.tiles_range; st.col_tiles_view = p.col_tiles_view;
+    st.eps = eps; st.momentum = momentum;
+    return bn_affine_launch(y, C, M, views, nullptr, &st, residual, act, slope, out, stream);
 }

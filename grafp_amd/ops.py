@@ -647,6 +647,27 @@ def bn_finalize(part, C, K, groups, M, views, gamma, beta, pre_bias, running_mea
     return mean, invstd, tab
 
 
+def bn_finalize_affine(y, part, K, groups, views, gamma, beta, pre_bias, running_mean, running_var, momentum, eps,
+                       residual=None, act=ACT_NONE, slope=0.0):
+    """bn_finalize (training) + bn_affine in ONE launch (every workgroup combines the partial sums of its row itself):
+    -> (z, mean, invstd, tab).  y (C, M) bf16 and `part` from conv1x1_gemm(..., stats=True); 1 <= views <= 4."""
+    _require_gpu(y, part)
+    C, M = y.shape[0], y.numel() // y.shape[0]
+    mean = torch.empty((C, views), dtype=torch.float32, device=y.device)
+    invstd = torch.empty((C, views), dtype=torch.float32, device=y.device)
+    tab = torch.empty((C, views, 2), dtype=torch.float32, device=y.device)
+    g32, b32 = _f32c(gamma), _f32c(beta)
+    pb = None if pre_bias is None else _f32c(pre_bias)
+    res = None if residual is None else residual.to(torch.bfloat16).contiguous()
+    z = torch.empty_like(y)
+    with _timed("bn_affine", (C, M)):
+        check(lib.grafp_bn_finalize_affine_bf16(_p(y), _p(part), C, K, groups, M, views, _p(pb), _p(g32), _p(b32),
+                                                float(eps), float(momentum), _p(running_mean), _p(running_var), _p(mean),
+                                                _p(invstd), _p(tab), _p(res), int(act), float(slope), _p(z), _stream()),
+              "bn_finalize_affine")
+    return z, mean, invstd, tab
+
+
 def bn_affine(y, tab, views=1, residual=None, act=ACT_NONE, slope=0.0):
     """z = act(y * scale + shift) + residual over bf16 (C, M) rows (one read [+ residual], one write)."""
     _require_gpu(y, tab)
@@ -721,10 +742,14 @@ class _ConvBnAct(torch.autograd.Function):
             y, part = conv1x1_gemm(wl, x, conv_groups, views, stats=True)
         else:
             y, part = conv1x1_gemm(wl, x, conv_groups, views), None
-        mean, invstd, tab = bn_finalize(part, R, K, conv_groups, M, views, g32, b32, pb, running_mean, running_var,
-                                        training, momentum, eps)
-        res = None if residual is None else residual.detach()
-        z = bn_affine(y, tab, views, res, act, slope)
+        res = None if residual is None else residual.detach().to(torch.bfloat16).contiguous()
+        if training and views <= 4:
+            z, mean, invstd, tab = bn_finalize_affine(y, part, K, conv_groups, views, g32, b32, pb, running_mean,
+                                                      running_var, momentum, eps, res, act, slope)
+        else:
+            mean, invstd, tab = bn_finalize(part, R, K, conv_groups, M, views, g32, b32, pb, running_mean, running_var,
+                                            training, momentum, eps)
+            z = bn_affine(y, tab, views, res, act, slope)
         ctx.save_for_backward(x, wl, y, mean, invstd, g32, b32, pb if pb is not None else mean.new_empty(0))
         ctx.cfg = (R, K, M, conv_groups, views, act, float(slope), bool(training), pb is not None, residual is not None,
                    tuple(w.shape))

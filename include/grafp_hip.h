@@ -237,6 +237,15 @@ int grafp_bn_finalize(const float *stats_part, int C, int K, int groups, int64_t
 int grafp_bn_affine_bf16(const void *y, int C, int64_t M, int views, const float *tab, const void *residual, int act,
                          float slope, void *out, grafp_stream_t stream);
 
+/* grafp_bn_finalize (training) and grafp_bn_affine_bf16 in ONE launch: every workgroup combines the partial sums of its
+ * (row, view) itself; the first workgroup of a view saves mean / invstd / tab, the first of a row advances the running
+ * statistics.  Same arguments and results as the two calls; 1 <= views <= 4. */
+int grafp_bn_finalize_affine_bf16(const void *y, const float *stats_part, int C, int K, int groups, int64_t M, int views,
+                                  const float *pre_bias, const float *gamma, const float *beta, float eps,
+                                  float momentum, float *running_mean, float *running_var, float *save_mean,
+                                  float *save_invstd, float *tab, const void *residual, int act, float slope,
+                                  void *out, grafp_stream_t stream);
+
 /* ---- K9 backward: weight gradient of a 1x1 convolution on the (C, M) layout ------------------------------
  * dW[o][c] = sum_m grad_out[o][m] * x[c][m] for every 1x1 Conv2d of the encoder (torch_vertex.py:152-162,
  * torch_nn.py:56, graph_encoder.py:52-55,131): tiny output, contraction over M = B*N with both operands contiguous

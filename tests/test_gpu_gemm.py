@@ -70,6 +70,13 @@ def test_gemm_product_and_stats(R, K, groups, M, views):
     t = tab.reshape(R, views, 1, 2)
     zr = torch.relu(torch.addcmul(t[..., 1], y.float().reshape(R, views, -1), t[..., 0])).reshape(R, M) + res.float()
     assert float((z.float() - zr.to(torch.bfloat16).float()).abs().max()) <= float(zr.abs().max()) * 2.0 ** -7
+    # finalize + affine as ONE launch: the same bits everywhere
+    if views <= 4:
+        rm2, rv2 = torch.zeros(R, device=DEV), torch.ones(R, device=DEV)
+        z2, mean2, invstd2, tab2 = ops.bn_finalize_affine(y, part, K, groups, views, gamma, beta, bias, rm2, rv2, 0.1, 1e-5,
+                                                          residual=res, act=ops.ACT_RELU)
+        assert torch.equal(z2, z) and torch.equal(mean2, mean) and torch.equal(invstd2, invstd) and torch.equal(tab2, tab)
+        assert torch.equal(rm2, rm) and torch.equal(rv2, rv)
 
 
 def test_gemm_statistics_with_large_mean():
