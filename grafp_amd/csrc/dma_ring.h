@@ -1,5 +1,7 @@
 // dma_ring.h -- pieces shared by the LDS-DMA ring kernels (gemm.hip, wgrad.hip), gfx950 only.
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 
 namespace grafp {
@@ -7,6 +9,7 @@ namespace grafp {
 typedef short gm_bf16x8 __attribute__((ext_vector_type(8)));
 typedef short gm_s16x4 __attribute__((ext_vector_type(4)));
 typedef float gm_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned gm_u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 gm_bf16x2 __attribute__((ext_vector_type(2)));
 typedef const void __attribute__((address_space(1))) *gm_gptr;
 typedef void __attribute__((address_space(3))) *gm_lptr;

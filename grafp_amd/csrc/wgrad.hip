@@ -240,17 +240,31 @@ __global__ __launch_bounds__(256) void wgrad3_partial_kernel(const float *__rest
 // PRO: X is the RAW output of the previous layer's convolution; its BatchNorm + activation (per X row: scale, shift of
 // the slice's view) is applied to the X tile in LDS, so the normalised activation the forward pass never wrote is not
 // needed here either (grafp_conv1x1_gemm_bf16's pro_tab, same table).
-template <int WR_, int WM_, int RT_, int CT_, int NS_> struct WgCfg {
+template <int WR_, int WM_, int RT_, int CT_, int NS_, int KC_ = 64> struct WgCfg {
     static constexpr int WR = WR_, WM = WM_, RT = RT_, CT = CT_, NS = NS_, NW = WR_ * WM_, THREADS = 64 * NW;
     static constexpr int TO = WR_ * RT_ * 32, TC = WM_ * CT_ * 32;
-    static constexpr int KC = 64;                                  // contraction (m) per chunk: 128-byte rows
-    static constexpr int G_BYTES = TO * 128, X_BYTES = TC * 128, STAGE = G_BYTES + X_BYTES;
-    static constexpr int G_DMA = TO / 8 / NW, X_DMA = TC / 8 / NW;   // DMA instructions (8 rows each) per wave and chunk
-    static_assert(TO % (8 * NW) == 0 && TC % (8 * NW) == 0, "whole DMA instructions per wave");
+    static constexpr int KC = KC_;                                 // contraction (m) per chunk: 128- or 64-byte rows
+    static constexpr int ROWB = KC_ * 2, SLOTS = KC_ / 8;          // bytes and 16-byte slots per tile row
+    static constexpr int RPD = 1024 / ROWB;                        // tile rows one DMA instruction (64 x 16 B) covers
+    static constexpr int RP256 = 256 / ROWB;                       // tile rows per 256 B = per pass over the 64 banks
+    static constexpr int G_BYTES = TO * ROWB, X_BYTES = TC * ROWB, STAGE = G_BYTES + X_BYTES;
+    static constexpr int G_DMA = TO / RPD / NW, X_DMA = TC / RPD / NW;   // DMA instructions per wave and chunk
+    static_assert(KC_ == 64 || KC_ == 32, "row pieces of 128 or 64 bytes");
+    static_assert(TO % (RPD * NW) == 0 && TC % (RPD * NW) == 0, "whole DMA instructions per wave");
+    // slot s of row r lives at slot s ^ swz(r): a 16-lane ds_read_b128 group (16 consecutive rows, one slot) then
+    // covers every bank exactly once -- 128-byte rows: 2 rows x 8 slots, 64-byte rows: 4 rows x 4 slots per 256 B
+    static __device__ __forceinline__ int swz(int row) { return (row / RP256) & (SLOTS - 1); }
 };
 typedef WgCfg<2, 2, 1, 1, 4> WgT;
 typedef WgCfg<2, 2, 2, 2, 2> WgS;
 typedef WgCfg<2, 4, 4, 2, 2> WgL;
+// 64-byte row pieces: the same LDS holds twice as many chunks, i.e. twice the loads in flight per workgroup -- what the
+// wide tiles need (their operand re-reads come from L2 at the rate of bytes-in-flight / ~1.8 us)
+typedef WgCfg<2, 2, 2, 2, 5, 32> WgS32;                            // 128 x 128, 5 x 16 KB, 2 workgroups per CU
+typedef WgCfg<4, 2, 2, 2, 3, 32> WgM32;                            // 256 x 128, 8 waves, 3 x 24 KB, 2 workgroups per CU
+typedef WgCfg<2, 4, 4, 2, 4, 32> WgL32;                            // 256 x 256, 8 waves, 4 x 32 KB, 1 workgroup per CU
+typedef WgCfg<2, 2, 2, 2, 3> WgSG;                                 // wgrad_gr_kernel: 128 x 128, 80 KB, 2 workgroups per CU
+typedef WgCfg<2, 4, 4, 2, 3> WgLG;                                 // wgrad_gr_kernel: 256 x 256, 160 KB, 1 workgroup per CU
 
 template <typename CFG, bool PRO>
 __global__ __launch_bounds__(CFG::THREADS) void wgrad_dma_kernel(
@@ -286,22 +300,23 @@ __global__ __launch_bounds__(CFG::THREADS) void wgrad_dma_kernel(
             reinterpret_cast<float2 *>(s_tab)[r] = src[(size_t)c * views + view];
         }
     }
-    // DMA: instruction q covers tile rows 8q .. 8q+7 (128 B each); lane -> row 8q + lane/8, slot' = lane & 7 holds the
-    // source slot slot' ^ ((row >> 1) & 7).  Rows beyond the matrix re-read its last row (their outputs are not stored).
+    // DMA: instruction q covers tile rows RPD q .. RPD q + RPD - 1; lane -> row RPD q + lane / SLOTS, and its LDS slot
+    // lane % SLOTS receives the source slot (lane % SLOTS) ^ swz(row).  Rows beyond the matrix re-read its last row
+    // (their outputs are not stored).
     const unsigned short *g_src[CFG::G_DMA], *x_src[CFG::X_DMA];
 #pragma unroll
     for (int j = 0; j < CFG::G_DMA; ++j) {
-        const int row = 8 * (CFG::G_DMA * wave + j) + (lane >> 3);
+        const int row = CFG::RPD * (CFG::G_DMA * wave + j) + lane / CFG::SLOTS;
         int o = o0 + row;
         if (o > cout_g - 1) o = cout_g - 1;
-        g_src[j] = Gg + (size_t)o * M + (((lane & 7) ^ ((row >> 1) & 7)) << 3);
+        g_src[j] = Gg + (size_t)o * M + (((lane & (CFG::SLOTS - 1)) ^ CFG::swz(row)) << 3);
     }
 #pragma unroll
     for (int j = 0; j < CFG::X_DMA; ++j) {
-        const int row = 8 * (CFG::X_DMA * wave + j) + (lane >> 3);
+        const int row = CFG::RPD * (CFG::X_DMA * wave + j) + lane / CFG::SLOTS;
         int c = c0 + row;
         if (c > cin_g - 1) c = cin_g - 1;
-        x_src[j] = Xg + (size_t)c * M + (((lane & 7) ^ ((row >> 1) & 7)) << 3);
+        x_src[j] = Xg + (size_t)c * M + (((lane & (CFG::SLOTS - 1)) ^ CFG::swz(row)) << 3);
     }
     auto issue = [&](int t) {
         const unsigned st = lds0 + (t % NS) * CFG::STAGE;
@@ -311,19 +326,19 @@ __global__ __launch_bounds__(CFG::THREADS) void wgrad_dma_kernel(
         for (int j = 0; j < CFG::X_DMA; ++j)
             gm_dma16(x_src[j] + (size_t)t * KC, st + CFG::G_BYTES + (CFG::X_DMA * wave + j) * 1024);
     };
-    // fragment read offsets: row * 128 + ((2 ks + half) ^ ((row >> 1) & 7)) * 16; the XOR is applied per k-step below
+    // fragment read offsets: row * ROWB + ((2 ks + half) ^ swz(row)) * 16; the XOR is applied per k-step below
     int goff[RT], gx[RT], xoff[CT], xx[CT];
 #pragma unroll
     for (int a = 0; a < RT; ++a) {
         const int row = wo * 32 * RT + a * 32 + l31;
-        goff[a] = row * 128;
-        gx[a] = (row >> 1) & 7;
+        goff[a] = row * CFG::ROWB;
+        gx[a] = CFG::swz(row);
     }
 #pragma unroll
     for (int b = 0; b < CT; ++b) {
         const int row = wc * 32 * CT + b * 32 + l31;
-        xoff[b] = CFG::G_BYTES + row * 128;
-        xx[b] = (row >> 1) & 7;
+        xoff[b] = CFG::G_BYTES + row * CFG::ROWB;
+        xx[b] = CFG::swz(row);
     }
     f32x16 acc[RT][CT];
 #pragma unroll
@@ -346,11 +361,11 @@ __global__ __launch_bounds__(CFG::THREADS) void wgrad_dma_kernel(
         unsigned char *const st = smem + (t % NS) * CFG::STAGE;
         if (PRO) {
             // X tile: TC rows x 8 slots; every thread the same number of 16-byte pieces
-            constexpr int PIECES = CFG::TC * 8 / CFG::THREADS;
+            constexpr int PIECES = CFG::TC * CFG::SLOTS / CFG::THREADS;
 #pragma unroll
             for (int j = 0; j < PIECES; ++j) {
                 const int p = tid + CFG::THREADS * j;
-                const float2 ss = reinterpret_cast<const float2 *>(s_tab)[p >> 3];
+                const float2 ss = reinterpret_cast<const float2 *>(s_tab)[p / CFG::SLOTS];
                 uint4 *cell = reinterpret_cast<uint4 *>(st + CFG::G_BYTES + p * 16);
                 uint4 v = *cell;
                 unsigned w[4] = {v.x, v.y, v.z, v.w};
@@ -399,47 +414,233 @@ __global__ __launch_bounds__(CFG::THREADS) void wgrad_dma_kernel(
         }
 }
 
+// ---- G through registers: twice the bytes in flight for the wide tiles -------------------------------------------------
+// Measured (tools/microbench/rowpiece_read_bench.hip, tools/wgrad_sweep.sh): the wide tiles are bound by the RATE of their
+// LDS-DMA -- 1.6x (256 x 256) to 3.2x (128 x 128) the unique bytes, the re-reads are L2 hits (PMC: FETCH_SIZE = unique
+// bytes) -- and that rate is bytes-in-flight / latency: with 64 KB chunks only one fits the LDS beside the one being
+// consumed.  The register file is the larger pool (512 KB per CU), so here the G tile takes the other road: every lane
+// requests the 16 bytes the DMA would have delivered to its LDS slot (same rows, same source-side swizzle) into VGPRs,
+// TWO chunks ahead, and writes them to one of two G stages when it has finished the chunk before; X stays on a 3-stage
+// DMA ring.  Per workgroup 2 x (G + X) chunks are in flight instead of 1, with the same single barrier per chunk.
+// vmcnt is counted by hand over both kinds (all issued through inline asm, in a fixed order: X DMA, then G loads).
+// The staging registers are v224-v239 (set 0) and v240-v255 (set 1), named in the asm text: the kernel is compiled with
+// amdgpu_num_vgpr(224), so the compiler never allocates them, and no C++ value stands for data that has been requested
+// but not waited for.  (With ordinary "v" operands -- tied or pinned -- the register allocator copied the destination
+// registers between the request and the s_waitcnt: v_mov of not-yet-loaded registers, seen in the .s.)
+template <int SET> __device__ __forceinline__ void wg_gload4(const void *p0, const void *p1, const void *p2, const void *p3) {
+    if constexpr (SET == 0)
+        asm volatile("global_load_dwordx4 v[224:227], %0, off\n\tglobal_load_dwordx4 v[228:231], %1, off\n\t"
+                     "global_load_dwordx4 v[232:235], %2, off\n\tglobal_load_dwordx4 v[236:239], %3, off"
+                     :: "v"(p0), "v"(p1), "v"(p2), "v"(p3)
+                     : "memory", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234",
+                       "v235", "v236", "v237", "v238", "v239");
+    else
+        asm volatile("global_load_dwordx4 v[240:243], %0, off\n\tglobal_load_dwordx4 v[244:247], %1, off\n\t"
+                     "global_load_dwordx4 v[248:251], %2, off\n\tglobal_load_dwordx4 v[252:255], %3, off"
+                     :: "v"(p0), "v"(p1), "v"(p2), "v"(p3)
+                     : "memory", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250",
+                       "v251", "v252", "v253", "v254", "v255");
+}
+// wait until at most N newer vector-memory operations are outstanding, then set SET -> LDS [addr, addr + 4 x 1024)
+template <int N, int SET> __device__ __forceinline__ void wg_stash4(unsigned addr) {
+    if constexpr (SET == 0)
+        asm volatile("s_waitcnt vmcnt(%1)\n\tds_write_b128 %0, v[224:227]\n\tds_write_b128 %0, v[228:231] offset:1024\n\t"
+                     "ds_write_b128 %0, v[232:235] offset:2048\n\tds_write_b128 %0, v[236:239] offset:3072"
+                     :: "v"(addr), "n"(N) : "memory");
+    else
+        asm volatile("s_waitcnt vmcnt(%1)\n\tds_write_b128 %0, v[240:243]\n\tds_write_b128 %0, v[244:247] offset:1024\n\t"
+                     "ds_write_b128 %0, v[248:251] offset:2048\n\tds_write_b128 %0, v[252:255] offset:3072"
+                     :: "v"(addr), "n"(N) : "memory");
+}
+
+template <typename CFG>
+__global__ __launch_bounds__(CFG::THREADS, CFG::NW == 4 ? 2 : 1) __attribute__((amdgpu_num_vgpr(224))) void wgrad_gr_kernel(
+    const unsigned short *__restrict__ G, const unsigned short *__restrict__ X, int64_t M, int cout_g, int cin_g,
+    int tiles_o, int tiles_c, int slices_view, int64_t cols_per_slice, int views, float *__restrict__ part, int nblocks) {
+    constexpr int NSX = 3, RT = CFG::RT, CT = CFG::CT, KC = CFG::KC, GD = CFG::G_DMA, XD = CFG::X_DMA;
+    static_assert(KC == 64 && GD == 4, "128-byte row pieces; four G vectors per lane and chunk");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];       // [3 x X tile][2 x G tile]
+    constexpr int G0 = NSX * CFG::X_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wo = wave / CFG::WM, wc = wave % CFG::WM;
+    const unsigned lds0 = (unsigned)(uintptr_t)(gm_lptr)smem;
+    const int ntiles = tiles_o * tiles_c;
+    const int logical = xcd_remap(blockIdx.x, nblocks);
+    const int slice = logical / ntiles, tile = logical - slice * ntiles, grp = blockIdx.z;
+    const int view = slice / slices_view, sl = slice - view * slices_view;
+    const int o0 = (tile / tiles_c) * CFG::TO, c0 = (tile % tiles_c) * CFG::TC;
+    const int64_t Mv = M / views;
+    const int64_t m_begin = (int64_t)view * Mv + (int64_t)sl * cols_per_slice;
+    int64_t m_len = Mv - (int64_t)sl * cols_per_slice;
+    if (m_len > cols_per_slice) m_len = cols_per_slice;
+    const int T = (int)(m_len / KC);
+    const unsigned short *Gg = G + (size_t)grp * cout_g * M + m_begin;
+    const unsigned short *Xg = X + (size_t)grp * cin_g * M + m_begin;
+
+    const unsigned short *g_src[GD], *x_src[XD];
+#pragma unroll
+    for (int j = 0; j < GD; ++j) {
+        const int row = CFG::RPD * (GD * wave + j) + lane / CFG::SLOTS;
+        int o = o0 + row;
+        if (o > cout_g - 1) o = cout_g - 1;
+        g_src[j] = Gg + (size_t)o * M + (((lane & (CFG::SLOTS - 1)) ^ CFG::swz(row)) << 3);
+    }
+#pragma unroll
+    for (int j = 0; j < XD; ++j) {
+        const int row = CFG::RPD * (XD * wave + j) + lane / CFG::SLOTS;
+        int c = c0 + row;
+        if (c > cin_g - 1) c = cin_g - 1;
+        x_src[j] = Xg + (size_t)c * M + (((lane & (CFG::SLOTS - 1)) ^ CFG::swz(row)) << 3);
+    }
+    auto issue = [&](auto PAR, int t) {                             // chunk t: X by DMA, G into register set PAR
+        const unsigned st = lds0 + (t % NSX) * CFG::X_BYTES;
+#pragma unroll
+        for (int j = 0; j < XD; ++j) gm_dma16(x_src[j] + (size_t)t * KC, st + (XD * wave + j) * 1024);
+        wg_gload4<decltype(PAR)::value>(g_src[0] + (size_t)t * KC, g_src[1] + (size_t)t * KC, g_src[2] + (size_t)t * KC,
+                                        g_src[3] + (size_t)t * KC);
+    };
+    auto stash = [&](auto PAR, int t, bool newer) {                 // G of chunk t: registers -> its LDS stage
+        // operations issued after chunk t's G loads: chunk t + 1's X DMA and G loads, if there is one
+        const unsigned addr = lds0 + G0 + (t & 1) * CFG::G_BYTES + GD * wave * 1024 + lane * 16;
+        if (newer) wg_stash4<XD + GD, decltype(PAR)::value>(addr);
+        else wg_stash4<0, decltype(PAR)::value>(addr);
+    };
+    int goff[RT], gx[RT], xoff[CT], xx[CT];
+#pragma unroll
+    for (int a = 0; a < RT; ++a) {
+        const int row = wo * 32 * RT + a * 32 + l31;
+        goff[a] = G0 + row * CFG::ROWB;
+        gx[a] = CFG::swz(row);
+    }
+#pragma unroll
+    for (int b = 0; b < CT; ++b) {
+        const int row = wc * 32 * CT + b * 32 + l31;
+        xoff[b] = row * CFG::ROWB;
+        xx[b] = CFG::swz(row);
+    }
+    f32x16 acc[RT][CT];
+#pragma unroll
+    for (int a = 0; a < RT; ++a)
+#pragma unroll
+        for (int b = 0; b < CT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    if (T > 0) issue(P0{}, 0);
+    if (T > 1) issue(P1{}, 1);
+    if (T > 0) stash(P0{}, 0, T > 1);
+    auto body = [&](auto PAR, int t) {                              // PAR = t & 1
+        using NXT = std::integral_constant<int, 1 - decltype(PAR)::value>;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this wave's stash of chunk t
+        __builtin_amdgcn_s_barrier();                               // chunk t visible; chunk t - 1's stages are free
+        if (t + 2 < T) issue(PAR, t + 2);                           // X -> stage (t + 2) % 3, G -> the set chunk t left
+        const unsigned char *const xs = smem + (t % NSX) * CFG::X_BYTES;
+        const unsigned char *const gs = smem + (t & 1) * CFG::G_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < KC / 16; ++ks) {
+            gm_bf16x8 av[RT], bv[CT];
+#pragma unroll
+            for (int a = 0; a < RT; ++a)
+                av[a] = *reinterpret_cast<const gm_bf16x8 *>(gs + goff[a] + (((2 * ks + half) ^ gx[a]) << 4));
+#pragma unroll
+            for (int b = 0; b < CT; ++b)
+                bv[b] = *reinterpret_cast<const gm_bf16x8 *>(xs + xoff[b] + (((2 * ks + half) ^ xx[b]) << 4));
+#pragma unroll
+            for (int a = 0; a < RT; ++a)
+#pragma unroll
+                for (int b = 0; b < CT; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[a], bv[b], acc[a][b], 0, 0, 0);
+        }
+        // chunk t + 1's G (requested one iteration ago) -> the G stage chunk t - 1 used; its X DMA is older, so done too
+        if (t + 1 < T) stash(NXT{}, t + 1, t + 2 < T);
+    };
+    for (int t = 0; t < T; t += 2) {
+        body(P0{}, t);
+        if (t + 1 < T) body(P1{}, t + 1);
+    }
+    float *pp = part + ((size_t)slice * gridDim.z + grp) * cout_g * cin_g;
+#pragma unroll
+    for (int a = 0; a < RT; ++a)
+#pragma unroll
+        for (int b = 0; b < CT; ++b) {
+            const int c = c0 + wc * 32 * CT + b * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = o0 + wo * 32 * RT + a * 32 + mfma_row(r, half);
+                if (o < cout_g && c < cin_g) pp[(size_t)o * cin_g + c] = acc[a][b][r];
+            }
+        }
+}
+
 struct WgDmaPlan {
-    int cfg;                      // 0 = T (64 x 64), 1 = S (128 x 128), 2 = L (256 x 256)
+    int cfg;                      // 0 = T (64 x 64), 1 = S (128 x 128), 2 = L (256 x 256), 3 = S32, 4 = M32 (256 x 128), 5 = L32
     int to, tc, tiles_o, tiles_c, slices_view, nslices;
     int64_t cols;
 };
+static int g_wg_force = -2;            // -2: not read yet; -1: heuristic; 0 ... 7: that configuration; 9: register-staged
 static int wg_force_cfg() {
-    static int v = -2;
-    if (v == -2) {
-        const char *e = getenv("GRAFP_WGRAD_TILE");            // "T" / "S" / "L" / "old": measurements
-        v = !e ? -1 : (e[0] == 'T' ? 0 : e[0] == 'S' ? 1 : e[0] == 'L' ? 2 : 3);
+    if (g_wg_force == -2) {
+        // GRAFP_WGRAD_TILE = T / S / L / s / m / l / G / H / old: measurements (tools/wgrad_sweep.sh)
+        const char *e = getenv("GRAFP_WGRAD_TILE");
+        g_wg_force = !e ? -1 : (e[0] == 'T' ? 0 : e[0] == 'S' ? 1 : e[0] == 'L' ? 2 : e[0] == 's' ? 3 : e[0] == 'm' ? 4 :
+                                e[0] == 'l' ? 5 : e[0] == 'G' ? 6 : e[0] == 'H' ? 7 : 9);
     }
-    return v;
+    return g_wg_force;
 }
 static bool wgrad_dma_ok(int cout_g, int cin_g, int64_t M, int views) {
-    return wg_force_cfg() != 3 && cout_g % 32 == 0 && cin_g % 32 == 0 && views >= 1 && M % views == 0 &&
+    return wg_force_cfg() != 9 && cout_g % 32 == 0 && cin_g % 32 == 0 && views >= 1 && M % views == 0 &&
            (M / views) % 64 == 0;
 }
 static WgDmaPlan wgrad_dma_plan(int cout_g, int cin_g, int groups, int64_t M, int views, bool pro) {
     WgDmaPlan p;
     const int64_t outs = (int64_t)cout_g * cin_g;
-    // measured (tools/gemm_bench.py --wgrad at 512 and 2048 clip-views): while both operands fit the 256 MB Infinity
-    // Cache the 64 x 64 tile wins up to 2^19 outputs (many small workgroups, a few MB of partial sums; its operand
-    // re-reads are cache hits at ~14 TB/s) and the 128 x 128 tile beyond; once the operands are larger than that
-    // (1024 pairs on one GPU) the re-reads of the small tile go to HBM and the 128 tile wins for every dense layer with
-    // >= 128 rows on both sides, and for the "few outputs, wide operand" layers (64 x 128, 64 x 256 of stage 0).  The
-    // grouped convolutions (32 ... 256 rows per group) stay on the small tile up to stage 2.  With the in-LDS
-    // normalisation the 128 tile from 256 operand rows.  The 256 x 256 tile (L) loses everywhere to its partial sums.
-    const bool big = (double)(cout_g + cin_g) * groups * (double)M * 2.0 > 500e6;
-    const int lo = cout_g < cin_g ? cout_g : cin_g;
+    // Measured (tools/wgrad_sweep.sh: every configuration on every layer shape at 256 / 512 / 1024 / 2048 clip-views;
+    // profiles/r02_wgrad_sweep.txt).  Three regimes by the bytes of the two operands:
+    //  * they fit the 256 MB Infinity Cache with room to spare: the 64 x 64 tile (many small workgroups, a few MB of
+    //    partial sums, its operand re-reads are cache hits at ~14 TB/s), 128 x 128 from 2^19 outputs;
+    //  * 200 ... 750 MB: the wide layers (FFN and fc2 of stages 2-3; from 400 MB everything with >= 128 x 256 rows) on the
+    //    256 x 256 tile with 64-byte row pieces (L32: three 32 KB chunks in flight, 1.6x instead of 3.2x re-reads);
+    //  * beyond (1024 pairs on one GPU: every re-read of a small tile goes to HBM, and 64-byte pieces at 1-4 MB row
+    //    stride read at 2.5-3.8 TB/s -- rowpiece_read_bench): G through registers -- 256 x 256 (LG) for the wide layers
+    //    (-28 % on the stage-2 FFN), 128 x 128 (SG) for everything else with >= 128 rows on one side.
+    // The grouped convolutions (32 ... 128 rows per group) stay on the small tile.  With the in-LDS normalisation (pro)
+    // only the three DMA tiles of the first round.
+    const double opbytes = (double)(cout_g + cin_g) * groups * (double)M * 2.0;
+    const bool big = opbytes > 500e6;
+    const int lo = cout_g < cin_g ? cout_g : cin_g, hi = cout_g < cin_g ? cin_g : cout_g;
     p.cfg = 0;
     if (lo >= 128 && (outs >= (1 << 19) || (big && groups == 1))) p.cfg = 1;
     if (big && groups == 1 && cout_g >= 64 && cin_g >= 2 * cout_g) p.cfg = 1;
     if (pro && cin_g >= 256 && cout_g >= 128) p.cfg = 1;
-    if (wg_force_cfg() >= 0 && wg_force_cfg() <= 2) p.cfg = wg_force_cfg();
-    p.to = p.tc = p.cfg == 2 ? 256 : (p.cfg == 1 ? 128 : 64);
+    static const bool no_wide = getenv("GRAFP_WGRAD_NO_WIDE") != nullptr;      // A/B: the three DMA tiles only
+    if (!pro && !no_wide) {
+        if (opbytes >= 750e6) {
+            if (groups == 1 && (lo >= 256 || (lo >= 128 && hi >= 512))) p.cfg = 7;
+            else if (groups == 1 ? hi >= 128 : cout_g >= 256) p.cfg = 6;
+        } else if (groups == 1) {
+            if ((lo >= 256 && hi >= 1024 && opbytes >= 200e6) || (lo >= 128 && hi >= 256 && opbytes >= 400e6) ||
+                (lo >= 512 && opbytes >= 250e6))
+                p.cfg = 5;
+        } else if (cout_g >= 256 && opbytes >= 400e6) {
+            p.cfg = 5;
+        }
+    }
+    if (wg_force_cfg() >= 0 && wg_force_cfg() <= 7 && !(pro && wg_force_cfg() >= 6)) p.cfg = wg_force_cfg();
+    static const int tile_o[8] = {64, 128, 256, 128, 256, 256, 128, 256}, tile_c[8] = {64, 128, 256, 128, 128, 256, 128, 256};
+    p.to = tile_o[p.cfg];
+    p.tc = tile_c[p.cfg];
     p.tiles_o = (cout_g + p.to - 1) / p.to;
     p.tiles_c = (cin_g + p.tc - 1) / p.tc;
     const int64_t tiles = (int64_t)p.tiles_o * p.tiles_c * groups;
     const int64_t Mv = M / views;
     // two rounds of resident workgroups (L: one per CU, T/S: two), at least 8 chunks per slice
-    const int64_t target = p.cfg == 2 ? 512 : 1024;
+    static const int64_t targets[8] = {1024, 1024, 512, 1024, 512, 256, 1024, 512};
+    int64_t target = targets[p.cfg];
+    if (const char *e = getenv("GRAFP_WGRAD_TARGET")) target = atoi(e);
     int64_t sv = (target + tiles * views - 1) / (tiles * views);
     const int64_t max_sv = (Mv / 64 + 7) / 8;
     if (sv > max_sv) sv = max_sv;
@@ -504,6 +705,14 @@ static WgradPlan wgrad_plan(int cout_g, int cin_g, int groups, int64_t M) {
 
 }  // namespace grafp
 
+// test hook: force a tile configuration of the LDS-DMA weight gradient (0 = T ... 7 = LG, 9 = the register-staged
+// kernels of round 1, -1 = the measured heuristic); returns the previous setting
+extern "C" int grafp_debug_wgrad_tile(int cfg) {
+    const int prev = grafp::wg_force_cfg();
+    grafp::g_wg_force = (cfg >= 0 && cfg <= 7) || cfg == 9 ? cfg : -1;
+    return prev;
+}
+
 extern "C" size_t grafp_conv1x1_wgrad_pro_workspace(int Cout, int Cin, int groups, int64_t M, int views) {
     using namespace grafp;
     if (Cout <= 0 || Cin <= 0 || groups <= 0 || M <= 0 || Cout % groups || Cin % groups) return 0;
@@ -552,12 +761,38 @@ extern "C" int grafp_conv1x1_wgrad_pro_bf16(const void *grad_out, const void *x,
                            p.tiles_c, p.slices_view, p.cols, views, (const float2 *)pro_tab, pro_act, pro_slope,         \
                            (float *)ws, nblocks);                                                                        \
     } while (0)
+#define WG_LAUNCH_GR(CFG)                                                                                                \
+    do {                                                                                                                 \
+        const size_t lds = (size_t)3 * CFG::X_BYTES + 2 * CFG::G_BYTES;                                                  \
+        (void)hipFuncSetAttribute((const void *)wgrad_gr_kernel<CFG>, hipFuncAttributeMaxDynamicSharedMemorySize,        \
+                                  (int)lds);                                                                             \
+        hipLaunchKernelGGL((wgrad_gr_kernel<CFG>), grid, dim3(CFG::THREADS), lds, s, (const unsigned short *)grad_out,   \
+                           (const unsigned short *)x, M, cout_g, cin_g, p.tiles_o, p.tiles_c, p.slices_view, p.cols,     \
+                           views, (float *)ws, nblocks);                                                                 \
+    } while (0)
         if (pro_tab) {
-            if (p.cfg == 2) WG_LAUNCH(WgL, true); else if (p.cfg == 1) WG_LAUNCH(WgS, true); else WG_LAUNCH(WgT, true);
+            switch (p.cfg) {
+            case 0: WG_LAUNCH(WgT, true); break;
+            case 1: WG_LAUNCH(WgS, true); break;
+            case 2: WG_LAUNCH(WgL, true); break;
+            case 3: WG_LAUNCH(WgS32, true); break;
+            case 4: WG_LAUNCH(WgM32, true); break;
+            default: WG_LAUNCH(WgL32, true); break;
+            }
         } else {
-            if (p.cfg == 2) WG_LAUNCH(WgL, false); else if (p.cfg == 1) WG_LAUNCH(WgS, false); else WG_LAUNCH(WgT, false);
+            switch (p.cfg) {
+            case 6: WG_LAUNCH_GR(WgSG); break;
+            case 7: WG_LAUNCH_GR(WgLG); break;
+            case 0: WG_LAUNCH(WgT, false); break;
+            case 1: WG_LAUNCH(WgS, false); break;
+            case 2: WG_LAUNCH(WgL, false); break;
+            case 3: WG_LAUNCH(WgS32, false); break;
+            case 4: WG_LAUNCH(WgM32, false); break;
+            default: WG_LAUNCH(WgL32, false); break;
+            }
         }
 #undef WG_LAUNCH
+#undef WG_LAUNCH_GR
         GRAFP_CHECK_LAUNCH("wgrad_dma_kernel");
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, s, (const float *)ws,
                            p.nslices, n, dweight);

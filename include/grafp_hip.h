@@ -201,6 +201,7 @@ int grafp_ivfpq_scan_f32(const float *q, int nq, int d, const float *centroids, 
  * waiting for its row-mates and recomputes their partial sums itself (returns the previous value; < 0 only reads it;
  * 0 = never wait), and a kernel that merely occupies `blocks` x `threads` CU slots for `clocks` shader cycles. */
 int grafp_bn_debug_spin_limit(int polls);
+int grafp_debug_wgrad_tile(int cfg);   /* force a tile configuration of grafp_conv1x1_wgrad_bf16 (0..7, 9; -1 = heuristic); returns the previous one */
 int grafp_debug_occupy(int blocks, int threads, int64_t clocks, grafp_stream_t stream);
 
 /* ---- K9 forward / data gradient: the 1x1 convolution itself as a streaming bf16 GEMM, BatchNorm folded in ----

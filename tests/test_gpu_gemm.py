@@ -157,3 +157,25 @@ def test_wgrad_dma(cout, cin, groups, M, views, pro):
     assert float((dw.double() - want).abs().max()) <= tol
     # deterministic (fixed-order reduction, no atomics)
     assert torch.equal(dw, ops.conv1x1_wgrad(g, x, cout, cin, groups, M, views, tab, ops.ACT_RELU if pro else ops.ACT_NONE))
+
+
+# T, S, L (128-byte pieces), S32, M32, L32 (64-byte pieces), SG, LG (G through registers)
+@pytest.mark.parametrize("tile", range(8))
+@pytest.mark.parametrize("cout,cin,groups,M,views", [(256, 64, 1, 16384, 2), (1024, 256, 1, 2048, 2), (512, 1024, 4, 1024, 2),
+                                                     (96, 160, 1, 1280, 1), (256, 512, 1, 64, 1), (320, 256, 1, 4160, 1)])
+def test_wgrad_every_tile_configuration(tile, cout, cin, groups, M, views):
+    """The heuristic picks the wide configurations only at sizes a test cannot afford for every shape: force each one
+    (grafp_debug_wgrad_tile) on small cases -- ragged rows, one chunk per slice, odd chunk counts, groups."""
+    from grafp_amd import ops
+    from grafp_amd._lib import lib
+    g, x = _rand((cout, M), 31), _rand((cin, M), 32, 1.5, 0.5)
+    prev = lib.grafp_debug_wgrad_tile(tile)
+    try:
+        dw = ops.conv1x1_wgrad(g, x, cout, cin, groups, M, views)
+        again = ops.conv1x1_wgrad(g, x, cout, cin, groups, M, views)
+    finally:
+        lib.grafp_debug_wgrad_tile(prev)
+    og, cg = cout // groups, cin // groups
+    want = torch.cat([g[i * og:(i + 1) * og].double() @ x[i * cg:(i + 1) * cg].double().t() for i in range(groups)], dim=0)
+    assert float((dw.double() - want).abs().max()) <= 2e-3 * float(want.abs().max())
+    assert torch.equal(dw, again)

@@ -30,13 +30,15 @@ def wgrad(args, dev):
     depth, tot = (2, 2, 6, 2), 0.0
     for stage, (C, N) in enumerate(((64, 1024), (128, 512), (256, 256), (512, 128))):
         M = args.clips * N
+        if str(stage) not in args.stages:
+            continue
         for name, co, ci, g in (("fc1", C, C, 1), ("gconv g4", 2 * C, 2 * C, 4), ("gfc2", C, 2 * C, 1),
                                 ("ffn1", 4 * C, C, 1), ("ffn2", C, 4 * C, 1)):
             G = torch.randn(co, M, device=dev).to(torch.bfloat16)
             X = torch.randn(ci, M, device=dev).to(torch.bfloat16)
             tab = torch.rand(ci, args.views, 2, device=dev)
             t0 = timeit(lambda: ops.conv1x1_wgrad(G, X, co, ci, g, M, args.views))
-            t1 = timeit(lambda: ops.conv1x1_wgrad(G, X, co, ci, g, M, args.views, tab, 1))
+            t1 = 0.0 if args.no_pro else timeit(lambda: ops.conv1x1_wgrad(G, X, co, ci, g, M, args.views, tab, 1))
             by, fl = (co + ci) * M * 2.0, 2.0 * co * (ci // g) * M
             tot += t0 * depth[stage]
             print(f"s{stage} {name:9s} {co:5d} x {ci:5d} g={g} M={M:7d}  wgrad {t0:7.1f} us (+pro {t1:7.1f}) | "
@@ -49,6 +51,8 @@ def main():
     ap.add_argument("--views", type=int, default=2)
     ap.add_argument("--clips", type=int, default=512)
     ap.add_argument("--wgrad", action="store_true", help="time the weight-gradient kernel instead")
+    ap.add_argument("--stages", default="0123", help="--wgrad: encoder stages to run")
+    ap.add_argument("--no-pro", action="store_true", help="--wgrad: skip the normalise-on-load variant")
     args = ap.parse_args()
     dev = "cuda:0"
     if args.wgrad:
