@@ -13,6 +13,8 @@
 // gradient is exactly zero -- so it is folded in here instead of costing an elementwise launch + a reduction.
 #include <math.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace grafp {
@@ -443,6 +445,13 @@ __device__ __forceinline__ void bn1_rearm(int old, int S, int *counter, unsigned
     }
 }
 
+// The packed operands are kept across the rendezvous and unpacked AGAIN afterwards.  Without this fence the compiler
+// keeps the unpacked / derived floats of the first phase alive instead (common subexpressions): 118 VGPRs for 4 + 4
+// vectors, 188 for 8 + 8 -- two to four workgroups per CU, and every one of them that waits for its row-mates is a
+// slot that moves no data.  The empty asm makes the registers opaque at no cost.
+__device__ __forceinline__ void bn_opaque(float4 &v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+__device__ __forceinline__ void bn_opaque(uint4 &v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+
 template <typename T, bool RES>
 __global__ __launch_bounds__(BN1_THREADS) void bn_fwd1_kernel(const T *__restrict__ x, int64_t M, int64_t Mg, int Sg,
                                                              int G, const float *__restrict__ pre_bias,
@@ -530,6 +539,8 @@ __global__ __launch_bounds__(BN1_THREADS) void bn_fwd1_kernel(const T *__restric
         }
         __syncthreads();
     }
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) bn_opaque(raw[it]);
     int checkout = 0;
     if (tid == 0) checkout = bn1_checkout(counter);
     a = 0.0f, q = 0.0f;
@@ -666,6 +677,11 @@ __global__ __launch_bounds__(BN1_THREADS) void bn_bwd1_kernel(const T *__restric
             if (tid == 0) sp[i] = r2;
         }
         __syncthreads();
+    }
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        bn_opaque(rx[it]);
+        bn_opaque(rd[it]);
     }
     int checkout = 0;
     if (tid == 0) checkout = bn1_checkout(counter);
@@ -848,11 +864,13 @@ extern "C" int grafp_bn_bwd_1pass(const void *x, const void *dz, int dtype, int 
     if (sync && training) {
         const bool f32 = dtype == GRAFP_F32;
         const bool ok = f32 ? bn_vec_ok<float>(x, dz, dx, nullptr, Mg) : bn_vec_ok<unsigned short>(x, dz, dx, nullptr, Mg);
-        // long rows (1024 pairs on one GPU: 128 chunks per view) rendezvous over fewer, larger chunks: 8 vectors per
-        // thread and operand instead of 4 (measured at 2048 clip-views: 0.43 -> see DESIGN of the HBM peak)
+        // from 16 chunks per row the rendezvous runs over fewer, larger chunks: 8 vectors per thread and operand instead
+        // of 4 (tools/bn_bench.py, threshold swept 0 ... 128: 16 is best at 256, 512 and 2048 clip-views; with the
+        // operands fenced across the wait -- bn_opaque -- this variant needs 122 VGPRs, 4 workgroups per CU)
         int items = BN1_ITEMS_BWD;
         int Sg = ok ? bn1_plan(Mg, G, f32 ? 4 : 8, items) : 0;
-        if (ok && !f32 && (Sg == 0 || Sg * G > 128) && getenv("GRAFP_BN_BWD_ITEMS4") == nullptr) {
+        static const int items8_from = getenv("GRAFP_BN_BWD_ITEMS8_FROM") ? atoi(getenv("GRAFP_BN_BWD_ITEMS8_FROM")) : 16;
+        if (ok && !f32 && (Sg == 0 || Sg * G > items8_from) && getenv("GRAFP_BN_BWD_ITEMS4") == nullptr) {
             items = 2 * BN1_ITEMS_BWD;
             Sg = bn1_plan(Mg, G, 8, items);
         }
