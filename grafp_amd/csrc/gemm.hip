@@ -35,6 +35,9 @@ constexpr int GM_STORES_PER_RT = 4;
 #ifndef GM_NT
 #define GM_NT 1
 #endif
+#ifndef GM_ABLATE            // measurement builds (tools/gemm_ablate.sh): 1 = no DMA in the main loop, 2 = no epilogue,
+#define GM_ABLATE 0          // 4 = no MFMA; sums of those.  Results are wrong for every value but 0.
+#endif
 constexpr bool NT_STORE = GM_NT != 0;   // streaming (nt) stores of Y            // 16-byte store instructions per wave and 32-row output tile
 
 // Tile configurations: WR x WM waves, each wave RT x 2 MFMA tiles (32 RT rows x 64 columns).
@@ -199,13 +202,15 @@ __global__ __launch_bounds__(CFG::THREADS) void conv1x1_gemm_kernel(
         for (int b = 0; b < RT; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
-    float sS[RT], sQ[RT], sShift[RT];
+    gm_f32x2 sS[RT], sQ[RT];                                 // even / odd elements: packed f32 arithmetic
+    float sShift[RT];
     // output tiles of 32 rows this wave really owns (R is a multiple of 32)
     bool rt_valid[RT];
     int stores_per_epi = 0;
 #pragma unroll
     for (int ri = 0; ri < RT; ++ri) {
-        sS[ri] = sQ[ri] = sShift[ri] = 0.0f;
+        sS[ri] = sQ[ri] = gm_f32x2{0.0f, 0.0f};
+        sShift[ri] = 0.0f;
         rt_valid[ri] = r0 + wr * 32 * RT + ri * 32 < Rg;
         stores_per_epi += rt_valid[ri] ? GM_STORES_PER_RT : 0;
     }
@@ -240,7 +245,7 @@ __global__ __launch_bounds__(CFG::THREADS) void conv1x1_gemm_kernel(
             __builtin_amdgcn_s_barrier();
         }
         int issued_now = 0;
-        if (t + D < T) {
+        if (t + D < T && !(GM_ABLATE & 1)) {
             issue(t + D);
             issued_now = GM_DMA_PER_CHUNK;
         }
@@ -285,11 +290,16 @@ __global__ __launch_bounds__(CFG::THREADS) void conv1x1_gemm_kernel(
 #pragma unroll
             for (int ri = 0; ri < RT; ++ri)
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
-                    acc[mi][ri] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[mi], wb[ri], acc[mi][ri], 0, 0, 0);
+                for (int mi = 0; mi < 2; ++mi) {
+                    if (GM_ABLATE & 4) acc[mi][ri][0] += __builtin_bit_cast(float, xa[mi][0] + wb[ri][0]);
+                    else acc[mi][ri] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[mi], wb[ri], acc[mi][ri], 0, 0, 0);
+                }
         }
         int stored_now = 0;
-        if (++ch == nch) {
+        if ((GM_ABLATE & 2) && ch + 1 == nch) {
+            ch = 0;
+            ++tile;
+        } else if (++ch == nch) {
             ch = 0;
             // ---- epilogue of one output tile: round, statistics, transpose through LDS, 16-byte row stores ----
             const int64_t mcol = col0 + (int64_t)tile * TN + wm * 64;
@@ -308,14 +318,16 @@ __global__ __launch_bounds__(CFG::THREADS) void conv1x1_gemm_kernel(
                             const unsigned p0 = gm_pack_bf16(acc[mi][ri][4 * rg + 0], acc[mi][ri][4 * rg + 1]);
                             const unsigned p1 = gm_pack_bf16(acc[mi][ri][4 * rg + 2], acc[mi][ri][4 * rg + 3]);
                             if (STATS) {
-                                const float v[4] = {__uint_as_float(p0 << 16), __uint_as_float(p0 & 0xffff0000u),
-                                                    __uint_as_float(p1 << 16), __uint_as_float(p1 & 0xffff0000u)};
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) {
-                                    const float d = v[e] - sShift[ri];
-                                    sS[ri] += d;
-                                    sQ[ri] = __builtin_fmaf(d, d, sQ[ri]);
-                                }
+                                // two elements per VALU instruction (v_pk_add_f32 / v_pk_fma_f32): the statistics
+                                // are VALU work the MFMAs wait for -- 4 instructions per output element cost as
+                                // much as the products themselves at K = 128 (tools/gemm_ablate.py)
+                                const gm_f32x2 sh = {sShift[ri], sShift[ri]};
+                                const gm_f32x2 da = gm_f32x2{__uint_as_float(p0 << 16), __uint_as_float(p0 & 0xffff0000u)} - sh;
+                                const gm_f32x2 db = gm_f32x2{__uint_as_float(p1 << 16), __uint_as_float(p1 & 0xffff0000u)} - sh;
+                                sS[ri] += da;
+                                sQ[ri] = __builtin_elementwise_fma(da, da, sQ[ri]);
+                                sS[ri] += db;
+                                sQ[ri] = __builtin_elementwise_fma(db, db, sQ[ri]);
                             }
                             // m = mi*32 + 8 rg + 4 half + (0..3): 16-byte piece mi*4 + rg, 8-byte half `half`
                             const int p16 = (mi * 4 + rg) ^ (l31 & 7);
@@ -346,11 +358,22 @@ __global__ __launch_bounds__(CFG::THREADS) void conv1x1_gemm_kernel(
         for (int j = D; j > 0; --j) st_hist[j] = st_hist[j - 1];
         st_hist[0] = stored_now;
     }
+    if (GM_ABLATE) {                                          // keep the arithmetic of a measurement build alive
+        float sink = 0.0f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < RT; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sink += acc[a][b][r];
+        if (sink == 12345.678f) Y[0] = 1;
+    }
     if (STATS) {
         // per row: this wave's (sum, sum of squares, shift) over its 64-column share of every tile of the range
 #pragma unroll
         for (int ri = 0; ri < RT; ++ri) {
-            const float s = sS[ri] + __shfl_xor(sS[ri], 32), q = sQ[ri] + __shfl_xor(sQ[ri], 32);
+            const float s1 = sS[ri].x + sS[ri].y, q1 = sQ[ri].x + sQ[ri].y;
+            const float s = s1 + __shfl_xor(s1, 32), q = q1 + __shfl_xor(q1, 32);
             const int r = r0 + wr * 32 * RT + ri * 32 + l31;
             if (half == 0 && rt_valid[ri]) {
                 float *pp = part + ((((size_t)grp * Rg + r) * views + view) * P + (rloc * CFG::WM + wm)) * 3;
