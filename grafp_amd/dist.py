@@ -119,6 +119,7 @@ class GradSync:
         self._size = [len(m) for m in self._members]
         self._left, self._handles, self._fired = list(self._size), [], [False] * len(self.bounds)
         self._hooks = []
+        self.paused = False            # Trainer.step_graph: backward is being captured, the buckets are reduced afterwards
         if overlap and self.world > 1:
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
@@ -166,10 +167,31 @@ class GradSync:
         self._fired[b] = True
 
     def _on_grad(self, p):
+        if self.paused:
+            return
         b = self._bucket_of[id(p)]
         self._left[b] -= 1
         if self._left[b] == 0 and not self._fired[b]:
             self._launch(b)
+
+    def pack_all(self):
+        """Every bucket's gradients -> the flat buffer (a few multi-tensor copies, no collective): the tail of a CAPTURED
+        backward pass (Trainer.step_graph); reduce_all() then runs outside the graph."""
+        for b in range(len(self.bounds)):
+            self._pack(b)
+
+    def reduce_all(self):
+        """All-reduce (SUM) of the packed flat buffer, bucket by bucket, and wait; .grad of every parameter becomes its
+        view of the reduced buffer.  No autograd involvement: the eager piece between two replayed graphs."""
+        if self.flat is None:
+            return
+        if self.world > 1:
+            hs = [dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                  for lo, hi in self.bounds]
+            for h in hs:
+                h.wait()
+        for p in self.params:
+            p.grad = self._view[id(p)]
 
     def finish(self):
         """Call after backward(): launches whatever has not fired, waits for all buckets, and points every .grad at

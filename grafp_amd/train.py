@@ -61,13 +61,32 @@ class Trainer:
         self.opt.step()
         return loss.detach()
 
+    def _snapshot(self):
+        with torch.no_grad():
+            keep = [t.detach().clone() for t in list(self.model.parameters()) + list(self.model.buffers())]
+            opt_keep = {p: {k: v.detach().clone() for k, v in st.items() if torch.is_tensor(v)}
+                        for p, st in self.opt.state.items()}
+        return keep, opt_keep
+
+    def _restore(self, keep, opt_keep):
+        with torch.no_grad():
+            for t, v in zip(list(self.model.parameters()) + list(self.model.buffers()), keep):
+                t.copy_(v)
+            for p, st in self.opt.state.items():     # Adam moments and step counters: as before the warm-up
+                for k, v in st.items():
+                    if torch.is_tensor(v):
+                        v.copy_(opt_keep[p][k]) if p in opt_keep else v.zero_()
+
     def step_graph(self, x_i, x_j):
-        """Same step, replayed from a HIP graph (single process only: the collectives of the data-parallel path are
-        not captured).  The first call runs three eager steps on a side stream (allocator and library warm-up, as
-        torch.cuda.graphs asks), records the fourth and replays it; later calls copy the batch into the static input buffers and
-        replay ~700 launches as one graph launch.  Shapes must not change between calls."""
-        if self.world > 1:
-            raise RuntimeError("step_graph: single-process only (use step() under data parallelism)")
+        """Same step, replayed from HIP graphs.  The first call runs three eager steps on a side stream (allocator and
+        library warm-up, as torch.cuda.graphs asks), records the fourth and replays it; later calls copy the batch
+        into the static input buffers and replay.  Shapes must not change between calls.
+          * one process: ONE graph (augment, forward, loss, backward, Adam), ~700 launches as one graph launch;
+          * data parallel: THREE graphs with the two collectives between them, eager, exactly where step() has them --
+            [augment + forward] -> all-gather of (z_i, z_j) -> [global-negative loss + backward + pack of the gradient
+            buckets] -> bucket all-reduces -> [Adam].  The collectives are not captured (RCCL kernels inside a graph
+            are untested on this stack), so the all-reduce no longer overlaps backward; at 128 pairs per GPU the launch
+            gaps it removes are worth more than that overlap (~0.9 ms of xGMI time)."""
         if self._graph is None:
             if getattr(self.augment, "seed", None) is not None:
                 raise RuntimeError("step_graph: a private augmentation generator (aug_seed) is eager-only -- its draws "
@@ -76,35 +95,83 @@ class Trainer:
             # the warm-up steps (allocator / library warm-up, as torch.cuda.graphs asks) and the capture itself must
             # not count as training: weights, BatchNorm statistics and optimizer state are put back afterwards, so the
             # first call is ONE step like every later one
-            with torch.no_grad():
-                keep = [t.detach().clone() for t in list(self.model.parameters()) + list(self.model.buffers())]
-                opt_keep = {p: {k: v.detach().clone() for k, v in st.items() if torch.is_tensor(v)}
-                            for p, st in self.opt.state.items()}
+            keep, opt_keep = self._snapshot()
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 for _ in range(3):
                     self.step(sx_i, sx_j)
             torch.cuda.current_stream().wait_stream(side)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                loss = self.step(sx_i, sx_j)
-            with torch.no_grad():
-                for t, v in zip(list(self.model.parameters()) + list(self.model.buffers()), keep):
-                    t.copy_(v)
-                for p, st in self.opt.state.items():     # Adam moments and step counters: as before the warm-up
-                    for k, v in st.items():
-                        if torch.is_tensor(v):
-                            v.copy_(opt_keep[p][k]) if p in opt_keep else v.zero_()
-            self._graph = (graph, sx_i, sx_j, loss)
-            graph.replay()                     # capture only records: this runs the step on the batch
-            return loss.clone()
-        graph, sx_i, sx_j, loss = self._graph
+            if self.world == 1:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    loss = self.step(sx_i, sx_j)
+                self._graph = ("single", graph, sx_i, sx_j, loss)
+            else:
+                self._graph = self._capture_data_parallel(sx_i, sx_j)
+            self._restore(keep, opt_keep)
+            return self._replay()                # capture only records: this runs the step on the batch
+        sx_i, sx_j = self._graph[2], self._graph[3]
         if sx_i.shape != x_i.shape or sx_j.shape != x_j.shape:
             raise ValueError("step_graph: batch shape changed since capture")
         sx_i.copy_(x_i)
         sx_j.copy_(x_j)
-        graph.replay()
+        return self._replay()
+
+    def _capture_data_parallel(self, sx_i, sx_j):
+        import torch.distributed as tdist
+        from . import ops
+        R, rank = self.world, gdist.rank_of(self.group)
+        self.model.train()
+        self.sync.zero()
+        self.sync.paused = True                      # no collective from the autograd hooks while backward is recorded
+        try:
+            g_fwd = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_fwd):
+                with torch.no_grad():
+                    X_i, X_j = self.augment(sx_i, sx_j)
+                with self._autocast():
+                    _, _, z_i, z_j = self.model(X_i, X_j)
+                mine = torch.stack((z_i.detach().float(), z_j.detach().float()), dim=0).contiguous()   # (2, B_loc, D)
+            gathered = torch.empty((R * 2,) + tuple(mine.shape[1:]), dtype=mine.dtype, device=mine.device)
+            tdist.all_gather_into_tensor(gathered, mine, group=self.group)
+            g_bwd = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_bwd, pool=g_fwd.pool()):
+                both = gathered.reshape(R, 2, *mine.shape[1:]).permute(1, 0, 2, 3)
+                zi_all = both[0].reshape(-1, mine.shape[2]).contiguous()
+                zj_all = both[1].reshape(-1, mine.shape[2]).contiguous()
+                loss = ops.ntxent(z_i, z_j, self.cfg["tau"], zi_all, zj_all, rank * z_i.shape[0])
+                loss.backward()
+                self.sync.pack_all()
+                loss = loss.detach()
+            self.sync.reduce_all()
+            g_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_opt, pool=g_fwd.pool()):
+                self.opt.step()
+        finally:
+            self.sync.paused = False
+        return ("dp", (g_fwd, g_bwd, g_opt), sx_i, sx_j, loss, mine, gathered)
+
+    def _replay(self):
+        if self._graph[0] == "single":
+            self._graph[1].replay()
+            return self._graph[4].clone()
+        import torch.distributed as tdist
+        (g_fwd, g_bwd, g_opt), loss, mine, gathered = self._graph[1], self._graph[4], self._graph[5], self._graph[6]
+        # RCCL collectives are stream-ordered behind the replayed graph.  A host-staged backend (gloo: the two-ranks-on-
+        # one-GPU tests) synchronises with the stream from its own thread, and doing that while a ~700-node graph
+        # launch is still being enqueued costs SECONDS per step on this stack (measured: 1-11 s against 47 ms with the
+        # explicit synchronize below) -- so for those backends the stream is drained first.
+        host_staged = tdist.get_backend(self.group) != "nccl"
+        g_fwd.replay()
+        if host_staged:
+            torch.cuda.current_stream().synchronize()
+        tdist.all_gather_into_tensor(gathered, mine, group=self.group)
+        g_bwd.replay()
+        if host_staged:
+            torch.cuda.current_stream().synchronize()
+        self.sync.reduce_all()
+        g_opt.replay()
         return loss.clone()
 
     def checkpoint(self, epoch, loss_log, hit_rate_log, hit_rates=None):

@@ -13,8 +13,56 @@ from grafp_amd.train import Trainer, build_model, synthetic_batch      # noqa: E
 from grafp_amd.util import load_config                                 # noqa: E402
 
 
+def graph_mode(out, B):
+    """Trainer.step_graph under data parallelism (three graphs, eager collectives between) against Trainer.step from
+    the same weights and optimizer state, on this rank's shard: losses and parameter updates."""
+    rank, world, device = gdist.init_from_env()
+    cfg = load_config()
+    cfg["bsz_train"] = B
+    torch.manual_seed(1234)
+    model = build_model(cfg, device=device)
+    tr = Trainer(cfg, model, device, amp_dtype=torch.bfloat16)
+    per = B // world
+    sl = slice(rank * per, (rank + 1) * per)
+    x_i, x_j = synthetic_batch(B, 7, device)
+    tr.step_graph(x_i[sl], x_j[sl])                                # warm-up, capture, first replay
+
+    def snapshot():
+        return ([p.detach().clone() for p in model.parameters()], [b.detach().clone() for b in model.buffers()],
+                [{k: v.detach().clone() for k, v in st.items() if torch.is_tensor(v)} for st in tr.opt.state.values()])
+
+    def restore(snap):
+        with torch.no_grad():
+            for p, v in zip(model.parameters(), snap[0]):
+                p.copy_(v)
+            for b, v in zip(model.buffers(), snap[1]):
+                b.copy_(v)
+            for st, sv in zip(tr.opt.state.values(), snap[2]):
+                for k, v in sv.items():
+                    st[k].copy_(v)
+
+    res = []
+    for seed in (51, 52):
+        y_i, y_j = synthetic_batch(B, seed, device)
+        snap = snapshot()
+        loss_e = float(tr.step(y_i[sl], y_j[sl]))
+        p_e = torch.cat([p.detach().flatten() for p in model.parameters()]).clone()
+        restore(snap)
+        loss_g = float(tr.step_graph(y_i[sl], y_j[sl]))
+        p_g = torch.cat([p.detach().flatten() for p in model.parameters()]).clone()
+        p_0 = torch.cat([v.flatten() for v in snap[0]])
+        res.append({"loss_e": loss_e, "loss_g": loss_g, "d_e": float((p_e - p_0).norm()),
+                    "d_diff": float((p_g - p_e).norm()), "p_sum": float(p_g.double().sum())})
+    torch.cuda.synchronize()
+    torch.save(res, f"{out}.{rank}.pt")
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
 def main():
     out, B = sys.argv[1], int(sys.argv[2])
+    if len(sys.argv) > 3 and sys.argv[3] == "graph":
+        return graph_mode(out, B)
     rank, world, device = gdist.init_from_env()
     cfg = load_config()
     cfg["bsz_train"] = B

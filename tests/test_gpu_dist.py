@@ -141,6 +141,21 @@ def test_two_ranks_at_128_pairs_per_rank(tmp_path):
     assert abs(got[0]["grad_norm"] - want_norm) <= 2e-4 * want_norm
 
 
+def test_step_graph_data_parallel(tmp_path):
+    """Trainer.step_graph on two ranks (forward graph -> all-gather -> loss/backward/pack graph -> bucket all-reduces ->
+    Adam graph): from the same state a replayed step returns the eager step's loss share and moves the parameters
+    where the eager step moves them, and both ranks end with the same parameters."""
+    out = str(tmp_path / "g2")
+    _launch(2, out, 32, extra=("graph",))
+    got = [torch.load(f"{out}.{r}.pt", weights_only=False) for r in range(2)]
+    for r in range(2):
+        for step in got[r]:
+            assert abs(step["loss_g"] - step["loss_e"]) <= 2e-3 * max(1.0, abs(step["loss_e"])), step   # bf16 step
+            assert step["d_e"] > 0 and step["d_diff"] < 0.05 * step["d_e"], step
+    for a, b in zip(got[0], got[1]):
+        assert a["p_sum"] == b["p_sum"]                 # replicas stay in step (same reduced gradients, same update)
+
+
 def test_bench_two_ranks_one_gpu(tmp_path):
     """bench.py's N > 1 path end to end (barriers, MAX over ranks, rank-0 JSON line, sharded retrieval leg) with both
     ranks on cuda:0."""
@@ -165,6 +180,7 @@ def test_bench_two_ranks_one_gpu(tmp_path):
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0      # the global batch is split
     assert line["config"]["global_batch"] == 32 and line["roofline"]["frac"] > 0
+    assert line["hip_graph"].get("value", 0) > 0, line["hip_graph"]                        # the graph-replayed data-parallel step
     w = line["weak_scaling_256_per_gpu"]                                                   # ... and 256 pairs per rank beside it
     assert w["global_batch"] == 512 and w["scaling"] == "weak" and w["value"] > 0
     rs = line["retrieval_sharded"]                 # config-5 shape: one 1.25 M-row shard per rank, planted queries

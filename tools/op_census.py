@@ -21,3 +21,19 @@ for e in ev:
     cnt[(e.name, st[0] if st else "(torch internal)")] += 1
 for (name, where), n in cnt.most_common(40):
     print(f"{n:5d} {name:16s} {where}")
+
+# device kernels of the same step: name -> launches, total microseconds
+kc = collections.Counter()
+kt = collections.Counter()
+for e in prof.events():
+    if str(e.device_type).endswith("CUDA"):
+        kc[e.name[:90]] += 1
+        kt[e.name[:90]] += e.device_time if hasattr(e, "device_time") else e.cuda_time
+print("--- device kernels of one step")
+for name, n in kc.most_common(25):
+    print(f"{n:5d} {kt[name]:9.1f} us  {name}")
+# who launches the fills?
+for e in prof.events():
+    if e.name in ("aten::fill_", "aten::zero_", "aten::zeros", "aten::zeros_like", "aten::new_zeros", "aten::full"):
+        st = [s for s in (e.stack or [])][:6]
+        print(e.name, "|", " <- ".join(s.split("/")[-1] for s in st[:5]))
