@@ -104,11 +104,16 @@ static GemmPlan gemm_plan(int Rg, int K, int groups, int64_t M, int views) {
     return p;
 }
 
-template <typename CFG, int NS, bool PRO, bool STATS>
+// CAT: the operand is the row-wise concatenation [X (K1 rows); X2 (K - K1 rows)] of two tensors (never materialised):
+// the data gradient of the first layer of a residual block takes the shortcut's gradient as extra operand rows
+// against an identity block of the weight, dX = [W^T | I] [dY; dZ] -- the sum is rounded once and the separate
+// gradient-accumulation add (two reads, one write of C x M) is gone.
+template <typename CFG, int NS, bool PRO, bool STATS, bool CAT = false>
 __global__ __launch_bounds__(CFG::THREADS) void conv1x1_gemm_kernel(
     const unsigned short *__restrict__ A, int lda, const unsigned short *__restrict__ X, unsigned short *__restrict__ Y,
     int64_t M, int Rg, int K, int row_tiles, int ranges_view, int tiles_range, int col_tiles_view, int views,
-    const float2 *__restrict__ pro_tab, int pro_act, float pro_slope, float *__restrict__ part, int P, int nblocks) {
+    const float2 *__restrict__ pro_tab, int pro_act, float pro_slope, float *__restrict__ part, int P, int nblocks,
+    const unsigned short *__restrict__ X2 = nullptr, int K1 = 0) {
     constexpr int D = NS - 1;                               // chunks in flight
     constexpr int RT = CFG::RT, TN = CFG::TN, ROWB = CFG::ROWB;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -159,18 +164,30 @@ __global__ __launch_bounds__(CFG::THREADS) void conv1x1_gemm_kernel(
         const int seg = (sl >> 2) ^ (row & 3);
         b_src[j] = X + (size_t)row * M + col0 + (seg * 4 + (sl & 3)) * 8;
     }
+    const unsigned short *b_src2[2] = {nullptr, nullptr};
+    const int nch1 = CAT ? K1 / GM_KC : nch;
+    if (CAT) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b_src2[j] = X2 + (b_src[j] - X);
+    }
     int is_ch = 0;                                           // chunk-in-tile of the next chunk to issue
     auto issue = [&](int t) {
         const unsigned st = lds0 + (t % NS) * CFG::STAGE + 2 * wave * 1024;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             gm_dma16(a_src[j] + is_ch * GM_KC, st + j * 1024);
-            gm_dma16(b_src[j] + (size_t)is_ch * GM_KC * M, st + CFG::A_BYTES + j * 1024);
+            const unsigned short *xs = b_src[j] + (size_t)is_ch * GM_KC * M;
+            if (CAT && is_ch >= nch1) xs = b_src2[j] + (size_t)(is_ch - nch1) * GM_KC * M;
+            gm_dma16(xs, st + CFG::A_BYTES + j * 1024);
         }
         if (++is_ch == nch) {
             is_ch = 0;
             b_src[0] += TN;
             b_src[1] += TN;
+            if (CAT) {
+                b_src2[0] += TN;
+                b_src2[1] += TN;
+            }
         }
     };
 
@@ -643,6 +660,35 @@ extern "C" int grafp_conv1x1_gemm_bf16(const void *w, const void *x, int R, int 
     }
 #undef GM_LAUNCH
     GRAFP_CHECK_LAUNCH("conv1x1_gemm_kernel");
+    return GRAFP_OK;
+}
+
+extern "C" int grafp_conv1x1_gemm_cat_bf16(const void *w, const void *x1, int K1, const void *x2, int K2, int R, int64_t M,
+                                           void *y, grafp_stream_t stream) {
+    using namespace grafp;
+    GRAFP_REQUIRE(w && x1 && x2 && y, "conv1x1_gemm_cat: null pointer");
+    const int K = K1 + K2;
+    GRAFP_REQUIRE(K1 > 0 && K2 > 0 && K1 % GM_KC == 0 && gemm_shape_ok(R, K, 1, M, 1),
+                  "conv1x1_gemm_cat: unsupported shape R=%d K1=%d K2=%d M=%lld", R, K1, K2, (long long)M);
+    GRAFP_REQUIRE((((uintptr_t)w | (uintptr_t)x1 | (uintptr_t)x2 | (uintptr_t)y) & 15) == 0,
+                  "conv1x1_gemm_cat: operands must be 16-byte aligned");
+    const GemmPlan p = gemm_plan(R, K, 1, M, 1);
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(p.nblocks, 1, 1);
+#define GM_LAUNCH_CAT(CFG, NS)                                                                                          \
+    do {                                                                                                                \
+        const size_t lds = (size_t)(NS) * CFG::STAGE + CFG::NW * GM_OUT_BYTES;                                          \
+        (void)hipFuncSetAttribute((const void *)conv1x1_gemm_kernel<CFG, NS, false, false, true>,                       \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                \
+        hipLaunchKernelGGL((conv1x1_gemm_kernel<CFG, NS, false, false, true>), grid, dim3(CFG::THREADS), lds, s,        \
+                           (const unsigned short *)w, K, (const unsigned short *)x1, (unsigned short *)y, M, R, K,      \
+                           p.row_tiles, p.ranges_view, p.tiles_range, p.col_tiles_view, 1, (const float2 *)nullptr, 0,  \
+                           0.0f, (float *)nullptr, p.P, p.nblocks, (const unsigned short *)x2, K1);                     \
+    } while (0)
+    if (p.large) GM_LAUNCH_CAT(GemmL, 3);
+    else GM_LAUNCH_CAT(GemmS, 4);
+#undef GM_LAUNCH_CAT
+    GRAFP_CHECK_LAUNCH("conv1x1_gemm_kernel (cat)");
     return GRAFP_OK;
 }
 

@@ -98,7 +98,8 @@ def _bn_training(bn, groups):
     return training, (0.0 if bn.momentum is None else bn.momentum)
 
 
-def conv_bn_act(conv, bn, x, residual=None, act=ops.ACT_NONE, slope=0.0, groups=1, weight=None, use_bias=True):
+def conv_bn_act(conv, bn, x, residual=None, act=ops.ACT_NONE, slope=0.0, groups=1, weight=None, use_bias=True,
+                token=None, token_role=0):
     """[1x1 Conv2d -> BatchNorm2d -> activation -> + shortcut] on x (Cin, B, N) -> (Cout, B, N).  bf16 activations on
     the GPU take the fused path (ops.conv_bn_act: hand-written GEMM with the batch statistics in its epilogue, one
     normalise pass); everything else the GEMM + fused BatchNorm kernel pair.  `weight`: a 2-D (Cout, K) weight derived
@@ -115,13 +116,31 @@ def conv_bn_act(conv, bn, x, residual=None, act=ops.ACT_NONE, slope=0.0, groups=
         w = conv.weight if weight is None else weight
         res = None if residual is None else residual.reshape(cout, B * N)
         z = ops.conv_bn_act(x2, w, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum, bn.eps,
-                            bias, res, act, slope, cg, groups, getattr(conv, "_w_lowp", None) if weight is None else None)
+                            bias, res, act, slope, cg, groups, getattr(conv, "_w_lowp", None) if weight is None else None,
+                            token, token_role)
         return z.reshape(cout, B, N)
     if weight is None:
         y = conv1x1(conv, x)
     else:
         y = ops.conv1x1_rows(x2, weight).reshape(cout, B, N)
     return bn_act(bn, y, pre_bias=bias, residual=residual, act=act, slope=slope, groups=groups)
+
+
+def shortcut_token(x, first_conv, last_conv, groups=1):
+    """A ShortcutToken for the residual block  x -> first_conv ... last_conv(+ x)  when both ends take the fused bf16
+    path in training mode (otherwise None: autograd adds the two gradients of x as usual)."""
+    if not (torch.is_grad_enabled() and x.requires_grad and first_conv.groups == 1):
+        return None
+    cin, B, N = x.shape
+    xa = x
+    if torch.is_autocast_enabled() and x.is_cuda and x.dtype == torch.float32:
+        xa = x.to(torch.get_autocast_dtype("cuda"))
+    x2 = xa.reshape(cin, B * N)
+    if not (ops.conv_bn_act_supported(x2, first_conv.out_channels, 1, groups) and ops.shortcut_token_supported(x2)):
+        return None
+    if not ops.conv_bn_act_shape_supported(last_conv.in_channels, B * N, last_conv.out_channels, last_conv.groups, groups):
+        return None
+    return ops.ShortcutToken()
 
 
 def bn_act(bn, y, pre_bias=None, residual=None, act=ops.ACT_NONE, slope=0.0, groups=1):

@@ -11,7 +11,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ... import ops
-from .._dense import conv_bn_act, from_cbn, to_cbn
+from .._dense import conv_bn_act, from_cbn, shortcut_token, to_cbn
 from .pos_embed import get_2d_relative_pos_embed
 from .torch_edge import DenseDilatedKnnGraph
 from .torch_nn import BasicConv
@@ -91,9 +91,10 @@ class Grapher(nn.Module):
 
     def forward_cbn(self, x, groups=1):
         """x (C,B,N) -> (C,B,N): 3 GEMMs, 3 fused BN kernels, the k-NN build and the max-relative gather."""
-        y = conv_bn_act(self.fc1[0], self.fc1[1], x, groups=groups)
+        tok = shortcut_token(x, self.fc1[0], self.fc2[0], groups)     # the shortcut's gradient rides fc1's data gradient
+        y = conv_bn_act(self.fc1[0], self.fc1[1], x, groups=groups, token=tok, token_role=1)
         y = self.graph_conv.forward_cbn(y, groups)
-        return conv_bn_act(self.fc2[0], self.fc2[1], y, residual=x, groups=groups)
+        return conv_bn_act(self.fc2[0], self.fc2[1], y, residual=x, groups=groups, token=tok, token_role=2)
 
     def forward(self, x):
         return from_cbn(self.forward_cbn(to_cbn(x)), x)

@@ -632,6 +632,41 @@ def conv1x1_gemm(w, x, groups=1, views=1, pro_tab=None, pro_act=ACT_NONE, pro_sl
     return (y, part) if stats else y
 
 
+def conv1x1_gemm_cat(w, x1, x2):
+    """y = W [x1; x2] for bf16 rows x1 (K1, M), x2 (K2, M) and w (R, K1 + K2): the concatenation is never materialised."""
+    _require_gpu(w, x1, x2)
+    if w.dtype != torch.bfloat16 or x1.dtype != torch.bfloat16 or x2.dtype != torch.bfloat16:
+        raise TypeError("conv1x1_gemm_cat: bf16 operands")
+    w, x1, x2 = w.contiguous(), x1.contiguous(), x2.contiguous()
+    R, K1, K2, M = w.shape[0], x1.shape[0], x2.shape[0], x1.shape[1]
+    if w.shape[1] != K1 + K2 or x2.shape[1] != M:
+        raise ValueError(f"conv1x1_gemm_cat: weight {tuple(w.shape)} vs operands {tuple(x1.shape)} + {tuple(x2.shape)}")
+    y = torch.empty((R, M), dtype=torch.bfloat16, device=x1.device)
+    with _timed("conv1x1_gemm", (R, K1 + K2, 1, M)):
+        check(lib.grafp_conv1x1_gemm_cat_bf16(_p(w), _p(x1), K1, _p(x2), K2, R, M, _p(y), _stream()), "conv1x1_gemm_cat")
+    return y
+
+
+class ShortcutToken:
+    """Hands the shortcut's gradient of a residual block from the backward of its LAST layer (which receives dZ and
+    would return it unchanged for the shortcut) to the backward of its FIRST layer (whose data gradient autograd would
+    add it to): `x = f(x) + x` then costs no separate accumulate kernel -- see conv1x1_gemm_cat."""
+    __slots__ = ("grad",)
+
+    def __init__(self):
+        self.grad = None
+
+
+_EYES = {}
+
+
+def _eye_bf16(n, device):
+    key = (n, str(device))
+    if key not in _EYES:
+        _EYES[key] = torch.eye(n, dtype=torch.bfloat16, device=device)
+    return _EYES[key]
+
+
 def bn_finalize(part, C, K, groups, M, views, gamma, beta, pre_bias, running_mean, running_var, training, momentum, eps):
     """GEMM partial sums (or, in eval mode, the running statistics) -> (mean (C,views), invstd (C,views),
     tab (C,views,2) = (scale, shift) with z = act(y * scale + shift)); advances the running statistics when training."""
@@ -728,8 +763,9 @@ class _ConvBnAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, w_lowp, conv_groups, views, gamma, beta, pre_bias, residual, running_mean, running_var,
-                training, momentum, eps, act, slope):
+                training, momentum, eps, act, slope, token=None, token_role=0):
         x = x.detach()
+        ctx.token, ctx.token_role = token, token_role        # 1: first layer of the block (consumes), 2: last (provides)
         K, M = x.shape
         R = w.shape[0]
         if w_lowp is not None and w_lowp.dtype == torch.bfloat16 and w_lowp.numel() == w.numel():
@@ -763,13 +799,23 @@ class _ConvBnAct(torch.autograd.Function):
         dy, dgamma, dbeta, dpb = _bn_bwd(y, dz, R, M, views, pb if has_pb else None, g32, b32, mean, invstd, act, slope,
                                          training)
         dx = None
+        tok = ctx.token
         if ctx.needs_input_grad[0]:
-            dx = conv1x1_gemm(_group_transpose(wl, cg), dy, cg, 1)
+            short = tok.grad if (tok is not None and ctx.token_role == 1) else None
+            if short is not None:
+                # dX = [W^T | I] [dY; dZ_shortcut]: the block input's two gradients in one product, rounded once
+                tok.grad = None
+                w_aug = torch.cat((wl.t(), _eye_bf16(K, wl.device)), dim=1)
+                dx = conv1x1_gemm_cat(w_aug, dy, short)
+            else:
+                dx = conv1x1_gemm(_group_transpose(wl, cg), dy, cg, 1)
         dw = None
         if ctx.needs_input_grad[1]:
             dw = _wgrad_bf16(dy, x, R, K, cg, M).reshape(wfull)
-        return (dx, dw, None, None, None, dgamma, dbeta, dpb, (dz if has_res else None), None, None, None, None, None,
-                None, None)
+        dres = dz if has_res else None
+        if has_res and tok is not None and ctx.token_role == 2 and tok.grad is None:
+            tok.grad, dres = dz, None                      # the first layer's backward adds it (see above)
+        return (dx, dw, None, None, None, dgamma, dbeta, dpb, dres, None, None, None, None, None, None, None, None, None)
 
 
 def conv_bn_act_supported(x, cout, conv_groups, views):
@@ -779,15 +825,31 @@ def conv_bn_act_supported(x, cout, conv_groups, views):
     if os.environ.get("GRAFP_LIBRARY_GEMM", "0") == "1":
         return False
     K, M = x.shape
+    return conv_bn_act_shape_supported(K, M, cout, conv_groups, views)
+
+
+def conv_bn_act_shape_supported(K, M, cout, conv_groups, views):
+    if os.environ.get("GRAFP_LIBRARY_GEMM", "0") == "1":
+        return False
     return gemm_supported(cout, K, conv_groups, M, views) and gemm_supported(K, cout, conv_groups, M, 1)
 
 
 def conv_bn_act(x, w, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, pre_bias=None,
-                residual=None, act=ACT_NONE, slope=0.0, conv_groups=1, views=1, w_lowp=None):
-    """act(BatchNorm(W x + pre_bias)) + residual for bf16 (K, M) rows (see _ConvBnAct)."""
+                residual=None, act=ACT_NONE, slope=0.0, conv_groups=1, views=1, w_lowp=None, token=None, token_role=0):
+    """act(BatchNorm(W x + pre_bias)) + residual for bf16 (K, M) rows (see _ConvBnAct).  token / token_role: a
+    ShortcutToken shared by the first (role 1: its input IS the shortcut) and the last layer (role 2: `residual` is that
+    same input) of a residual block."""
     return _ConvBnAct.apply(x.contiguous(), w, w_lowp, int(conv_groups), int(views), gamma, beta, pre_bias, residual,
                             running_mean, running_var, bool(training), float(momentum), float(eps), int(act),
-                            float(slope))
+                            float(slope), token, int(token_role))
+
+
+def shortcut_token_supported(x, conv_groups=1):
+    """The fused shortcut gradient needs the (K, K + K) x M data-gradient product of the block's first layer."""
+    if os.environ.get("GRAFP_NO_SHORTCUT_FUSION", "0") == "1" or conv_groups != 1:
+        return False
+    K, M = x.shape
+    return x.is_cuda and x.dtype == torch.bfloat16 and bool(lib.grafp_conv1x1_gemm_supported(K, 2 * K, 1, M, 1))
 
 
 # ------------------------------------------------------------------------------------------------

@@ -224,6 +224,14 @@ int grafp_conv1x1_gemm_partials(int R, int K, int groups, int64_t M, int views);
 int grafp_conv1x1_gemm_bf16(const void *w, const void *x, int R, int K, int groups, int64_t M, int views,
                             const float *pro_tab, int pro_act, float pro_slope, void *y, float *stats_part,
                             grafp_stream_t stream);
+
+/* y = W [x1; x2]: the operand is the row-wise concatenation of two (K1, M) / (K2, M) bf16 tensors (never materialised),
+ * W (R, K1 + K2) bf16.  Used for the data gradient of the first layer of a residual block,
+ * dX = [W^T | I] [dY; dZ]: the shortcut's gradient dZ (autograd's accumulate of
+ * /root/reference/encoder/gcn_lib/torch_vertex.py:187-194 and encoder/graph_encoder.py:59-66, `x = ... + shortcut`)
+ * enters the product against an identity block and the sum is rounded once. */
+int grafp_conv1x1_gemm_cat_bf16(const void *w, const void *x1, int K1, const void *x2, int K2, int R, int64_t M, void *y,
+                                grafp_stream_t stream);
 /* BatchNorm2d statistics from the GEMM's partial sums (training != 0; nn.BatchNorm2d semantics as grafp_bn_fwd:
  * biased variance for the normalisation, unbiased for the running update, once per view in order) or from the running
  * statistics (training == 0, stats_part ignored).  (C, K, groups, M, views) are the arguments of the GEMM launch that

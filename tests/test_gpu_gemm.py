@@ -179,3 +179,19 @@ def test_wgrad_every_tile_configuration(tile, cout, cin, groups, M, views):
     want = torch.cat([g[i * og:(i + 1) * og].double() @ x[i * cg:(i + 1) * cg].double().t() for i in range(groups)], dim=0)
     assert float((dw.double() - want).abs().max()) <= 2e-3 * float(want.abs().max())
     assert torch.equal(dw, again)
+
+
+def test_gemm_cat_equals_product_plus_shortcut():
+    """conv1x1_gemm_cat(W | I, dY, dZ) = W dY + dZ with ONE rounding (the data gradient of a residual block's first
+    layer with the shortcut's gradient as extra operand rows), for an S-tile and an L-tile shape."""
+    from grafp_amd import ops
+    for R, K1, M in ((64, 64, 4096), (256, 1024, 2048), (128, 128, 1024)):
+        wt = _rand((R, K1), 41, 0.1)
+        dy, dz = _rand((K1, M), 42), _rand((R, M), 43)
+        w_aug = torch.cat((wt, torch.eye(R, dtype=torch.bfloat16, device=DEV)), dim=1)
+        got = ops.conv1x1_gemm_cat(w_aug, dy, dz)
+        want = wt.double() @ dy.double() + dz.double()
+        err = (got.double() - want).abs()
+        assert float((err / (want.abs() + 1.0)).max()) <= 2.0 ** -8          # one bf16 rounding of an exact-ish f32 sum
+        # and it is the concatenated product, bit for bit
+        assert torch.equal(got, ops.conv1x1_gemm(w_aug, torch.cat((dy, dz), dim=0)))

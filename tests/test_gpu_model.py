@@ -453,3 +453,49 @@ def test_db_writers_device_stream_and_part_files(dev, tmp_path, monkeypatch, sta
     lo, hi = fpdb.track_range(len(tracks), 0, 2)
     n0 = sum((1 + t.shape[1] // 512 - 32) // 3 + 1 for t in tracks[lo:hi])
     assert len(parted.part_rows(0)) == n0 and len(parted.part_rows(1)) == want.shape[0] - n0
+
+
+def test_shortcut_gradient_fused_into_data_gradient(dev, monkeypatch):
+    """The shortcut's gradient of every Grapher / FFN block rides the data-gradient GEMM of the block's first layer
+    (ops.ShortcutToken): parameter gradients equal those of the plain autograd accumulation up to bf16 rounding."""
+    from grafp_amd.train import Trainer, build_model, synthetic_batch
+    from grafp_amd.util import load_config
+    cfg = load_config()
+    cfg["bsz_train"] = 8
+    torch.manual_seed(3)
+    model = build_model(cfg, device=dev)
+    tr = Trainer(cfg, model, dev, amp_dtype=torch.bfloat16)
+    x_i, x_j = synthetic_batch(8, 11, dev)
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+
+    def grads(fused):
+        monkeypatch.setenv("GRAFP_NO_SHORTCUT_FUSION", "0" if fused else "1")
+        model.load_state_dict(state)
+        model.train()
+        for p in model.parameters():
+            p.grad = None
+        with torch.no_grad():
+            X_i, X_j = tr.augment(x_i, x_j)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            _, _, z_i, z_j = model(X_i, X_j)
+        from grafp_amd.simclr.ntxent import ntxent_loss
+        loss = ntxent_loss(z_i, z_j, cfg)
+        loss.backward()
+        return float(loss.detach()), {n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    l1, g1 = grads(True)
+    l0, g0 = grads(False)
+    assert l1 == l0                                              # the forward pass is untouched
+    assert g1.keys() == g0.keys()
+    num = sum(float((g1[n] - g0[n]).pow(2).sum()) for n in g0)
+    den = sum(float(g0[n].pow(2).sum()) for n in g0)
+    # bf16 gradients, 24 residual blocks deep: the one rounding that changes per block input (2^-9 per element) is
+    # amplified to ~2 % of the whole gradient (measured 0.024); a shortcut gradient that went missing or was counted
+    # twice would show up at order 1
+    assert den > 0 and (num / den) ** 0.5 <= 6e-2, (num / den) ** 0.5
+    # per parameter, among those that carry gradient at all (the BatchNorm bias of a Grapher's fc1 has a mathematically
+    # ZERO gradient -- max-relative differences and the next BatchNorm remove a per-channel constant -- so what is
+    # computed for it is rounding noise, 1e-6 of the total norm, and differs by 100 % between any two roundings)
+    floor = 1e-3 * den ** 0.5
+    worst = max(float((g1[n] - g0[n]).norm() / g0[n].norm()) for n in g0 if float(g0[n].norm()) >= floor)
+    assert worst <= 0.3, worst
