@@ -602,11 +602,12 @@ static WgDmaPlan wgrad_dma_plan(int cout_g, int cin_g, int groups, int64_t M, in
     // profiles/r02_wgrad_sweep.txt).  Three regimes by the bytes of the two operands:
     //  * they fit the 256 MB Infinity Cache with room to spare: the 64 x 64 tile (many small workgroups, a few MB of
     //    partial sums, its operand re-reads are cache hits at ~14 TB/s), 128 x 128 from 2^19 outputs;
-    //  * 200 ... 750 MB: the wide layers (FFN and fc2 of stages 2-3; from 400 MB everything with >= 128 x 256 rows) on the
-    //    256 x 256 tile with 64-byte row pieces (L32: three 32 KB chunks in flight, 1.6x instead of 3.2x re-reads);
-    //  * beyond (1024 pairs on one GPU: every re-read of a small tile goes to HBM, and 64-byte pieces at 1-4 MB row
-    //    stride read at 2.5-3.8 TB/s -- rowpiece_read_bench): G through registers -- 256 x 256 (LG) for the wide layers
-    //    (-28 % on the stage-2 FFN), 128 x 128 (SG) for everything else with >= 128 rows on one side.
+    //  * from 200 MB the wide layers (FFN and fc2 of stages 2-3; from 400 MB everything with >= 128 x 256 rows) on the
+    //    256 x 256 tile with the G operand through registers (LG: two chunks of both operands in flight, 1.6x instead
+    //    of 3.2x re-reads); the 64-byte-piece form of that tile (L32) is within 5 % of it up to 750 MB and loses
+    //    beyond (64-byte pieces at 1-4 MB row stride read at 2.5-3.8 TB/s -- rowpiece_read_bench);
+    //  * beyond 750 MB (1024 pairs on one GPU: every re-read of a small tile goes to HBM) everything else with >= 128
+    //    rows on one side on the 128 x 128 register-staged tile (SG).
     // The grouped convolutions (32 ... 128 rows per group) stay on the small tile.  With the in-LDS normalisation (pro)
     // only the three DMA tiles of the first round.
     const double opbytes = (double)(cout_g + cin_g) * groups * (double)M * 2.0;
@@ -618,15 +619,13 @@ static WgDmaPlan wgrad_dma_plan(int cout_g, int cin_g, int groups, int64_t M, in
     if (pro && cin_g >= 256 && cout_g >= 128) p.cfg = 1;
     static const bool no_wide = getenv("GRAFP_WGRAD_NO_WIDE") != nullptr;      // A/B: the three DMA tiles only
     if (!pro && !no_wide) {
-        if (opbytes >= 750e6) {
-            if (groups == 1 && (lo >= 256 || (lo >= 128 && hi >= 512))) p.cfg = 7;
-            else if (groups == 1 ? hi >= 128 : cout_g >= 256) p.cfg = 6;
-        } else if (groups == 1) {
-            if ((lo >= 256 && hi >= 1024 && opbytes >= 200e6) || (lo >= 128 && hi >= 256 && opbytes >= 400e6) ||
-                (lo >= 512 && opbytes >= 250e6))
-                p.cfg = 5;
+        const bool wide = (lo >= 256 && hi >= 1024 && opbytes >= 200e6) || (lo >= 128 && hi >= 256 && opbytes >= 400e6) ||
+                          (lo >= 512 && opbytes >= 250e6);
+        if (groups == 1) {
+            if (wide) p.cfg = 7;                                   // LG, one workgroup per CU (see targets below)
+            else if (opbytes >= 750e6 && hi >= 128) p.cfg = 6;     // SG
         } else if (cout_g >= 256 && opbytes >= 400e6) {
-            p.cfg = 5;
+            p.cfg = opbytes >= 750e6 ? 6 : 5;
         }
     }
     if (wg_force_cfg() >= 0 && wg_force_cfg() <= 7 && !(pro && wg_force_cfg() >= 6)) p.cfg = wg_force_cfg();
@@ -638,7 +637,10 @@ static WgDmaPlan wgrad_dma_plan(int cout_g, int cin_g, int groups, int64_t M, in
     const int64_t tiles = (int64_t)p.tiles_o * p.tiles_c * groups;
     const int64_t Mv = M / views;
     // two rounds of resident workgroups (L: one per CU, T/S: two), at least 8 chunks per slice
-    static const int64_t targets[8] = {1024, 1024, 512, 1024, 512, 256, 1024, 512};
+    // workgroups to aim for: two rounds of resident workgroups for the small tiles; ONE round (one workgroup per CU)
+    // for the 256 x 256 tiles -- a second round doubles their partial sums (128 slices x 1 MB written and read back
+    // against 1.3 GB of operands) and was 5-30 % slower on every shape (LG at 2048 clip-views: 16.4 -> 15.0 ms per step)
+    static const int64_t targets[8] = {1024, 1024, 512, 1024, 512, 256, 512, 256};
     int64_t target = targets[p.cfg];
     if (const char *e = getenv("GRAFP_WGRAD_TARGET")) target = atoi(e);
     int64_t sv = (target + tiles * views - 1) / (tiles * views);
