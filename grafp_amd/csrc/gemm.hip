@@ -91,7 +91,11 @@ static GemmPlan gemm_plan(int Rg, int K, int groups, int64_t M, int views) {
     p.col_tiles_view = (int)(Mg / p.tn);
     const int nch = K / GM_KC;
     // two rounds of resident workgroups, but at least ~8 chunks per workgroup to amortise the pipeline fill
-    int64_t want = (int64_t)(512 * per_cu) / ((int64_t)p.row_tiles * groups * views);
+    // (four rounds once the launch streams >= 750 MB: -3 % over all layers at 2048 clip-views, nothing below;
+    // swept 256 ... 8192 per workgroup-per-CU, GRAFP_GEMM_WGS overrides for measurements)
+    static const int wgs_env = getenv("GRAFP_GEMM_WGS") ? atoi(getenv("GRAFP_GEMM_WGS")) : 0;
+    const int wgs = wgs_env > 0 ? wgs_env : ((double)(Rg + K) * groups * (double)M * 2.0 >= 750e6 ? 1024 : 512);
+    int64_t want = (int64_t)(wgs * per_cu) / ((int64_t)p.row_tiles * groups * views);
     if (want < 1) want = 1;
     int tiles_range = (int)((p.col_tiles_view + want - 1) / want);
     const int min_tiles = (8 + nch - 1) / nch;
