@@ -637,11 +637,13 @@ static WgDmaPlan wgrad_dma_plan(int cout_g, int cin_g, int groups, int64_t M, in
     const int64_t tiles = (int64_t)p.tiles_o * p.tiles_c * groups;
     const int64_t Mv = M / views;
     // two rounds of resident workgroups (L: one per CU, T/S: two), at least 8 chunks per slice
-    // workgroups to aim for: two rounds of resident workgroups for the small tiles; ONE round (one workgroup per CU)
+    // workgroups to aim for: ONE round of resident workgroups (512 for the tiles with two workgroups per CU: -11 % over
+    // all layers at 256 clip-views, -5 % at 512 against two rounds; one workgroup per CU
     // for the 256 x 256 tiles -- a second round doubles their partial sums (128 slices x 1 MB written and read back
     // against 1.3 GB of operands) and was 5-30 % slower on every shape (LG at 2048 clip-views: 16.4 -> 15.0 ms per step)
-    static const int64_t targets[8] = {1024, 1024, 512, 1024, 512, 256, 512, 256};
+    static const int64_t targets[8] = {512, 512, 512, 1024, 512, 256, 512, 256};
     int64_t target = targets[p.cfg];
+    if (p.cfg <= 1 && opbytes >= 750e6) target = 1024;        // the small tiles at 1024 pairs per GPU: two rounds (+2 %)
     if (const char *e = getenv("GRAFP_WGRAD_TARGET")) target = atoi(e);
     int64_t sv = (target + tiles * views - 1) / (tiles * views);
     const int64_t max_sv = (Mv / 64 + 7) / 8;
