@@ -731,7 +731,11 @@ static int bn_affine_launch(const void *y, int C, int64_t M, int views, const fl
     GRAFP_REQUIRE(act >= 0 && act <= 2, "bn_affine: bad activation %d", act);
     const int64_t Mg = M / views;
     // ~2048 workgroups in total, >= 8192 elements per workgroup
-    int chunks_view = (int)((2048 + (int64_t)C * views - 1) / ((int64_t)C * views));
+    // (swept 1024 ... 262144, tools/bn_bench.py --affine: the plain form gains 10 % from 64 k small workgroups at 2048
+    // clip-views, but the training form re-combines its row's partial statistics in every workgroup and loses 20 %;
+    // a separate finalize launch + 64 k workgroups ties with this at 1024 pairs and loses at 256)
+    static const int wgs = getenv("GRAFP_AFFINE_WGS") ? atoi(getenv("GRAFP_AFFINE_WGS")) : 2048;
+    int chunks_view = (int)((wgs + (int64_t)C * views - 1) / ((int64_t)C * views));
     const int64_t max_chunks = (Mg + 8191) / 8192;
     if (chunks_view > max_chunks) chunks_view = (int)max_chunks;
     if (chunks_view < 1) chunks_view = 1;

@@ -31,11 +31,25 @@ def main():
     ap.add_argument("--views", type=int, default=2)
     ap.add_argument("--spin", type=int, default=None)
     ap.add_argument("--pad", type=int, default=None, help="elements between the three tensors (one allocation)")
+    ap.add_argument("--affine", action="store_true", help="time the normalise pass (bn_affine_bf16_kernel) instead")
     args = ap.parse_args()
     if args.spin is not None:
         lib.grafp_bn_debug_spin_limit(args.spin)
     dev, tot = "cuda:0", 0.0
     depth = (2, 2, 6, 2)
+    if args.affine:
+        for stage, (C, N) in enumerate(((64, 1024), (128, 512), (256, 256), (512, 128))):
+            M = args.clips * N
+            for name, rows, n, with_res in (("C", C, 1, False), ("C+res", C, 2, True), ("2C", 2 * C, 1, False), ("4C", 4 * C, 1, False)):
+                y = torch.randn(rows, M, device=dev).to(torch.bfloat16)
+                res = torch.randn(rows, M, device=dev).to(torch.bfloat16) if with_res else None
+                tab = torch.rand(rows, args.views, 2, device=dev)
+                t = timeit(lambda: ops.bn_affine(y, tab, args.views, res, ops.ACT_RELU, 0.0))
+                tot += t * n * depth[stage]
+                by = (3.0 if with_res else 2.0) * rows * M * 2
+                print(f"s{stage} rows {rows:5d} {name:6s} M {M:8d}: {t:8.1f} us  {by / t / 1e6:5.2f} TB/s", flush=True)
+        print(f"per step: {tot / 1e3:.2f} ms")
+        return
     for stage, (C, N) in enumerate(((64, 1024), (128, 512), (256, 256), (512, 128))):
         M = args.clips * N
         for name, rows, n in (("C", C, 3), ("2C", 2 * C, 1), ("4C", 4 * C, 1)):
