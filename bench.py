@@ -318,21 +318,6 @@ def main():
         kernels = summarise_kernels(timed, 2 if args.dtype == "bf16" else 4)
     ms_k = 1e3 * max_over_ranks(t_k) / max(1, args.kernel_steps)
 
-    # ---- the same data-parallel step replayed from HIP graphs (forward | loss + backward + pack | Adam, the two
-    #      collectives eager between them): every rank takes the same path, so the collectives stay aligned ----
-    hip_graph = None
-    if world > 1 and not args.no_graph:
-        try:
-            trainer.step_graph(x_i, x_j)
-            dt, _ = timed_steps(lambda: trainer.step_graph(x_i, x_j), args.steps, barrier)
-            dt = max_over_ranks(dt)
-            hip_graph = {"value": round(B * world * args.steps / dt, 2), "unit": "clips/s",
-                         "ms_per_step": round(1e3 * dt / args.steps, 3), "steps": args.steps,
-                         "note": "three HIP graphs per step with the all-gather of (z_i, z_j) and the bucket "
-                                 "all-reduces eager between them (Trainer.step_graph); `value` above is the eager step"}
-        except Exception as exc:          # noqa: BLE001 -- report, do not fail the bench line
-            hip_graph = {"error": f"{type(exc).__name__}: {exc}"[:200]}
-
     weak = None
     if world > 1 and B != 256 and args.batch_per_gpu is None:
         # the weak-scaling variant beside the headline: 256 pairs per GPU (BASELINE config 2 on every GPU)
@@ -377,6 +362,22 @@ def main():
                    "top1_hit_rate": float((ids[:, 0] == want).float().mean().item()), "n_gpus": world,
                    "query_sigma": QUERY_SIGMA}
         del index, rows
+
+    # ---- the same data-parallel step replayed from HIP graphs (forward | loss + backward + pack | Adam, the two
+    #      collectives eager between them): every rank takes the same path, so the collectives stay aligned ----
+    # (last of the legs: whatever happens here, everything above is already measured)
+    hip_graph = None
+    if world > 1 and not args.no_graph:
+        try:
+            trainer.step_graph(x_i, x_j)
+            dt, _ = timed_steps(lambda: trainer.step_graph(x_i, x_j), args.steps, barrier)
+            dt = max_over_ranks(dt)
+            hip_graph = {"value": round(B * world * args.steps / dt, 2), "unit": "clips/s",
+                         "ms_per_step": round(1e3 * dt / args.steps, 3), "steps": args.steps,
+                         "note": "three HIP graphs per step with the all-gather of (z_i, z_j) and the bucket "
+                                 "all-reduces eager between them (Trainer.step_graph); `value` above is the eager step"}
+        except Exception as exc:          # noqa: BLE001 -- report, do not fail the bench line
+            hip_graph = {"error": f"{type(exc).__name__}: {exc}"[:200]}
 
     if rank == 0:
         clips = B * world * args.steps

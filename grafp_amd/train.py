@@ -127,7 +127,8 @@ class Trainer:
         self.sync.paused = True                      # no collective from the autograd hooks while backward is recorded
         try:
             g_fwd = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_fwd):
+            # thread_local: the process group's watchdog thread may query events while this thread records
+            with torch.cuda.graph(g_fwd, capture_error_mode="thread_local"):
                 with torch.no_grad():
                     X_i, X_j = self.augment(sx_i, sx_j)
                 with self._autocast():
@@ -136,7 +137,7 @@ class Trainer:
             gathered = torch.empty((R * 2,) + tuple(mine.shape[1:]), dtype=mine.dtype, device=mine.device)
             tdist.all_gather_into_tensor(gathered, mine, group=self.group)
             g_bwd = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_bwd, pool=g_fwd.pool()):
+            with torch.cuda.graph(g_bwd, pool=g_fwd.pool(), capture_error_mode="thread_local"):
                 both = gathered.reshape(R, 2, *mine.shape[1:]).permute(1, 0, 2, 3)
                 zi_all = both[0].reshape(-1, mine.shape[2]).contiguous()
                 zj_all = both[1].reshape(-1, mine.shape[2]).contiguous()
@@ -146,7 +147,7 @@ class Trainer:
                 loss = loss.detach()
             self.sync.reduce_all()
             g_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_opt, pool=g_fwd.pool()):
+            with torch.cuda.graph(g_opt, pool=g_fwd.pool(), capture_error_mode="thread_local"):
                 self.opt.step()
         finally:
             self.sync.paused = False
