@@ -36,7 +36,7 @@ constexpr int GM_STORES_PER_RT = 4;
 #define GM_NT 1
 #endif
 #ifndef GM_ABLATE            // measurement builds (tools/gemm_ablate.sh): 1 = no DMA in the main loop, 2 = no epilogue,
-#define GM_ABLATE 0          // 4 = no MFMA; sums of those.  Results are wrong for every value but 0.
+#define GM_ABLATE 0          // 4 = no MFMA, 8 = all stores to one L2-resident tile; sums.  Results are wrong for every value but 0.
 #endif
 constexpr bool NT_STORE = GM_NT != 0;   // streaming (nt) stores of Y            // 16-byte store instructions per wave and 32-row output tile
 
@@ -360,11 +360,12 @@ __global__ __launch_bounds__(CFG::THREADS) void conv1x1_gemm_kernel(
                     for (int it = 0; it < 4; ++it) {
                         const int row = it * 8 + (lane >> 3), p16 = lane & 7;
                         const uint4 v = *reinterpret_cast<const uint4 *>(my_out + row * 128 + ((p16 ^ (row & 7)) << 4));
-                        const int r = r0 + wr * 32 * RT + ri * 32 + row;
+                        const int r = (GM_ABLATE & 8) ? row : r0 + wr * 32 * RT + ri * 32 + row;   // 8: every store hits one L2-resident tile
                         typedef unsigned gm_u4 __attribute__((ext_vector_type(4)));
                         const gm_u4 vv = {v.x, v.y, v.z, v.w};
-                        if (NT_STORE) __builtin_nontemporal_store(vv, reinterpret_cast<gm_u4 *>(Y + (size_t)r * M + mcol + p16 * 8));
-                        else *reinterpret_cast<uint4 *>(Y + (size_t)r * M + mcol + p16 * 8) = v;
+                        const int64_t mc = (GM_ABLATE & 8) ? 0 : mcol;
+                        if (NT_STORE && !(GM_ABLATE & 8)) __builtin_nontemporal_store(vv, reinterpret_cast<gm_u4 *>(Y + (size_t)r * M + mc + p16 * 8));
+                        else *reinterpret_cast<uint4 *>(Y + (size_t)r * M + mc + p16 * 8) = v;
                     }
                 }
             }
