@@ -651,11 +651,15 @@ extern "C" int grafp_conv1x1_gemm_bf16(const void *w, const void *x, int R, int 
                            p.row_tiles, p.ranges_view, p.tiles_range, p.col_tiles_view, views, (const float2 *)pro_tab, \
                            pro_act, pro_slope, stats_part, p.P, p.nblocks);                                             \
     } while (0)
-    // ring depth: S keeps 2 workgroups per CU (80 KB each: 4 stages, 3 with the PRO table); L is alone on its CU (3 stages)
+    // ring depth: S keeps 2 workgroups per CU (80 KB each: 4 stages, 3 with the PRO table); L is alone on its CU
+    // L without the PRO table: four stages = all 160 KB of LDS (-2.7 % over all layers at 2048 clip-views against three)
+    static const bool l4 = getenv("GRAFP_GEMM_L3") == nullptr;
     if (p.large) {
         if (pro && stats) GM_LAUNCH(GemmL, 3, true, true);
         else if (pro) GM_LAUNCH(GemmL, 3, true, false);
+        else if (stats && l4) GM_LAUNCH(GemmL, 4, false, true);
         else if (stats) GM_LAUNCH(GemmL, 3, false, true);
+        else if (l4) GM_LAUNCH(GemmL, 4, false, false);
         else GM_LAUNCH(GemmL, 3, false, false);
     } else {
         if (pro && stats) GM_LAUNCH(GemmS, 3, true, true);
