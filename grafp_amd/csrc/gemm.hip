@@ -694,7 +694,7 @@ extern "C" int grafp_conv1x1_gemm_cat_bf16(const void *w, const void *x1, int K1
                            p.row_tiles, p.ranges_view, p.tiles_range, p.col_tiles_view, 1, (const float2 *)nullptr, 0,  \
                            0.0f, (float *)nullptr, p.P, p.nblocks, (const unsigned short *)x2, K1);                     \
     } while (0)
-    if (p.large) GM_LAUNCH_CAT(GemmL, 3);
+    if (p.large) GM_LAUNCH_CAT(GemmL, 4);
     else GM_LAUNCH_CAT(GemmS, 4);
 #undef GM_LAUNCH_CAT
     GRAFP_CHECK_LAUNCH("conv1x1_gemm_kernel (cat)");
