@@ -117,7 +117,8 @@ def conv_bn_act(conv, bn, x, residual=None, act=ops.ACT_NONE, slope=0.0, groups=
         res = None if residual is None else residual.reshape(cout, B * N)
         z = ops.conv_bn_act(x2, w, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum, bn.eps,
                             bias, res, act, slope, cg, groups, getattr(conv, "_w_lowp", None) if weight is None else None,
-                            token, token_role)
+                            token, token_role, getattr(conv, "_w_t", None) if weight is None else None,
+                            getattr(conv, "_w_aug", None) if weight is None else None)
         return z.reshape(cout, B, N)
     if weight is None:
         y = conv1x1(conv, x)

@@ -82,6 +82,7 @@ class Grapher(nn.Module):
         self.graph_conv = DyGraphConv2d(in_channels, in_channels * 2, kernel_size, dilation, conv, act, norm, bias,
                                         stochastic, epsilon, r)
         self.fc2 = nn.Sequential(nn.Conv2d(in_channels * 2, in_channels, 1), nn.BatchNorm2d(in_channels))
+        self.fc1[0]._shortcut_first = True     # its data gradient also carries the shortcut's (ops.ShortcutToken)
         self.drop_path = nn.Identity()
         self.relative_pos = None
         if relative_pos:   # frozen, never read by forward: kept for state-dict compatibility only

@@ -61,6 +61,7 @@ class FFN(nn.Module):
         self.act = act_layer(act)
         self.fc1 = nn.Sequential(nn.Conv2d(in_features, hidden_features, 1, bias=False), nn.BatchNorm2d(hidden_features))
         self.fc2 = nn.Sequential(nn.Conv2d(hidden_features, out_features, 1, bias=False), nn.BatchNorm2d(out_features))
+        self.fc1[0]._shortcut_first = True     # its data gradient also carries the shortcut's (ops.ShortcutToken)
 
     def forward_cbn(self, x, groups=1):
         """x (C,B,N) -> (C,B,N): 2 GEMMs + 2 fused BN kernels (ReLU and the shortcut add are inside them)."""

@@ -576,30 +576,75 @@ def conv1x1_rows(x, w, groups=1, w_lowp=None):
 
 
 class lowp_weights:
-    """Lowers the weights of many 1x1 convolutions to the autocast dtype with ONE multi-tensor copy per forward pass
-    (instead of one cast launch per layer).  `refresh()` before the layers run; conv._w_lowp is then picked up by
-    encoder/_dense.conv1x1.  The buffers are overwritten by the next refresh(): fine as long as the weights do not
-    change between a forward pass and its backward pass."""
+    """The weights of all 1x1 convolutions prepared for one forward + backward pass: the bf16 copy (forward operand),
+    the per-group transposed bf16 copy (data-gradient operand) and, for the first layer of a residual block (conv.
+    _shortcut_first), [W^T | I] -- ONE launch of grafp_weights_prepare for every layer whose rows and columns per
+    group are multiples of 32, one multi-tensor cast for the rest (the 8-channel stem).  `refresh()` before the layers
+    run; conv._w_lowp, conv._w_t and conv._w_aug are picked up by encoder/_dense.conv_bn_act.
+    The buffers are overwritten by the next refresh(): fine as long as the weights do not change between a forward
+    pass and its backward pass."""
 
     def __init__(self, convs):
-        self.convs = [c for c in convs if c.groups == 1]
-        self._bufs, self._dtype = None, None
+        self.convs = list(convs)
+        self._dtype, self._dev = None, None
+        self._fast, self._slow, self._slow_bufs = [], [], []
+        self._table = self._tile_entry = None
+        self._keep, self._src_ptrs = [], []
+
+    def _build(self, dtype, dev):
+        self._dtype, self._dev = dtype, dev
+        self._fast, self._slow, self._slow_bufs, self._keep = [], [], [], []
+        rows, tiles, base = [], [], 0
+        for c in self.convs:
+            w = c.weight
+            G = c.groups
+            Rg, Kg = w.shape[0] // G, w.shape[1]
+            if dtype == torch.bfloat16 and Rg % 32 == 0 and Kg % 32 == 0 and w.dtype == torch.float32 and w.is_contiguous():
+                lo = torch.empty((w.shape[0], Kg), dtype=dtype, device=dev)
+                aug = bool(getattr(c, "_shortcut_first", False)) and G == 1
+                ld_t = Rg + Kg if aug else Rg
+                wt = torch.zeros((G * Kg, ld_t), dtype=dtype, device=dev)
+                if aug:
+                    wt[:, Rg:] = torch.eye(Kg, dtype=dtype, device=dev)
+                n_t = G * (Rg // 32) * (Kg // 32)
+                rows.append([w.data_ptr(), lo.data_ptr(), wt.data_ptr(), Rg, Kg, G, ld_t, base])
+                tiles.append(torch.full((n_t,), len(rows) - 1, dtype=torch.int32))
+                base += n_t
+                self._fast.append((c, lo, wt, aug, Rg))
+            elif G == 1:
+                self._slow.append(c)
+                self._slow_bufs.append(torch.empty(w.shape, dtype=dtype, device=dev))
+        if rows:
+            self._table = torch.tensor(rows, dtype=torch.int64).to(dev)
+            self._tile_entry = torch.cat(tiles).to(dev)
+        else:
+            self._table = self._tile_entry = None
 
     def refresh(self, dtype):
         ws = [c.weight for c in self.convs]
         if not ws or not ws[0].is_cuda:
             return
-        if self._bufs is None or self._dtype != dtype or self._bufs[0].device != ws[0].device:
-            self._bufs = [torch.empty(w.shape, dtype=dtype, device=w.device) for w in ws]
-            self._dtype = dtype
+        dev = ws[0].device
+        stale = (self._dtype != dtype or self._dev != dev or
+                 any(c.weight.data_ptr() != ptr for c, ptr in zip(self.convs, self._src_ptrs)))
+        if stale:
+            self._build(dtype, dev)
+            self._src_ptrs = [c.weight.data_ptr() for c in self.convs]
         with torch.no_grad():
-            torch._foreach_copy_(self._bufs, ws)
-        for c, b in zip(self.convs, self._bufs):
-            c._w_lowp = b
+            if self._table is not None:
+                check(lib.grafp_weights_prepare(_p(self._table), _p(self._tile_entry), int(self._tile_entry.numel()),
+                                                _stream()), "weights_prepare")
+            if self._slow:
+                torch._foreach_copy_(self._slow_bufs, [c.weight for c in self._slow])
+        for c, lo, wt, aug, Rg in self._fast:
+            c._w_lowp = lo.view(c.weight.shape) if c.weight.dim() == 4 else lo
+            c._w_t, c._w_aug = (None, wt) if aug else (wt, None)
+        for c, b in zip(self._slow, self._slow_bufs):
+            c._w_lowp, c._w_t, c._w_aug = b, None, None
 
     def clear(self):
         for c in self.convs:
-            c._w_lowp = None
+            c._w_lowp = c._w_t = c._w_aug = None
 
 
 # ------------------------------------------------------------------------------------------------
@@ -763,9 +808,10 @@ class _ConvBnAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, w_lowp, conv_groups, views, gamma, beta, pre_bias, residual, running_mean, running_var,
-                training, momentum, eps, act, slope, token=None, token_role=0):
+                training, momentum, eps, act, slope, token=None, token_role=0, w_t=None, w_aug=None):
         x = x.detach()
         ctx.token, ctx.token_role = token, token_role        # 1: first layer of the block (consumes), 2: last (provides)
+        ctx.w_t, ctx.w_aug = w_t, w_aug                      # prepared with the forward operand (lowp_weights), or None
         K, M = x.shape
         R = w.shape[0]
         if w_lowp is not None and w_lowp.dtype == torch.bfloat16 and w_lowp.numel() == w.numel():
@@ -802,11 +848,15 @@ class _ConvBnAct(torch.autograd.Function):
         tok = ctx.token
         if ctx.needs_input_grad[0]:
             short = tok.grad if (tok is not None and ctx.token_role == 1) else None
+            w_t, w_aug = ctx.w_t, ctx.w_aug
             if short is not None:
                 # dX = [W^T | I] [dY; dZ_shortcut]: the block input's two gradients in one product, rounded once
                 tok.grad = None
-                w_aug = torch.cat((wl.t(), _eye_bf16(K, wl.device)), dim=1)
+                if w_aug is None:
+                    w_aug = torch.cat((wl.t(), _eye_bf16(K, wl.device)), dim=1)
                 dx = conv1x1_gemm_cat(w_aug, dy, short)
+            elif w_t is not None and w_t.is_contiguous():
+                dx = conv1x1_gemm(w_t, dy, cg, 1)
             else:
                 dx = conv1x1_gemm(_group_transpose(wl, cg), dy, cg, 1)
         dw = None
@@ -815,7 +865,8 @@ class _ConvBnAct(torch.autograd.Function):
         dres = dz if has_res else None
         if has_res and tok is not None and ctx.token_role == 2 and tok.grad is None:
             tok.grad, dres = dz, None                      # the first layer's backward adds it (see above)
-        return (dx, dw, None, None, None, dgamma, dbeta, dpb, dres, None, None, None, None, None, None, None, None, None)
+        return (dx, dw, None, None, None, dgamma, dbeta, dpb, dres, None, None, None, None, None, None, None, None, None,
+                None, None)
 
 
 def conv_bn_act_supported(x, cout, conv_groups, views):
@@ -835,13 +886,14 @@ def conv_bn_act_shape_supported(K, M, cout, conv_groups, views):
 
 
 def conv_bn_act(x, w, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, pre_bias=None,
-                residual=None, act=ACT_NONE, slope=0.0, conv_groups=1, views=1, w_lowp=None, token=None, token_role=0):
+                residual=None, act=ACT_NONE, slope=0.0, conv_groups=1, views=1, w_lowp=None, token=None, token_role=0,
+                w_t=None, w_aug=None):
     """act(BatchNorm(W x + pre_bias)) + residual for bf16 (K, M) rows (see _ConvBnAct).  token / token_role: a
     ShortcutToken shared by the first (role 1: its input IS the shortcut) and the last layer (role 2: `residual` is that
     same input) of a residual block."""
     return _ConvBnAct.apply(x.contiguous(), w, w_lowp, int(conv_groups), int(views), gamma, beta, pre_bias, residual,
                             running_mean, running_var, bool(training), float(momentum), float(eps), int(act),
-                            float(slope), token, int(token_role))
+                            float(slope), token, int(token_role), w_t, w_aug)
 
 
 def shortcut_token_supported(x, conv_groups=1):

@@ -232,6 +232,14 @@ int grafp_conv1x1_gemm_bf16(const void *w, const void *x, int R, int K, int grou
  * enters the product against an identity block and the sum is rounded once. */
 int grafp_conv1x1_gemm_cat_bf16(const void *w, const void *x1, int K1, const void *x2, int K2, int R, int64_t M, void *y,
                                 grafp_stream_t stream);
+
+/* All 1x1-convolution weights of one training step in ONE launch: per layer the bf16 copy (forward GEMM operand) and
+ * the per-group transposed bf16 copy (data-gradient operand; with ld_t > R/g the columns beyond R/g -- an identity
+ * block written once by the caller -- are left alone).  `table`: n_layers x 8 int64 words {src f32 (G*Rg, Kg), dst
+ * bf16 (G*Rg, Kg), dst_t bf16 (G*Kg, ld_t), Rg, Kg, G, ld_t, first tile}, Rg and Kg multiples of 32; `tile_entry`:
+ * layer index of every 32 x 32 tile.  Replaces the per-layer weight.to(bfloat16) / .t().contiguous() launches that
+ * stand in for /root/reference/encoder/gcn_lib/torch_nn.py:56-60 (Conv2d weights are used as they are there). */
+int grafp_weights_prepare(const void *table, const int32_t *tile_entry, int n_tiles, grafp_stream_t stream);
 /* BatchNorm2d statistics from the GEMM's partial sums (training != 0; nn.BatchNorm2d semantics as grafp_bn_fwd:
  * biased variance for the normalisation, unbiased for the running update, once per view in order) or from the running
  * statistics (training == 0, stats_part ignored).  (C, K, groups, M, views) are the arguments of the GEMM launch that

@@ -195,3 +195,32 @@ def test_gemm_cat_equals_product_plus_shortcut():
         assert float((err / (want.abs() + 1.0)).max()) <= 2.0 ** -8          # one bf16 rounding of an exact-ish f32 sum
         # and it is the concatenated product, bit for bit
         assert torch.equal(got, ops.conv1x1_gemm(w_aug, torch.cat((dy, dz), dim=0)))
+
+
+def test_weights_prepare_one_launch():
+    """ops.lowp_weights: bf16 copies, per-group transposed copies and [W^T | I] of many 1x1 convolutions in one launch
+    == weight.to(bfloat16), its (grouped) transpose, and the concatenation with the identity."""
+    from grafp_amd import ops
+    torch.manual_seed(5)
+    convs = [torch.nn.Conv2d(64, 256, 1, bias=False), torch.nn.Conv2d(128, 128, 1, groups=4), torch.nn.Conv2d(256, 64, 1),
+             torch.nn.Conv2d(8, 64, 1, bias=False), torch.nn.Conv2d(96, 160, 1)]
+    convs = [c.to(DEV) for c in convs]
+    convs[0]._shortcut_first = True
+    lw = ops.lowp_weights(convs)
+    for rep in range(2):                                   # second pass: weights changed in place, same buffers
+        if rep:
+            with torch.no_grad():
+                for c in convs:
+                    c.weight.mul_(1.5).add_(0.01)
+        lw.refresh(torch.bfloat16)
+        for c in convs:
+            want = c.weight.detach().to(torch.bfloat16)
+            assert torch.equal(c._w_lowp.reshape(want.shape), want)
+            R, Kg = want.shape[0], want.shape[1]
+            if Kg % 32 or (R // c.groups) % 32:
+                continue                                   # the 8-channel stem: plain cast only
+            if getattr(c, "_shortcut_first", False):
+                eye = torch.eye(Kg, dtype=torch.bfloat16, device=DEV)
+                assert c._w_t is None and torch.equal(c._w_aug, torch.cat((want.reshape(R, Kg).t(), eye), dim=1))
+            else:
+                assert c._w_aug is None and torch.equal(c._w_t, ops._group_transpose(want.reshape(R, Kg), c.groups))
