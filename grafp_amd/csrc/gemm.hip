@@ -104,8 +104,19 @@ static GemmPlan gemm_plan(int Rg, int K, int groups, int64_t M, int views) {
     p.tiles_range = tiles_range;
     p.ranges_view = (p.col_tiles_view + tiles_range - 1) / tiles_range;
     p.nblocks = p.row_tiles * p.ranges_view * views;
-    p.P = p.ranges_view * p.wm;       // one partial per (range, wave column)
+    p.P = p.ranges_view;              // one partial per column range: the wave columns of a workgroup are merged in LDS
     return p;
+}
+
+// Chan's pairwise combination of (count, mean, M2): set b appended to set a
+__device__ __forceinline__ void gm_chan(float &n, float &mean, float &m2, float nb, float mb, float m2b) {
+    const float nn = n + nb;
+    if (nn > 0.0f) {
+        const float delta = mb - mean, f = nb / nn;
+        mean = __builtin_fmaf(delta, f, mean);
+        m2 += m2b + delta * delta * (n * f);
+        n = nn;
+    }
 }
 
 // CAT: the operand is the row-wise concatenation [X (K1 rows); X2 (K - K1 rows)] of two tensors (never materialised):
@@ -391,17 +402,39 @@ __global__ __launch_bounds__(CFG::THREADS) void conv1x1_gemm_kernel(
         if (sink == 12345.678f) Y[0] = 1;
     }
     if (STATS) {
-        // per row: this wave's (sum, sum of squares, shift) over its 64-column share of every tile of the range
+        // per row: this wave's (sum, sum of squares, shift) over its 64-column share of every tile of the range ->
+        // (count, mean, M2); the WM wave columns of the workgroup are merged through LDS (Chan, fixed order) so that the
+        // consumer finds ONE partial per (row, range) -- its combine runs in every workgroup of the normalise pass
+        float *s_st = reinterpret_cast<float *>(smem);                  // [WM][TR][2] (mean, M2): the ring is idle now
+        const float np = 64.0f * (float)ntile;
+        __syncthreads();
 #pragma unroll
         for (int ri = 0; ri < RT; ++ri) {
             const float s1 = sS[ri].x + sS[ri].y, q1 = sQ[ri].x + sQ[ri].y;
             const float s = s1 + __shfl_xor(s1, 32), q = q1 + __shfl_xor(q1, 32);
-            const int r = r0 + wr * 32 * RT + ri * 32 + l31;
-            if (half == 0 && rt_valid[ri]) {
-                float *pp = part + ((((size_t)grp * Rg + r) * views + view) * P + (rloc * CFG::WM + wm)) * 3;
-                pp[0] = s;
-                pp[1] = q;
-                pp[2] = sShift[ri];
+            if (half == 0) {
+                const int row = wr * 32 * RT + ri * 32 + l31;
+                const float dm = s / np;
+                s_st[(wm * CFG::TR + row) * 2 + 0] = sShift[ri] + dm;
+                s_st[(wm * CFG::TR + row) * 2 + 1] = fmaxf(q - s * dm, 0.0f);
+            }
+        }
+        __syncthreads();
+        if (wm == 0 && half == 0) {
+#pragma unroll
+            for (int ri = 0; ri < RT; ++ri) {
+                const int row = wr * 32 * RT + ri * 32 + l31;
+                float n = 0.0f, mean = 0.0f, m2 = 0.0f;
+#pragma unroll
+                for (int w = 0; w < CFG::WM; ++w)
+                    gm_chan(n, mean, m2, np, s_st[(w * CFG::TR + row) * 2], s_st[(w * CFG::TR + row) * 2 + 1]);
+                const int r = r0 + row;
+                if (rt_valid[ri]) {
+                    float *pp = part + ((((size_t)grp * Rg + r) * views + view) * P + rloc) * 3;
+                    pp[0] = 0.0f;                                       // (S, Q, shift) with S = 0: mean = shift, M2 = Q
+                    pp[1] = m2;
+                    pp[2] = mean;
+                }
             }
         }
     }
@@ -412,15 +445,6 @@ __global__ __launch_bounds__(CFG::THREADS) void conv1x1_gemm_kernel(
 // saved for backward; (scale, shift) for the affine kernel / the next GEMM's PRO: z = act(y * scale + shift); running
 // statistics advance once per view, in order.  One workgroup per row, one wave per view.  f32 is enough here: the
 // partials are already centred on a sample of their own row, and the combination never subtracts large numbers.
-__device__ __forceinline__ void gm_chan(float &n, float &mean, float &m2, float nb, float mb, float m2b) {
-    const float nn = n + nb;
-    if (nn > 0.0f) {
-        const float delta = mb - mean, f = nb / nn;
-        mean = __builtin_fmaf(delta, f, mean);
-        m2 += m2b + delta * delta * (n * f);
-        n = nn;
-    }
-}
 // (count, mean, M2) of row c, view v from its P partials: every lane of the calling WAVE returns the same values
 __device__ __forceinline__ void gm_row_stats(const float *__restrict__ part, int c, int v, int views, int P, int wm,
                                              int tiles_range, int col_tiles_view, int lane, float &n, float &mean,
@@ -428,10 +452,10 @@ __device__ __forceinline__ void gm_row_stats(const float *__restrict__ part, int
     n = 0.0f, mean = 0.0f, m2 = 0.0f;
     for (int p = lane; p < P; p += 64) {
         const float *pp = part + (((size_t)c * views + v) * P + p) * 3;
-        const int range = p / wm;
+        const int range = p;                 // one partial per column range (the workgroup merged its wave columns)
         const int tiles = (tiles_range < col_tiles_view - range * tiles_range) ? tiles_range
                                                                                : col_tiles_view - range * tiles_range;
-        const float np = 64.0f * tiles, S = pp[0], Q = pp[1], sh = pp[2];
+        const float np = (float)wm * 64.0f * tiles, S = pp[0], Q = pp[1], sh = pp[2];
         const float dm = S / np;
         gm_chan(n, mean, m2, np, sh + dm, fmaxf(Q - S * dm, 0.0f));
     }
