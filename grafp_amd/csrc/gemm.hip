@@ -9,7 +9,8 @@
 // and Y tiles through HBM and only at stages 2-3 matrix-bound; what is fused here is what used to cost whole extra
 // passes over the activations:
 //   * STATS: per output row the shifted sums  sum(y - s), sum((y - s)^2)  of the bf16-ROUNDED outputs, accumulated in
-//     registers over all tiles of a workgroup and written as ONE partial per (row, workgroup-wave): the BatchNorm that
+//     registers over all tiles of a workgroup, merged over its wave columns in LDS and written as ONE (count, mean, M2)
+//     partial per (row, workgroup): the BatchNorm that
 //     follows needs no statistics pass (grafp_bn_finalize + grafp_bn_affine, or the next GEMM's PRO);
 //   * PRO: x -> act(x * scale[k] + shift[k]) per operand row while the tile sits in LDS: the normalised hidden
 //     activation of the FFN (4C rows, the largest tensor of a block) and of the max-relative conv are never written.
