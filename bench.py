@@ -95,7 +95,8 @@ def summarise_kernels(timed, esize=4):
             per = 2.0 if name == "bn_fwd" else 3.0
             by = sum(per * C * M * e for _, _, (C, M, e) in ev)
         elif name == "bn_affine":
-            by = sum(2.0 * C * M * 2 for _, _, (C, M) in ev)
+            # read y, write z, and read the shortcut where the layer closes a residual block
+            by = sum((3.0 if m[2] else 2.0) * m[0] * m[1] * 2 for _, _, m in ev)
         elif name == "conv1x1_wgrad":
             by = sum((co + ci) * M * 2.0 for _, _, (co, ci, g, M) in ev)
             row["tflops"] = round(sum(2.0 * co * (ci // g) * M for _, _, (co, ci, g, M) in ev) / (tot * 1e-3) / 1e12, 1)

@@ -740,7 +740,7 @@ def bn_finalize_affine(y, part, K, groups, views, gamma, beta, pre_bias, running
     pb = None if pre_bias is None else _f32c(pre_bias)
     res = None if residual is None else residual.to(torch.bfloat16).contiguous()
     z = torch.empty_like(y)
-    with _timed("bn_affine", (C, M)):
+    with _timed("bn_affine", (C, M, res is not None)):
         check(lib.grafp_bn_finalize_affine_bf16(_p(y), _p(part), C, K, groups, M, views, _p(pb), _p(g32), _p(b32),
                                                 float(eps), float(momentum), _p(running_mean), _p(running_var), _p(mean),
                                                 _p(invstd), _p(tab), _p(res), int(act), float(slope), _p(z), _stream()),
@@ -755,7 +755,7 @@ def bn_affine(y, tab, views=1, residual=None, act=ACT_NONE, slope=0.0):
     C, M = y.shape[0], y.numel() // y.shape[0]
     res = None if residual is None else residual.to(torch.bfloat16).contiguous()
     out = torch.empty_like(y)
-    with _timed("bn_affine", (C, M)):
+    with _timed("bn_affine", (C, M, res is not None)):
         check(lib.grafp_bn_affine_bf16(_p(y), C, M, views, _p(tab), _p(res), int(act), float(slope), _p(out), _stream()),
               "bn_affine")
     return out
