@@ -60,6 +60,7 @@ SIGNATURES = {
     "grafp_debug_occupy": (_I, [_I, _I, _L, _P]),
     "grafp_conv1x1_gemm_supported": (_I, [_I, _I, _I, _L, _I]),
     "grafp_conv1x1_gemm_partials": (_I, [_I, _I, _I, _L, _I]),
+    "grafp_conv1x1_gemm_plan": (_I, [_I, _I, _I, _L, _I, _P]),
     "grafp_conv1x1_gemm_bf16": (_I, [_P, _P, _I, _I, _I, _L, _I, _P, _I, _F, _P, _P, _P]),
     "grafp_conv1x1_gemm_cat_bf16": (_I, [_P, _P, _I, _P, _I, _I, _L, _P, _P]),
     "grafp_weights_prepare": (_I, [_P, _P, _I, _P]),
@@ -69,6 +70,7 @@ SIGNATURES = {
     "grafp_conv1x1_wgrad_workspace": (_Z, [_I, _I, _I, _L]),
     "grafp_conv1x1_wgrad_bf16": (_I, [_P, _P, _I, _I, _I, _L, _P, _P, _Z, _P]),
     "grafp_conv1x1_wgrad_pro_workspace": (_Z, [_I, _I, _I, _L, _I]),
+    "grafp_conv1x1_wgrad_plan": (_I, [_I, _I, _I, _L, _I, _P]),
     "grafp_conv1x1_wgrad_pro_bf16": (_I, [_P, _P, _I, _I, _I, _L, _I, _P, _I, _F, _P, _P, _Z, _P]),
     "grafp_conv1x1_wgrad_f32_workspace": (_Z, [_I, _I, _I, _L]),
     "grafp_conv1x1_wgrad_f32": (_I, [_P, _P, _I, _I, _I, _L, _P, _P, _Z, _P]),

@@ -62,6 +62,7 @@ typedef GemmCfg<2, 4, 4> GemmL;
 struct GemmPlan {
     int large;                                   // tile configuration: 0 = S, 1 = L
     int tr, tn, wm, row_tiles, col_tiles_view, ranges_view, tiles_range, nblocks, P;
+    int wgs;                                     // resident-workgroup target the column ranges were cut for
 };
 static int gemm_force_cfg() {
     static int v = -2;
@@ -96,6 +97,7 @@ static GemmPlan gemm_plan(int Rg, int K, int groups, int64_t M, int views) {
     // swept 256 ... 8192 per workgroup-per-CU, GRAFP_GEMM_WGS overrides for measurements)
     static const int wgs_env = getenv("GRAFP_GEMM_WGS") ? atoi(getenv("GRAFP_GEMM_WGS")) : 0;
     const int wgs = wgs_env > 0 ? wgs_env : ((double)(Rg + K) * groups * (double)M * 2.0 >= 750e6 ? 1024 : 512);
+    p.wgs = wgs;
     int64_t want = (int64_t)(wgs * per_cu) / ((int64_t)p.row_tiles * groups * views);
     if (want < 1) want = 1;
     int tiles_range = (int)((p.col_tiles_view + want - 1) / want);
@@ -649,6 +651,16 @@ extern "C" int grafp_conv1x1_gemm_partials(int R, int K, int groups, int64_t M, 
     using namespace grafp;
     if (!gemm_shape_ok(R, K, groups, M, views)) return 0;
     return gemm_plan(R / groups, K / groups, groups, M, views).P;
+}
+
+extern "C" int grafp_conv1x1_gemm_plan(int R, int K, int groups, int64_t M, int views, int *info) {
+    using namespace grafp;
+    GRAFP_REQUIRE(info, "conv1x1_gemm_plan: null pointer");
+    GRAFP_REQUIRE(gemm_shape_ok(R, K, groups, M, views), "conv1x1_gemm_plan: unsupported shape");
+    const GemmPlan p = gemm_plan(R / groups, K / groups, groups, M, views);
+    info[0] = p.large; info[1] = p.nblocks; info[2] = p.tiles_range; info[3] = p.P; info[4] = p.wgs;
+    info[5] = p.tr; info[6] = p.tn; info[7] = p.row_tiles;
+    return GRAFP_OK;
 }
 
 extern "C" int grafp_conv1x1_gemm_bf16(const void *w, const void *x, int R, int K, int groups, int64_t M, int views,

@@ -717,6 +717,23 @@ extern "C" int grafp_debug_wgrad_tile(int cfg) {
     return prev;
 }
 
+extern "C" int grafp_conv1x1_wgrad_plan(int Cout, int Cin, int groups, int64_t M, int views, int *info) {
+    using namespace grafp;
+    GRAFP_REQUIRE(info, "conv1x1_wgrad_plan: null pointer");
+    GRAFP_REQUIRE(Cout > 0 && Cin > 0 && groups > 0 && M > 0 && views > 0 && Cout % groups == 0 && Cin % groups == 0,
+                  "conv1x1_wgrad_plan: bad shape");
+    const int cout_g = Cout / groups, cin_g = Cin / groups;
+    for (int i = 0; i < 8; ++i) info[i] = 0;
+    if (wgrad_dma_ok(cout_g, cin_g, M, views)) {
+        const WgDmaPlan p = wgrad_dma_plan(cout_g, cin_g, groups, M, views, false);
+        info[0] = p.cfg; info[1] = p.to; info[2] = p.tc; info[3] = p.nslices; info[4] = p.tiles_o * p.tiles_c * groups;
+    } else {
+        const WgradPlan p = wgrad_plan(cout_g, cin_g, groups, M);
+        info[0] = -1; info[1] = info[2] = p.tw; info[3] = p.S; info[4] = p.tiles_o * p.tiles_c * groups;
+    }
+    return GRAFP_OK;
+}
+
 extern "C" size_t grafp_conv1x1_wgrad_pro_workspace(int Cout, int Cin, int groups, int64_t M, int views) {
     using namespace grafp;
     if (Cout <= 0 || Cin <= 0 || groups <= 0 || M <= 0 || Cout % groups || Cin % groups) return 0;

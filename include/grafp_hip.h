@@ -221,6 +221,11 @@ int grafp_debug_occupy(int blocks, int threads, int64_t clocks, grafp_stream_t s
  * (grafp_conv1x1_gemm_supported); anything else is the caller's library GEMM. */
 int grafp_conv1x1_gemm_supported(int R, int K, int groups, int64_t M, int views);
 int grafp_conv1x1_gemm_partials(int R, int K, int groups, int64_t M, int views);
+/* The launch plan grafp_conv1x1_gemm_bf16 uses for this shape (a pure function of the arguments; no reference
+ * counterpart -- it lets a caller or a test see WHICH size-dependent plan a launch takes): info (host, 8 ints) =
+ * {tile configuration, workgroups, column tiles per workgroup, partials per (row, view), resident-workgroup target,
+ *  tile rows, tile columns, row tiles}. */
+int grafp_conv1x1_gemm_plan(int R, int K, int groups, int64_t M, int views, int *info);
 int grafp_conv1x1_gemm_bf16(const void *w, const void *x, int R, int K, int groups, int64_t M, int views,
                             const float *pro_tab, int pro_act, float pro_slope, void *y, float *stats_part,
                             grafp_stream_t stream);
@@ -278,6 +283,10 @@ int grafp_conv1x1_wgrad_bf16(const void *grad_out, const void *x, int Cout, int 
  * x tile in LDS again, so the normalised activation is never materialised in either direction.  views: column segments
  * with their own table entries (a split-K slice never straddles two); pro_tab NULL = plain weight gradient. */
 size_t grafp_conv1x1_wgrad_pro_workspace(int Cout, int Cin, int groups, int64_t M, int views);
+/* The launch plan of the weight gradient for this shape (as grafp_conv1x1_gemm_plan): info (host, 8 ints) =
+ * {tile configuration (0 T, 1 S, 2 L, 3 S32, 4 M32, 5 L32, 6 SG, 7 LG; -1 = the register-staged kernel of odd shapes),
+ *  tile output rows, tile operand rows, split-K slices, output tiles, 0, 0, 0}. */
+int grafp_conv1x1_wgrad_plan(int Cout, int Cin, int groups, int64_t M, int views, int *info);
 int grafp_conv1x1_wgrad_pro_bf16(const void *grad_out, const void *x, int Cout, int Cin, int groups, int64_t M,
                                  int views, const float *pro_tab, int pro_act, float pro_slope, float *dweight,
                                  void *ws, size_t ws_bytes, grafp_stream_t stream);

@@ -117,8 +117,29 @@ def _bn(sd, name, x, train, momentum=0.1, eps=1e-5):
 
 
 def round_bf16(x):
-    """Round-to-nearest-even to bfloat16, returned as f32: the storage rounding of the bf16 mode."""
+    """Round-to-nearest-even to bfloat16, returned as f32: the storage rounding of the bf16 mode.  Under autograd the
+    GRADIENT passing through is rounded to bf16 as well (the backward of the two casts), which is where the HIP bf16
+    path stores its gradients: dY behind the BatchNorm backward, dX behind the data-gradient product."""
     return x.to(torch.bfloat16).to(torch.float32)
+
+
+class _RoundStraightThrough(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def round_bf16_weight(w):
+    """The bf16 operand copy of an f32 parameter: rounded forward, gradient passed through unrounded (the HIP path
+    accumulates and returns weight gradients in f32: grafp_conv1x1_wgrad_bf16)."""
+    return _RoundStraightThrough.apply(w)
+
+
+round_bf16.weight = round_bf16_weight
 
 
 def _conv1x1(sd, name, x, groups=1, q=None, **conv_kw):
@@ -127,7 +148,8 @@ def _conv1x1(sd, name, x, groups=1, q=None, **conv_kw):
     added in f32 by the normalisation that follows (grafp_amd/encoder/_dense.py: `pre_bias`)."""
     if q is None:
         return F.conv2d(x, sd[name + ".weight"], sd.get(name + ".bias"), groups=groups, **conv_kw)
-    y = q(F.conv2d(q(x), q(sd[name + ".weight"]), None, groups=groups, **conv_kw))
+    qw = getattr(q, "weight", q)                       # weights: rounded operand copy, f32 gradient (see round_bf16_weight)
+    y = q(F.conv2d(q(x), qw(sd[name + ".weight"]), None, groups=groups, **conv_kw))
     b = sd.get(name + ".bias")
     return y if b is None else y + b.reshape(1, -1, 1, 1)
 
