@@ -32,8 +32,14 @@ class Trainer:
         # train.py:174 (same Adam, defaults); on the GPU the update of all 271 parameter tensors is one fused launch
         # with device-side step counters instead of ~35 multi-tensor launches and 271 host-side counter bumps
         on_gpu = torch.device(device).type == "cuda"
-        # capturable: the step counters live on the device, so the whole step can be recorded into a HIP graph
-        self.opt = torch.optim.Adam(model.parameters(), lr=lr or cfg["lr"], fused=on_gpu, capturable=on_gpu)
+        # capturable: the step counters live on the device, so the whole step can be recorded into a HIP graph -- and
+        # so does the learning rate (a 0-d device tensor the scheduler updates in place): a captured Adam reads it at
+        # REPLAY time, so CosineAnnealingLR (train.py:175,224: scheduler.step() once per epoch) keeps working under
+        # step_graph instead of being frozen at its value at capture time
+        lr0 = lr or cfg["lr"]
+        if on_gpu:
+            lr0 = torch.tensor(float(lr0), dtype=torch.float32, device=device)
+        self.opt = torch.optim.Adam(model.parameters(), lr=lr0, fused=on_gpu, capturable=on_gpu)
         self._graph = None                     # (hipGraph, static x_i, static x_j, static loss) once captured
         self.sched = torch.optim.lr_scheduler.CosineAnnealingLR(self.opt, T_max=cfg["T_max"], eta_min=cfg["min_lr"])
         self.sync = gdist.GradSync(model.parameters(), group=group, n_buckets=n_buckets)
@@ -96,20 +102,24 @@ class Trainer:
             # not count as training: weights, BatchNorm statistics and optimizer state are put back afterwards, so the
             # first call is ONE step like every later one
             keep, opt_keep = self._snapshot()
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(3):
-                    self.step(sx_i, sx_j)
-            torch.cuda.current_stream().wait_stream(side)
-            if self.world == 1:
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
-                    loss = self.step(sx_i, sx_j)
-                self._graph = ("single", graph, sx_i, sx_j, loss)
-            else:
-                self._graph = self._capture_data_parallel(sx_i, sx_j)
-            self._restore(keep, opt_keep)
+            try:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(3):
+                        self.step(sx_i, sx_j)
+                torch.cuda.current_stream().wait_stream(side)
+                if self.world == 1:
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        loss = self.step(sx_i, sx_j)
+                    captured = ("single", graph, sx_i, sx_j, loss)
+                else:
+                    captured = self._capture_data_parallel(sx_i, sx_j)
+            finally:
+                # also when the warm-up or the capture raised: the caller's model is as it was before the call
+                self._restore(keep, opt_keep)
+            self._graph = captured
             return self._replay()                # capture only records: this runs the step on the batch
         sx_i, sx_j = self._graph[2], self._graph[3]
         if sx_i.shape != x_i.shape or sx_j.shape != x_j.shape:

@@ -24,10 +24,11 @@ from _common import RecordedGraphs, ReplayGraphs, filled_state_dict, simclr_inpu
 
 pytestmark = pytest.mark.gpu
 
-# measured on MI355X (both variants): activation gradients <= 2.6e-3 (median 1.3e-3), parameter gradients <= 3.4e-3;
-# one bf16 rounding step is 2^-9 = 2e-3 relative per element, and the two sides round sums formed in different orders
-BAR_ACT = 2.0 ** -7
-BAR_PARAM = 2.0 ** -7
+# measured on MI355X: activation gradients <= 2.4e-3 relative L2 (median 1.7e-3), parameter gradients <= 3.3e-3 (median
+# 1.5e-5); one bf16 rounding step is 2^-9 = 2e-3 relative per element, and the two sides round sums formed in
+# different orders -- the bars leave a factor of two
+BAR_ACT = 5e-3
+BAR_PARAM = 7e-3
 
 
 @pytest.fixture(scope="module")
@@ -164,5 +165,5 @@ def test_bf16_backward_layer_by_layer_vs_oracle_autograd(dev, monkeypatch, fused
     rows.sort(reverse=True)
     print("parameter gradients: %d compared, worst %.3e (%s), median %.3e" % (len(rows), rows[0][0], rows[0][1],
                                                                               rows[len(rows) // 2][0]))
-    assert len(rows) >= 200
+    assert len(rows) >= 150
     assert rows[0][0] <= BAR_PARAM, rows[:5]

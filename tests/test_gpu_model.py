@@ -356,6 +356,53 @@ def test_trainer_step_graph_equals_eager(dev):
         assert float(d_e.norm()) > 0 and float((d_g - d_e).norm() / d_e.norm()) < 0.05     # atomics: not bit-equal
 
 
+def test_step_graph_follows_the_scheduler_and_restores_on_failure(dev, monkeypatch):
+    """The learning rate of the captured Adam is a device tensor read at REPLAY time: CosineAnnealingLR (train.py:175,
+    224) keeps steering a replayed step (lr = 0 moves nothing, the scheduler's next value moves the weights by the
+    ratio of the rates).  If the warm-up or the capture raises, the warm-up steps are undone."""
+    from grafp_amd.train import Trainer, build_model, synthetic_batch
+    from grafp_amd.util import load_config
+    cfg = load_config()
+    cfg["bsz_train"] = 8
+    torch.manual_seed(7)
+    model = build_model(cfg, device=dev)
+    tr = Trainer(cfg, model, dev, amp_dtype=torch.bfloat16)
+    xi, xj = synthetic_batch(8, 60, dev)
+
+    def flat():
+        return torch.cat([p.detach().flatten() for p in model.parameters()]).clone()
+    # a capture that fails after the warm-up steps leaves weights, BatchNorm statistics and Adam state untouched
+    p0, b0 = flat(), [b.detach().clone() for b in model.buffers()]
+    calls = {"n": 0}
+    orig_step = tr.step
+
+    def failing_step(a, b):
+        calls["n"] += 1
+        if calls["n"] == 3:
+            raise RuntimeError("injected")
+        return orig_step(a, b)
+    monkeypatch.setattr(tr, "step", failing_step)
+    with pytest.raises(RuntimeError, match="injected"):
+        tr.step_graph(xi, xj)
+    monkeypatch.undo()
+    assert tr._graph is None and torch.equal(flat(), p0)
+    assert all(torch.equal(a, b) for a, b in zip(model.buffers(), b0))
+    # capture for real; then drive the rate
+    tr.step_graph(xi, xj)
+    lr = tr.opt.param_groups[0]["lr"]
+    assert torch.is_tensor(lr) and lr.is_cuda
+    lr.fill_(0.0)
+    before = flat()
+    tr.step_graph(xi, xj)
+    assert torch.equal(flat(), before)                       # lr = 0: Adam's update is exactly zero
+    lr.fill_(cfg["lr"])
+    tr.sched.step()                                          # in place on the same tensor
+    assert tr.opt.param_groups[0]["lr"] is lr and 0.0 < float(lr) < cfg["lr"]
+    tr.step_graph(xi, xj)
+    moved = float((flat() - before).abs().max())
+    assert 0.0 < moved <= 10.0 * float(lr)                   # Adam: |update| ~ lr per element
+
+
 def test_trainer_with_device_augmentation_eager_and_graph(dev):
     """The training step with the second view augmented on the device (impulse responses + background noise for
     every clip): runs eagerly and replayed from one HIP graph (the per-clip draws use the device generator, which
