@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--no-config2", action="store_true", help="skip the 256-pair legs (eager, HIP graph, f32)")
     ap.add_argument("--kernel-steps", type=int, default=3, help="steps of the separate per-kernel timing pass")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=25.0)
+    ap.add_argument("--backend", default=None, help="test hook: process-group backend (default nccl = RCCL)")
+    ap.add_argument("--local-device", type=int, default=None, help="test hook: device index of every rank (ranks share a GPU)")
     return ap.parse_args()
 
 
@@ -276,7 +278,7 @@ def main():
     from grafp_amd.train import Trainer, build_model, synthetic_batch
     from grafp_amd.util import load_config
 
-    rank, world, device = gdist.init_from_env()
+    rank, world, device = gdist.init_from_env(backend=args.backend, local_device=args.local_device)
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (the hot path has no CPU fallback)"
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.backends.cudnn.benchmark = False

@@ -23,15 +23,16 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None):
-    """RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as set by torch.distributed.run.  Returns (rank, world, device)."""
+def init_from_env(backend=None, local_device=None):
+    """RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as set by torch.distributed.run.  Returns (rank, world, device).
+    backend / local_device: for a box with fewer GPUs than ranks (the tests run two ranks on cuda:0 over gloo: same
+    code path, no RCCL); production leaves both None (one GPU per rank = LOCAL_RANK, RCCL)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if torch.cuda.is_available():
-        # GRAFP_LOCAL_DEVICE / GRAFP_DIST_BACKEND: test hooks for a box with fewer GPUs than ranks (several ranks
-        # share one device over gloo: same code path, no RCCL); unset in production
-        local = int(os.environ.get("GRAFP_LOCAL_DEVICE", local))
+        if local_device is not None:
+            local = int(local_device)
         torch.cuda.set_device(local)
         device = torch.device("cuda", local)
     else:
@@ -39,7 +40,7 @@ def init_from_env(backend=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        backend = backend or os.environ.get("GRAFP_DIST_BACKEND") or ("nccl" if device.type == "cuda" else "gloo")
+        backend = backend or ("nccl" if device.type == "cuda" else "gloo")
         kw = {"device_id": device} if backend == "nccl" else {}
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return rank, world, device

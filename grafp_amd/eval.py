@@ -19,15 +19,19 @@ from . import ops
 from .ops import FlatL2Index
 
 
+# True: eval_faiss(index_type='ivfpq') is served by the exact index (a superset in accuracy, and faster on this GPU)
+SERVE_IVFPQ_EXACTLY = False
+
+
 def get_index(index_type, train_data, train_data_shape, use_gpu=True, max_nitem_train=2e7, n_centroids=64):
     """eval.py:9-123.  'l2' -> the exact brute-force index (ops.FlatL2Index); 'ivfpq' -> the IVF-PQ index of the
     published protocol (grafp_amd.ivfpq.IVFPQIndex: n_centroids lists, 64 x 8-bit codes, trained on at most
     max_nitem_train rows of train_data with a seeded k-means, nprobe = 20); every other faiss type ('ivf', 'ivfpq-rr',
     'lsh', 'hnsw': approximations of the same search) is served by the exact index, a superset in accuracy.
-    GRAFP_EXACT_INDEX=1 serves 'ivfpq' exactly too."""
+    `eval.SERVE_IVFPQ_EXACTLY = True` serves 'ivfpq' exactly too."""
     mode = str(index_type).lower()
     d = int(train_data_shape[1])
-    if mode == "ivfpq" and os.environ.get("GRAFP_EXACT_INDEX", "0") != "1":
+    if mode == "ivfpq" and not SERVE_IVFPQ_EXACTLY:
         from .ivfpq import IVFPQIndex
         index = IVFPQIndex(d, nlist=int(n_centroids), M=64 if d % 64 == 0 else d, nbits=8)
         n = len(train_data)

@@ -30,6 +30,9 @@ def _write_memmap(path_noext, arr):
     np.save(path_noext + "_shape.npy", shape)
 
 
+FORCE_STAGING = False      # tests: take the pinned-staging path even where hipHostRegister accepts the file pages
+
+
 class _MemmapAppender:
     """Streams (n_i, d) float32 blocks into `<name>.mm` (the raw row-major file np.memmap reads, eval.py:151-163) and
     writes `<name>_shape.npy` at the end; no second copy of the whole database exists in host memory.
@@ -40,7 +43,7 @@ class _MemmapAppender:
         HIP runtime (hipHostRegister accepts file-backed MAP_SHARED pages on this stack: measured 33 GB/s device -> file
         pages, tools/hostreg_probe.py), so a block is ONE asynchronous DMA from HBM into the page cache of the output
         file on a side stream -- no host copy at all, and the next model call is already running;
-      * STAGING (registration refused, or GRAFP_FPDB_STAGING=1): device -> two alternating pinned staging slots on the
+      * STAGING (registration refused, or `fpdb.FORCE_STAGING = True`): device -> two alternating pinned staging slots on the
         side stream, each drained with one memcpy into the memmap when it comes round again.
     The file grows sparsely window by window and is truncated to the rows written on close()."""
 
@@ -50,7 +53,7 @@ class _MemmapAppender:
         self.path, self.rows, self.dim = path_noext, 0, None
         self.slot_rows = int(slot_rows)
         self._win, self._win_lo, self._win_t, self._registered = None, 0, None, False
-        self._direct = os.environ.get("GRAFP_FPDB_STAGING", "0") != "1"
+        self._direct = not FORCE_STAGING
         self._slots, self._next, self._side = None, 0, None
         open(path_noext + ".mm", "wb").close()
 

@@ -38,6 +38,19 @@ def _f32c(t):
     return t.detach().to(torch.float32).contiguous()
 
 
+class _Switches:
+    """A/B switches of the host glue for tests and measurement tools (tests/, tools/): plain attributes read at call
+    time and set by the test or tool itself.  The product path reads NO environment variable for its behaviour."""
+    bn_two_pass = False           # True: the two-kernel BatchNorm (statistics, then apply) instead of the single pass
+    grouped_bmm_min = 128         # f32 mode: channels per group from which a grouped conv runs as a batched library GEMM
+    wgrad_f32_library = False     # True: f32 weight gradients by the library GEMM instead of the split-bf16 kernel
+    fused_conv_bn = True          # False: library GEMM + fused BatchNorm kernel pair instead of conv1x1_gemm (bf16 mode)
+    shortcut_fusion = True        # False: autograd's accumulate kernel instead of the [W^T | I] data-gradient product
+
+
+switches = _Switches()
+
+
 # ------------------------------------------------------------------------------------------------
 # Optional per-kernel timing with HIP events on the launch stream (bench.py's roofline block)
 # ------------------------------------------------------------------------------------------------
@@ -367,9 +380,9 @@ _BN_SYNC = {}
 
 def _bn_sync(device, C, M):
     """The rendezvous buffer of the single-pass BatchNorm kernels: filled with ones once per (device, stream); every
-    call leaves it that way (include/grafp_hip.h, grafp_bn_fwd_1pass).  GRAFP_BN_TWO_PASS=1 selects the two-pass
+    call leaves it that way (include/grafp_hip.h, grafp_bn_fwd_1pass).  switches.bn_two_pass selects the two-pass
     kernels (None)."""
-    if os.environ.get("GRAFP_BN_TWO_PASS", "0") == "1":
+    if switches.bn_two_pass:
         return None
     key = (device, torch.cuda.current_stream(device).cuda_stream)
     buf = _BN_SYNC.get(key)
@@ -494,9 +507,6 @@ def _block_diag_weight(w, groups, dtype=None):
     return out.reshape(cout, groups * cin_g)
 
 
-_GROUPED_BMM_MIN = int(os.environ.get("GRAFP_GROUPED_BMM_MIN", "128"))   # channels per group from which the grouped conv runs as a batched GEMM
-
-
 class _Conv1x1(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, groups, w_lowp=None):
@@ -506,7 +516,7 @@ class _Conv1x1(torch.autograd.Function):
         # w may be the 4-D Conv2d parameter itself (Cout, Cin/g, 1, 1): taking it un-reshaped keeps a view node out of
         # the graph, so the weight gradient returned below is adopted as .grad without a copy
         w2 = w.detach().reshape(w.shape[0], -1)
-        batched = groups > 1 and w2.shape[1] >= _GROUPED_BMM_MIN and x.is_cuda
+        batched = groups > 1 and w2.shape[1] >= switches.grouped_bmm_min and x.is_cuda
         if batched:
             # wide groups (stages 2-3: 128 / 256 channels per group): a `groups`-batch GEMM; the dense block-diagonal
             # form spends 4x the flops, which at 1024 x 1024 is no longer free next to the operand traffic
@@ -549,9 +559,9 @@ class _Conv1x1(torch.autograd.Function):
                 with _timed("conv1x1_wgrad", (cout, cin, groups, M)):
                     check(lib.grafp_conv1x1_wgrad_bf16(_p(g), _p(x), cout, cin, groups, M, _p(dw), _p(ws), nbytes,
                                                        _stream()), "conv1x1_wgrad")
-            elif x.dtype == torch.float32 and x.is_cuda and os.environ.get("GRAFP_WGRAD_F32_LIBRARY", "0") != "1":
+            elif x.dtype == torch.float32 and x.is_cuda and not switches.wgrad_f32_library:
                 # f32 step: split-bf16 (hi/lo) x 3 MFMAs inside the same streaming kernel; the library's f32 GEMM
-                # runs this tall-K shape ~3.5x slower (GRAFP_WGRAD_F32_LIBRARY=1 selects it)
+                # runs this tall-K shape ~3.5x slower (switches.wgrad_f32_library selects it)
                 dw = torch.empty((cout, cin_g), dtype=torch.float32, device=x.device)
                 nbytes = lib.grafp_conv1x1_wgrad_f32_workspace(cout, cin, groups, M)
                 ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
@@ -873,14 +883,12 @@ def conv_bn_act_supported(x, cout, conv_groups, views):
     """The fused bf16 path applies to HIP bf16 (K, M) rows whose shape both GEMMs (forward, data gradient) accept."""
     if not (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 2):
         return False
-    if os.environ.get("GRAFP_LIBRARY_GEMM", "0") == "1":
-        return False
     K, M = x.shape
     return conv_bn_act_shape_supported(K, M, cout, conv_groups, views)
 
 
 def conv_bn_act_shape_supported(K, M, cout, conv_groups, views):
-    if os.environ.get("GRAFP_LIBRARY_GEMM", "0") == "1":
+    if not switches.fused_conv_bn:
         return False
     return gemm_supported(cout, K, conv_groups, M, views) and gemm_supported(K, cout, conv_groups, M, 1)
 
@@ -898,7 +906,7 @@ def conv_bn_act(x, w, gamma, beta, running_mean, running_var, training, momentum
 
 def shortcut_token_supported(x, conv_groups=1):
     """The fused shortcut gradient needs the (K, K + K) x M data-gradient product of the block's first layer."""
-    if os.environ.get("GRAFP_NO_SHORTCUT_FUSION", "0") == "1" or conv_groups != 1:
+    if not switches.shortcut_fusion or conv_groups != 1:
         return False
     K, M = x.shape
     return x.is_cuda and x.dtype == torch.bfloat16 and bool(lib.grafp_conv1x1_gemm_supported(K, 2 * K, 1, M, 1))

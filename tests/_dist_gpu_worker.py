@@ -1,5 +1,5 @@
-"""Worker of tests/test_gpu_dist.py: one of WORLD_SIZE ranks sharing cuda:0 over gloo (GRAFP_LOCAL_DEVICE=0,
-GRAFP_DIST_BACKEND=gloo).  Runs one data-parallel training step on its shard of a fixed batch with the real HIP
+"""Worker of tests/test_gpu_dist.py: one of WORLD_SIZE ranks sharing cuda:0 over gloo
+(init_from_env(backend='gloo', local_device=0)).  Runs one data-parallel training step on its shard of a fixed batch with the real HIP
 kernels and writes its loss share, a few all-reduced gradients and its sharded-search result to OUT.rank.pt."""
 import os
 import sys
@@ -16,7 +16,7 @@ from grafp_amd.util import load_config                                 # noqa: E
 def graph_mode(out, B):
     """Trainer.step_graph under data parallelism (three graphs, eager collectives between) against Trainer.step from
     the same weights and optimizer state, on this rank's shard: losses and parameter updates."""
-    rank, world, device = gdist.init_from_env()
+    rank, world, device = gdist.init_from_env(backend="gloo", local_device=0)
     cfg = load_config()
     cfg["bsz_train"] = B
     torch.manual_seed(1234)
@@ -63,7 +63,7 @@ def main():
     out, B = sys.argv[1], int(sys.argv[2])
     if len(sys.argv) > 3 and sys.argv[3] == "graph":
         return graph_mode(out, B)
-    rank, world, device = gdist.init_from_env()
+    rank, world, device = gdist.init_from_env(backend="gloo", local_device=0)
     cfg = load_config()
     cfg["bsz_train"] = B
     torch.manual_seed(1234)

@@ -94,7 +94,8 @@ def _rel(got, want):
 def test_bf16_backward_layer_by_layer_vs_oracle_autograd(dev, monkeypatch, fused):
     from grafp_amd.simclr.ntxent import ntxent_loss
     from oracle import model as om
-    monkeypatch.setenv("GRAFP_NO_SHORTCUT_FUSION", "0" if fused else "1")
+    from grafp_amd import ops
+    monkeypatch.setattr(ops.switches, "shortcut_fusion", bool(fused))
     cfg, model = _model(dev)
     model.train()
     xi, xj = simclr_inputs()
@@ -130,7 +131,6 @@ def test_bf16_backward_layer_by_layer_vs_oracle_autograd(dev, monkeypatch, fused
     assert abs(float(loss) - float(loss_o)) <= 1e-4 * abs(float(loss_o))
     loss.backward()                                    # readout + projector + NT-Xent: down to the last forced leaf
     if fused:
-        from grafp_amd import ops
         tokens_used = []
         orig_cat = ops.conv1x1_gemm_cat
         monkeypatch.setattr(ops, "conv1x1_gemm_cat", lambda *a, **k: (tokens_used.append(1), orig_cat(*a, **k))[1])

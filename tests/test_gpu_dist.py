@@ -19,8 +19,7 @@ def _launch(world, out, B, extra=()):
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT="29653", GRAFP_LOCAL_DEVICE="0", GRAFP_DIST_BACKEND="gloo",
-                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   MASTER_PORT="29653", HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_dist_gpu_worker.py"), out, str(B), *extra],
                                       env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
@@ -164,11 +163,10 @@ def test_bench_two_ranks_one_gpu(tmp_path):
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT="29654", GRAFP_LOCAL_DEVICE="0", GRAFP_DIST_BACKEND="gloo",
-                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   MASTER_PORT="29654", HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
                                        "--warmup", "1", "--global-batch", "32", "--kernel-steps", "1",
-                                       "--no-cpu-baseline"],
+                                       "--no-cpu-baseline", "--backend", "gloo", "--local-device", "0"],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     logs = []
     for p in procs:

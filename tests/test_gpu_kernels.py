@@ -563,7 +563,7 @@ def test_bn_single_pass_equals_two_pass(dev, monkeypatch, C, M, G, dt):
     pb = 0.5 * torch.randn(C, device=dev, generator=gen)
 
     def run(two_pass):
-        monkeypatch.setenv("GRAFP_BN_TWO_PASS", "1" if two_pass else "0")
+        monkeypatch.setattr(ops.switches, "bn_two_pass", bool(two_pass))
         xg = x.clone().requires_grad_(True); gg = gamma.clone().requires_grad_(True); bg = beta.clone().requires_grad_(True)
         rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
         out = ops.bn_act(xg, gg, bg, rm, rv, True, 0.1, 1e-5, pb, res, 2, 0.2, G)
@@ -619,7 +619,7 @@ def test_conv1x1_wgrad_f32_split_bf16(dev, monkeypatch, cout, cin, groups, M):
         ops.conv1x1_rows(xg, wg, groups).backward(g)
         return wg.grad
     got = run()
-    monkeypatch.setenv("GRAFP_WGRAD_F32_LIBRARY", "1")
+    monkeypatch.setattr(ops.switches, "wgrad_f32_library", True)
     lib_ = run()
     xd, gd = x.double(), g.double()
     want = torch.cat([gd.reshape(groups, cout // groups, M)[i] @ xd.reshape(groups, cin // groups, M)[i].t()
@@ -935,5 +935,6 @@ def test_eval_faiss_with_the_ivfpq_index(dev, tmp_path, monkeypatch):
     approx = eval_faiss(str(tmp_path), index_type="ivfpq", n_centroids=8, **kw)
     assert approx.shape == g["hit_rates"].shape
     assert np.abs(approx - g["hit_rates"]).max() <= 10.0 and approx[3].min() >= g["hit_rates"][3].min() - 10.0   # 40 ids: 2.5 pt each
-    monkeypatch.setenv("GRAFP_EXACT_INDEX", "1")
+    import grafp_amd.eval as geval
+    monkeypatch.setattr(geval, "SERVE_IVFPQ_EXACTLY", True)
     np.testing.assert_array_equal(eval_faiss(str(tmp_path), index_type="ivfpq", **kw), g["hit_rates"])

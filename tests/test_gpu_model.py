@@ -466,8 +466,8 @@ def test_db_writers_device_stream_and_part_files(dev, tmp_path, monkeypatch, sta
     through two pinned staging slots (small windows and slots here, so that window changes, both slots and the file
     growth are exercised); the shard-aware layout (one part file per rank, contiguous track ranges) reads back as the
     same rows through load_memmap_data and as per-rank slices."""
-    monkeypatch.setenv("GRAFP_FPDB_STAGING", staging)
     from grafp_amd import fpdb
+    monkeypatch.setattr(fpdb, "FORCE_STAGING", staging == "1")
     from grafp_amd.eval import PartedRows, load_memmap_data
     from grafp_amd.modules.transformations import GPUTransformNeuralfp
     cfg, model = _filled_model(dev)
@@ -516,7 +516,8 @@ def test_shortcut_gradient_fused_into_data_gradient(dev, monkeypatch):
     state = {k: v.clone() for k, v in model.state_dict().items()}
 
     def grads(fused):
-        monkeypatch.setenv("GRAFP_NO_SHORTCUT_FUSION", "0" if fused else "1")
+        from grafp_amd import ops
+        monkeypatch.setattr(ops.switches, "shortcut_fusion", bool(fused))
         model.load_state_dict(state)
         model.train()
         for p in model.parameters():
