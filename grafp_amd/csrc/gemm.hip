@@ -26,52 +26,52 @@
 // The W tile rows are 64 B; their 16-byte slots are swizzled by (r >> 2) & 3 the same way (ds_read_b128).
 #include "common.h"
 #include "dma_ring.h"
+#include "tuning.h"
 
 namespace grafp {
 
 constexpr int GM_KC = 32;                      // contraction per chunk
-constexpr int GM_OUT_BYTES = 32 * 128;         // per-wave output staging: 32 rows (r) x 64 m bf16
-constexpr int GM_DMA_PER_CHUNK = 4;            // LDS-DMA instructions per wave and chunk (2 W + 2 X) in both configs
-constexpr int GM_STORES_PER_RT = 4;
-#ifndef GM_NT
-#define GM_NT 1
-#endif
-#ifndef GM_ABLATE            // measurement builds (tools/gemm_ablate.sh): 1 = no DMA in the main loop, 2 = no epilogue,
-#define GM_ABLATE 0          // 4 = no MFMA, 8 = all stores to one L2-resident tile; sums.  Results are wrong for every value but 0.
-#endif
-constexpr bool NT_STORE = GM_NT != 0;   // streaming (nt) stores of Y            // 16-byte store instructions per wave and 32-row output tile
+constexpr int GM_STORES_PER_RT = 4;            // 16-byte store instructions per wave and 32-row output tile
 
-// Tile configurations: WR x WM waves, each wave RT x 2 MFMA tiles (32 RT rows x 64 columns).
-//   S: 2 x 2 waves, RT 2 -> 128 x 128 tile, 4 waves, 2 workgroups per CU: the streaming shapes (stages 0-1), where what
-//      matters is X/Y bytes in flight per CU;
-//   L: 2 x 4 waves, RT 4 -> 256 x 256 tile, 8 waves, 1 workgroup per CU: the matrix-heavy shapes (stages 2-3).  The S
-//      tile moves 16 KB of operands through the LDS-DMA path per 1 MFLOP (64 flop/B) and that path saturates at about
-//      9 TB/s chip-wide (measured: 580-820 TFLOP/s on every stage 2-3 shape); the L tile moves 32 KB per 4 MFLOP.
-template <int WR_, int WM_, int RT_> struct GemmCfg {
-    static constexpr int WR = WR_, WM = WM_, RT = RT_, NW = WR_ * WM_, THREADS = 64 * NW;
+// Tile configurations: WR x WM waves, each wave RT x 2 MFMA tiles (32 RT rows x 64 columns); OR = rows of the per-wave
+// output staging slab (32: a whole 32-row MFMA tile is transposed at once; 16: in two halves, which frees 2 KB of LDS
+// per wave for a fourth ring stage).
+//   S:    2 x 2 waves, RT 2 -> 128 x 128, 4 waves, 2 workgroups per CU: small problems and shapes no wider tile divides;
+//   L:    2 x 4 waves, RT 4 -> 256 x 256, 8 waves, 1 workgroup per CU: >= 256 output rows per group.  The S tile moves
+//         16 KB of operands through the LDS-DMA path per 1 MFLOP (64 flop/B) and that path saturates at about 9 TB/s
+//         chip-wide (measured: 580-820 TFLOP/s on every stage 2-3 shape); the L tile moves 32 KB per 4 MFLOP;
+//   N32 / N64 / N128: 1 x 8 waves side by side, RT 1 / 2 / 4 -> 32 / 64 / 128 rows x 512 columns (round 3): the layers
+//         with <= 128 output rows per group (stages 0-1, every grouped convolution of stages 0-1, the data gradients
+//         into C rows).  On the 256-row tile such a launch spent 2-8x its flops on rows that do not exist (s0 ffn2,
+//         R = 64, K = 256: 275 GFLOP issued for 69 useful -- the kernel was MFMA-bound on garbage at 4.4 TB/s) and half
+//         of every ring stage on a duplicated W tile; here a stage is [W R x 32 | X 32 x 512]: 32 KB of X per stage,
+//         1 KB row segments, 96 KB of the operand that comes from HBM in flight per CU instead of 48.
+template <int WR_, int WM_, int RT_, int OR_ = 32> struct GemmCfg {
+    static constexpr int WR = WR_, WM = WM_, RT = RT_, OR = OR_, NW = WR_ * WM_, THREADS = 64 * NW;
     static constexpr int TR = WR_ * RT_ * 32, TN = WM_ * 64;
+    static constexpr int NA = TR / 16, NB = TN / 16, NI = NA + NB;   // 1-KiB LDS-DMA instructions per chunk: W, X, all
+    static constexpr int PER = (NI + NW - 1) / NW;                   // ... per wave (a wave's last one may not exist)
     static constexpr int A_BYTES = TR * GM_KC * 2, B_BYTES = GM_KC * TN * 2, STAGE = A_BYTES + B_BYTES;
     static constexpr int ROWB = TN * 2;                   // bytes per X tile row
     static constexpr int SLOTS = TN / 8;                  // 16-byte slots per X tile row
     static constexpr int RPI = 64 / SLOTS;                // X tile rows per DMA instruction
-    static_assert(TR / 16 / NW == 2 && TN / 16 / NW == 2, "two W and two X DMA instructions per wave and chunk");
+    static constexpr int OUT_BYTES = OR_ * 128;           // per-wave output staging: OR rows (r) x 64 m bf16
+    static constexpr int PRO_PIECES = TN / (16 * NW);     // PRO: 16-byte X pieces per thread and chunk
+    static_assert(SLOTS <= 64 && 64 % SLOTS == 0 && A_BYTES == NA * 1024 && B_BYTES == NB * 1024, "1-KiB DMA pieces");
+    static_assert(OR_ == 32 || OR_ == 16, "staging slab");
 };
 typedef GemmCfg<2, 2, 2> GemmS;
 typedef GemmCfg<2, 4, 4> GemmL;
+typedef GemmCfg<1, 8, 1, 16> GemmN32;
+typedef GemmCfg<1, 8, 2, 16> GemmN64;
+typedef GemmCfg<1, 8, 4, 32> GemmN128;
+enum { GM_CFG_S = 0, GM_CFG_L = 1, GM_CFG_N32 = 2, GM_CFG_N64 = 3, GM_CFG_N128 = 4 };
 
 struct GemmPlan {
-    int large;                                   // tile configuration: 0 = S, 1 = L
-    int tr, tn, wm, row_tiles, col_tiles_view, ranges_view, tiles_range, nblocks, P;
+    int cfg;                                     // tile configuration (GM_CFG_*)
+    int tr, tn, wm, ns, row_tiles, col_tiles_view, ranges_view, tiles_range, nblocks, P;
     int wgs;                                     // resident-workgroup target the column ranges were cut for
 };
-static int gemm_force_cfg() {
-    static int v = -2;
-    if (v == -2) {
-        const char *e = getenv("GRAFP_GEMM_TILE");           // "S" / "L": force a configuration (measurements)
-        v = !e ? -1 : (e[0] == 'L' ? 1 : 0);
-    }
-    return v;
-}
 // R rows per conv group, M columns, `views` column segments with separate statistics (a range never straddles two)
 static GemmPlan gemm_plan(int Rg, int K, int groups, int64_t M, int views) {
     GemmPlan p;
@@ -83,20 +83,33 @@ static GemmPlan gemm_plan(int Rg, int K, int groups, int64_t M, int views) {
     // >= 2^20 columns (stage 0 at 1024 pairs per GPU), where its 512-byte row segments stream best
     bool large = (Rg >= 512 || (Rg >= 256 && (K >= 512 || 4 * K <= Rg || Mg >= (1 << 18))) || Mg >= (1 << 20)) &&
                  Mg % GemmL::TN == 0;
-    if (gemm_force_cfg() >= 0) large = gemm_force_cfg() == 1 && Mg % GemmL::TN == 0;
-    p.large = large ? 1 : 0;
-    p.tr = large ? GemmL::TR : GemmS::TR;
-    p.tn = large ? GemmL::TN : GemmS::TN;
-    p.wm = large ? GemmL::WM : GemmS::WM;
-    const int per_cu = large ? 1 : 2;
+    p.cfg = large ? GM_CFG_L : GM_CFG_S;
+    // <= 128 rows per group: the 512-column tiles (see above), from 2^16 columns per view (below that the S tile's many
+    // small workgroups fill the chip better)
+    const int64_t n_from = GRAFP_TUNE_INT("GRAFP_GEMM_N_FROM", 1 << 16);
+    if (Rg <= 128 && Mg % GemmN64::TN == 0 && Mg >= n_from)
+        p.cfg = Rg <= 32 ? GM_CFG_N32 : Rg <= 64 ? GM_CFG_N64 : GM_CFG_N128;
+    const int force = GRAFP_TUNE_INT("GRAFP_GEMM_CFG", -1);                 // measurement builds only (tuning.h)
+    if (force == GM_CFG_S || (force == GM_CFG_L && Mg % GemmL::TN == 0) ||
+        (force >= GM_CFG_N32 && force <= GM_CFG_N128 && Mg % GemmN64::TN == 0))
+        p.cfg = force;
+    static const int trs[5] = {GemmS::TR, GemmL::TR, GemmN32::TR, GemmN64::TR, GemmN128::TR};
+    static const int tns[5] = {GemmS::TN, GemmL::TN, GemmN32::TN, GemmN64::TN, GemmN128::TN};
+    p.tr = trs[p.cfg];
+    p.tn = tns[p.cfg];
+    p.wm = p.tn / 64;
+    // ring depth: S keeps 2 workgroups per CU (80 KB each: 4 stages); the others are alone on their CU and take what
+    // the 160 KB hold beside the staging slabs; 3 stages everywhere beside a PRO table (gemm_dispatch)
+    p.ns = p.cfg == GM_CFG_N128 ? 3 : 4;
+    const int per_cu = p.cfg == GM_CFG_S ? 2 : 1;
     p.row_tiles = (Rg + p.tr - 1) / p.tr;
     p.col_tiles_view = (int)(Mg / p.tn);
     const int nch = K / GM_KC;
     // two rounds of resident workgroups, but at least ~8 chunks per workgroup to amortise the pipeline fill
     // (four rounds once the launch streams >= 750 MB: -3 % over all layers at 2048 clip-views, nothing below;
-    // swept 256 ... 8192 per workgroup-per-CU, GRAFP_GEMM_WGS overrides for measurements)
-    static const int wgs_env = getenv("GRAFP_GEMM_WGS") ? atoi(getenv("GRAFP_GEMM_WGS")) : 0;
-    const int wgs = wgs_env > 0 ? wgs_env : ((double)(Rg + K) * groups * (double)M * 2.0 >= 750e6 ? 1024 : 512);
+    // swept 256 ... 8192 per workgroup-per-CU)
+    const int wgs_dflt = (double)(Rg + K) * groups * (double)M * 2.0 >= 750e6 ? 1024 : 512;
+    const int wgs = GRAFP_TUNE_INT("GRAFP_GEMM_WGS", 0) > 0 ? GRAFP_TUNE_INT("GRAFP_GEMM_WGS", 0) : wgs_dflt;
     p.wgs = wgs;
     int64_t want = (int64_t)(wgs * per_cu) / ((int64_t)p.row_tiles * groups * views);
     if (want < 1) want = 1;
@@ -133,10 +146,10 @@ __global__ __launch_bounds__(CFG::THREADS) void conv1x1_gemm_kernel(
     const float2 *__restrict__ pro_tab, int pro_act, float pro_slope, float *__restrict__ part, int P, int nblocks,
     const unsigned short *__restrict__ X2 = nullptr, int K1 = 0) {
     constexpr int D = NS - 1;                               // chunks in flight
-    constexpr int RT = CFG::RT, TN = CFG::TN, ROWB = CFG::ROWB;
+    constexpr int RT = CFG::RT, TN = CFG::TN, ROWB = CFG::ROWB, PER = CFG::PER, OR = CFG::OR;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *const s_out = smem + NS * CFG::STAGE;              // NW x GM_OUT_BYTES
-    unsigned char *const s_tab = s_out + CFG::NW * GM_OUT_BYTES;      // PRO: K x float2 (scale, shift) of this view
+    unsigned char *const s_out = smem + NS * CFG::STAGE;              // NW x OUT_BYTES
+    unsigned char *const s_tab = s_out + CFG::NW * CFG::OUT_BYTES;    // PRO: K x float2 (scale, shift) of this view
 
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // scalar: everything derived stays in SGPRs
@@ -161,51 +174,55 @@ __global__ __launch_bounds__(CFG::THREADS) void conv1x1_gemm_kernel(
         for (int k = tid; k < K; k += CFG::THREADS) reinterpret_cast<float2 *>(s_tab)[k] = src[(size_t)k * views + view];
     }
 
-    // ---- DMA source addresses of this lane (LDS side is lane-linear: stage + instruction * 1 KiB + lane * 16) ----
-    // W chunk: instruction q = 2*wave + j covers rows 16q .. 16q+15 (64 B each); slot' = lane & 3 holds source slot
-    //          slot' ^ ((row >> 2) & 3)
-    const unsigned short *a_src[2];
+    // ---- the chunk's NI LDS-DMA instructions (1 KiB each: 64 lanes x 16 bytes; W rows first, then X rows) are dealt to
+    //      the waves round robin: this wave issues q = wave + j * NW.  LDS side lane-linear: stage + q KiB + lane * 16.
+    // W piece q < NA: rows 16q .. 16q+15 (64 B each); slot' = lane & 3 holds source slot slot' ^ ((row >> 2) & 3)
+    // X piece q - NA: RPI k-rows (ROWB bytes each); 16-byte slot s' = lane % SLOTS of its row holds source segment
+    //          (s' >> 2) ^ (row & 3) (low two bits of the 64-byte segment index), piece s' & 3
+    const unsigned short *src[PER], *src2[PER];
+    bool is_w[PER];
+    int my_dma = 0;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        int row = r0 + 16 * (2 * wave + j) + (lane >> 2);
-        if (row > Rg - 1) row = Rg - 1;                      // rows beyond R: duplicates, never stored
-        const int slot = (lane & 3) ^ ((lane >> 4) & 3);
-        a_src[j] = A + (size_t)row * lda + slot * 8;
+    for (int j = 0; j < PER; ++j) {
+        const int q = wave + j * CFG::NW;                    // scalar
+        is_w[j] = q < CFG::NA;
+        src2[j] = nullptr;
+        if (q < CFG::NI) ++my_dma;
+        if (is_w[j]) {
+            int row = r0 + 16 * q + (lane >> 2);
+            if (row > Rg - 1) row = Rg - 1;                  // rows beyond R: duplicates, never stored
+            const int slot = (lane & 3) ^ ((lane >> 4) & 3);
+            src[j] = A + (size_t)row * lda + slot * 8;
+        } else {
+            const int row = CFG::RPI * (q - CFG::NA) + lane / CFG::SLOTS;
+            const int sl = lane % CFG::SLOTS;
+            const int seg = (sl >> 2) ^ (row & 3);
+            src[j] = X + (size_t)row * M + col0 + (seg * 4 + (sl & 3)) * 8;
+            if (CAT) src2[j] = X2 + (src[j] - X);
+        }
     }
-    // X chunk: instruction q covers RPI k-rows (ROWB bytes each); 16-byte slot s' = lane % SLOTS of its row holds
-    //          source segment (s' >> 2) ^ (row & 3) (low two bits of the 64-byte segment index), piece s' & 3
-    const unsigned short *b_src[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int row = CFG::RPI * (2 * wave + j) + lane / CFG::SLOTS;
-        const int sl = lane % CFG::SLOTS;
-        const int seg = (sl >> 2) ^ (row & 3);
-        b_src[j] = X + (size_t)row * M + col0 + (seg * 4 + (sl & 3)) * 8;
-    }
-    const unsigned short *b_src2[2] = {nullptr, nullptr};
     const int nch1 = CAT ? K1 / GM_KC : nch;
-    if (CAT) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) b_src2[j] = X2 + (b_src[j] - X);
-    }
     int is_ch = 0;                                           // chunk-in-tile of the next chunk to issue
     auto issue = [&](int t) {
-        const unsigned st = lds0 + (t % NS) * CFG::STAGE + 2 * wave * 1024;
+        const unsigned st = lds0 + (t % NS) * CFG::STAGE + wave * 1024;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            gm_dma16(a_src[j] + is_ch * GM_KC, st + j * 1024);
-            const unsigned short *xs = b_src[j] + (size_t)is_ch * GM_KC * M;
-            if (CAT && is_ch >= nch1) xs = b_src2[j] + (size_t)(is_ch - nch1) * GM_KC * M;
-            gm_dma16(xs, st + CFG::A_BYTES + j * 1024);
+        for (int j = 0; j < PER; ++j) {
+            if (wave + j * CFG::NW < CFG::NI) {              // scalar: false only for the last piece of some waves
+                const unsigned short *g;
+                if (is_w[j]) g = src[j] + is_ch * GM_KC;
+                else if (CAT && is_ch >= nch1) g = src2[j] + (size_t)(is_ch - nch1) * GM_KC * M;
+                else g = src[j] + (size_t)is_ch * GM_KC * M;
+                gm_dma16(g, st + j * (CFG::NW * 1024));
+            }
         }
         if (++is_ch == nch) {
             is_ch = 0;
-            b_src[0] += TN;
-            b_src[1] += TN;
-            if (CAT) {
-                b_src2[0] += TN;
-                b_src2[1] += TN;
-            }
+#pragma unroll
+            for (int j = 0; j < PER; ++j)
+                if (!is_w[j]) {
+                    src[j] += TN;
+                    if (CAT) src2[j] += TN;
+                }
         }
     };
 
@@ -264,10 +281,10 @@ __global__ __launch_bounds__(CFG::THREADS) void conv1x1_gemm_kernel(
     for (int c = 0; c < D; ++c)
         if (c < T) {
             issue(c);
-            if (c >= 1) dma_hist[D - 1 - c] = GM_DMA_PER_CHUNK;
+            if (c >= 1) dma_hist[D - 1 - c] = my_dma;
         }
 
-    unsigned char *const my_out = s_out + wave * GM_OUT_BYTES;
+    unsigned char *const my_out = s_out + wave * CFG::OUT_BYTES;
     int ch = 0, tile = 0;
     for (int t = 0; t < T; ++t) {
         {   // chunk t landed (this wave's part), then everybody's; the stage of chunk t-1 is free after the barrier
@@ -280,15 +297,15 @@ __global__ __launch_bounds__(CFG::THREADS) void conv1x1_gemm_kernel(
             __builtin_amdgcn_s_barrier();
         }
         int issued_now = 0;
-        if (t + D < T && !(GM_ABLATE & 1)) {
+        if (t + D < T) {
             issue(t + D);
-            issued_now = GM_DMA_PER_CHUNK;
+            issued_now = my_dma;
         }
         unsigned char *const st = smem + (t % NS) * CFG::STAGE;
         if (PRO) {
-            // normalise + activate the X chunk in place: 32 rows x SLOTS 16-byte pieces, two per thread
+            // normalise + activate the X chunk in place: 32 rows x SLOTS 16-byte pieces, PRO_PIECES per thread
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < CFG::PRO_PIECES; ++j) {
                 const int p = tid + CFG::THREADS * j;
                 const float2 ss = reinterpret_cast<const float2 *>(s_tab)[ch * GM_KC + p / CFG::SLOTS];
                 uint4 *cell = reinterpret_cast<uint4 *>(st + CFG::A_BYTES + p * 16);
@@ -325,16 +342,11 @@ __global__ __launch_bounds__(CFG::THREADS) void conv1x1_gemm_kernel(
 #pragma unroll
             for (int ri = 0; ri < RT; ++ri)
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi) {
-                    if (GM_ABLATE & 4) acc[mi][ri][0] += __builtin_bit_cast(float, xa[mi][0] + wb[ri][0]);
-                    else acc[mi][ri] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[mi], wb[ri], acc[mi][ri], 0, 0, 0);
-                }
+                for (int mi = 0; mi < 2; ++mi)
+                    acc[mi][ri] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[mi], wb[ri], acc[mi][ri], 0, 0, 0);
         }
         int stored_now = 0;
-        if ((GM_ABLATE & 2) && ch + 1 == nch) {
-            ch = 0;
-            ++tile;
-        } else if (++ch == nch) {
+        if (++ch == nch) {
             ch = 0;
             // ---- epilogue of one output tile: round, statistics, transpose through LDS, 16-byte row stores ----
             const int64_t mcol = col0 + (int64_t)tile * TN + wm * 64;
@@ -346,6 +358,7 @@ __global__ __launch_bounds__(CFG::THREADS) void conv1x1_gemm_kernel(
                         const unsigned pk = gm_pack_bf16(acc[0][ri][0], 0.f);
                         sShift[ri] = __shfl(__uint_as_float(pk << 16), l31);
                     }
+                    unsigned pk0[2][4], pk1[2][4];
 #pragma unroll
                     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -355,7 +368,7 @@ __global__ __launch_bounds__(CFG::THREADS) void conv1x1_gemm_kernel(
                             if (STATS) {
                                 // two elements per VALU instruction (v_pk_add_f32 / v_pk_fma_f32): the statistics
                                 // are VALU work the MFMAs wait for -- 4 instructions per output element cost as
-                                // much as the products themselves at K = 128 (tools/gemm_ablate.py)
+                                // much as the products themselves at K = 128
                                 const gm_f32x2 sh = {sShift[ri], sShift[ri]};
                                 const gm_f32x2 da = gm_f32x2{__uint_as_float(p0 << 16), __uint_as_float(p0 & 0xffff0000u)} - sh;
                                 const gm_f32x2 db = gm_f32x2{__uint_as_float(p1 << 16), __uint_as_float(p1 & 0xffff0000u)} - sh;
@@ -364,22 +377,34 @@ __global__ __launch_bounds__(CFG::THREADS) void conv1x1_gemm_kernel(
                                 sS[ri] += db;
                                 sQ[ri] = __builtin_elementwise_fma(db, db, sQ[ri]);
                             }
-                            // m = mi*32 + 8 rg + 4 half + (0..3): 16-byte piece mi*4 + rg, 8-byte half `half`
-                            const int p16 = (mi * 4 + rg) ^ (l31 & 7);
-                            *reinterpret_cast<uint2 *>(my_out + l31 * 128 + p16 * 16 + half * 8) = make_uint2(p0, p1);
+                            pk0[mi][rg] = p0;
+                            pk1[mi][rg] = p1;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) acc[mi][ri][4 * rg + e] = 0.0f;
                         }
+                    // transpose through the wave's own slab, OR rows at a time (lane l31 holds row l31 of the 32)
 #pragma unroll
-                    for (int it = 0; it < 4; ++it) {
-                        const int row = it * 8 + (lane >> 3), p16 = lane & 7;
-                        const uint4 v = *reinterpret_cast<const uint4 *>(my_out + row * 128 + ((p16 ^ (row & 7)) << 4));
-                        const int r = (GM_ABLATE & 8) ? row : r0 + wr * 32 * RT + ri * 32 + row;   // 8: every store hits one L2-resident tile
-                        typedef unsigned gm_u4 __attribute__((ext_vector_type(4)));
-                        const gm_u4 vv = {v.x, v.y, v.z, v.w};
-                        const int64_t mc = (GM_ABLATE & 8) ? 0 : mcol;
-                        if (NT_STORE && !(GM_ABLATE & 8)) __builtin_nontemporal_store(vv, reinterpret_cast<gm_u4 *>(Y + (size_t)r * M + mc + p16 * 8));
-                        else *reinterpret_cast<uint4 *>(Y + (size_t)r * M + mc + p16 * 8) = v;
+                    for (int h = 0; h < 32 / OR; ++h) {
+                        if (OR == 32 || (l31 >> 4) == h) {
+#pragma unroll
+                            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                                for (int rg = 0; rg < 4; ++rg) {
+                                    // m = mi*32 + 8 rg + 4 half + (0..3): 16-byte piece mi*4 + rg, 8-byte half `half`
+                                    const int p16 = (mi * 4 + rg) ^ (l31 & 7);
+                                    *reinterpret_cast<uint2 *>(my_out + (l31 & (OR - 1)) * 128 + p16 * 16 + half * 8) =
+                                        make_uint2(pk0[mi][rg], pk1[mi][rg]);
+                                }
+                        }
+#pragma unroll
+                        for (int it = 0; it < OR / 8; ++it) {
+                            const int row = it * 8 + (lane >> 3), p16 = lane & 7;
+                            const uint4 v = *reinterpret_cast<const uint4 *>(my_out + row * 128 + ((p16 ^ (row & 7)) << 4));
+                            const int r = r0 + wr * 32 * RT + ri * 32 + h * OR + row;
+                            const gm_u32x4 vv = {v.x, v.y, v.z, v.w};
+                            // streaming (nt) stores of Y: -10 ... 15 % on the family against plain stores
+                            __builtin_nontemporal_store(vv, reinterpret_cast<gm_u32x4 *>(Y + (size_t)r * M + mcol + p16 * 8));
+                        }
                     }
                 }
             }
@@ -393,16 +418,6 @@ __global__ __launch_bounds__(CFG::THREADS) void conv1x1_gemm_kernel(
 #pragma unroll
         for (int j = D; j > 0; --j) st_hist[j] = st_hist[j - 1];
         st_hist[0] = stored_now;
-    }
-    if (GM_ABLATE) {                                          // keep the arithmetic of a measurement build alive
-        float sink = 0.0f;
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < RT; ++b)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sink += acc[a][b][r];
-        if (sink == 12345.678f) Y[0] = 1;
     }
     if (STATS) {
         // per row: this wave's (sum, sum of squares, shift) over its 64-column share of every tile of the range ->
@@ -658,10 +673,64 @@ extern "C" int grafp_conv1x1_gemm_plan(int R, int K, int groups, int64_t M, int 
     GRAFP_REQUIRE(info, "conv1x1_gemm_plan: null pointer");
     GRAFP_REQUIRE(gemm_shape_ok(R, K, groups, M, views), "conv1x1_gemm_plan: unsupported shape");
     const GemmPlan p = gemm_plan(R / groups, K / groups, groups, M, views);
-    info[0] = p.large; info[1] = p.nblocks; info[2] = p.tiles_range; info[3] = p.P; info[4] = p.wgs;
+    info[0] = p.cfg; info[1] = p.nblocks; info[2] = p.tiles_range; info[3] = p.P; info[4] = p.wgs;
     info[5] = p.tr; info[6] = p.tn; info[7] = p.row_tiles;
     return GRAFP_OK;
 }
+
+namespace grafp {
+struct GemmArgs {
+    const unsigned short *w, *x, *x2;
+    unsigned short *y;
+    int lda, K1;
+    int64_t M;
+    int Rg, Kg, groups, views;
+    const float2 *pro_tab;
+    int pro_act;
+    float pro_slope;
+    float *part;
+};
+template <typename CFG, int NS, bool PRO, bool STATS, bool CAT>
+static void gemm_launch(const GemmPlan &p, const GemmArgs &a, hipStream_t s) {
+    const size_t lds = (size_t)NS * CFG::STAGE + CFG::NW * CFG::OUT_BYTES + (PRO ? (size_t)a.Kg * 8 : 0);
+    (void)hipFuncSetAttribute((const void *)conv1x1_gemm_kernel<CFG, NS, PRO, STATS, CAT>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((conv1x1_gemm_kernel<CFG, NS, PRO, STATS, CAT>), dim3(p.nblocks, 1, a.groups), dim3(CFG::THREADS),
+                       lds, s, a.w, a.lda, a.x, a.y, a.M, a.Rg, a.Kg, p.row_tiles, p.ranges_view, p.tiles_range,
+                       p.col_tiles_view, a.views, a.pro_tab, a.pro_act, a.pro_slope, a.part, p.P, p.nblocks, a.x2, a.K1);
+}
+// plain / statistics / concatenated-operand forms of one tile configuration
+template <typename CFG, int NS> static void gemm_launch_cfg(const GemmPlan &p, const GemmArgs &a, hipStream_t s) {
+    if (a.x2) gemm_launch<CFG, NS, false, false, true>(p, a, s);
+    else if (a.part) gemm_launch<CFG, NS, false, true, false>(p, a, s);
+    else gemm_launch<CFG, NS, false, false, false>(p, a, s);
+}
+static void gemm_dispatch(const GemmPlan &p, const GemmArgs &a, hipStream_t s) {
+    if (a.pro_tab) {                                  // normalise-on-load: three stages beside the table
+#define GM_PRO(CFG)                                                        \
+    do {                                                                   \
+        if (a.part) gemm_launch<CFG, 3, true, true, false>(p, a, s);       \
+        else gemm_launch<CFG, 3, true, false, false>(p, a, s);             \
+    } while (0)
+        switch (p.cfg) {
+        case GM_CFG_L: GM_PRO(GemmL); break;
+        case GM_CFG_N32: GM_PRO(GemmN32); break;
+        case GM_CFG_N64: GM_PRO(GemmN64); break;
+        case GM_CFG_N128: GM_PRO(GemmN128); break;
+        default: GM_PRO(GemmS); break;
+        }
+#undef GM_PRO
+        return;
+    }
+    switch (p.cfg) {
+    case GM_CFG_L: gemm_launch_cfg<GemmL, 4>(p, a, s); break;       // four stages = all 160 KB (-2.7 % against three)
+    case GM_CFG_N32: gemm_launch_cfg<GemmN32, 4>(p, a, s); break;
+    case GM_CFG_N64: gemm_launch_cfg<GemmN64, 4>(p, a, s); break;
+    case GM_CFG_N128: gemm_launch_cfg<GemmN128, 3>(p, a, s); break;
+    default: gemm_launch_cfg<GemmS, 4>(p, a, s); break;
+    }
+}
+}  // namespace grafp
 
 extern "C" int grafp_conv1x1_gemm_bf16(const void *w, const void *x, int R, int K, int groups, int64_t M, int views,
                                        const float *pro_tab, int pro_act, float pro_slope, void *y, float *stats_part,
@@ -675,36 +744,12 @@ extern "C" int grafp_conv1x1_gemm_bf16(const void *w, const void *x, int R, int 
     GRAFP_REQUIRE(pro_act >= 0 && pro_act <= 2, "conv1x1_gemm: bad activation %d", pro_act);
     const int Rg = R / groups, Kg = K / groups;
     const GemmPlan p = gemm_plan(Rg, Kg, groups, M, views);
-    hipStream_t s = (hipStream_t)stream;
-    const dim3 grid(p.nblocks, 1, groups);
-    const bool pro = pro_tab != nullptr, stats = stats_part != nullptr;
-#define GM_LAUNCH(CFG, NS, PRO, STATS)                                                                                  \
-    do {                                                                                                                \
-        const size_t lds = (size_t)(NS) * CFG::STAGE + CFG::NW * GM_OUT_BYTES + ((PRO) ? (size_t)Kg * 8 : 0);           \
-        (void)hipFuncSetAttribute((const void *)conv1x1_gemm_kernel<CFG, NS, PRO, STATS>,                               \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                \
-        hipLaunchKernelGGL((conv1x1_gemm_kernel<CFG, NS, PRO, STATS>), grid, dim3(CFG::THREADS), lds, s,                \
-                           (const unsigned short *)w, Kg, (const unsigned short *)x, (unsigned short *)y, M, Rg, Kg,    \
-                           p.row_tiles, p.ranges_view, p.tiles_range, p.col_tiles_view, views, (const float2 *)pro_tab, \
-                           pro_act, pro_slope, stats_part, p.P, p.nblocks);                                             \
-    } while (0)
-    // ring depth: S keeps 2 workgroups per CU (80 KB each: 4 stages, 3 with the PRO table); L is alone on its CU
-    // L without the PRO table: four stages = all 160 KB of LDS (-2.7 % over all layers at 2048 clip-views against three)
-    static const bool l4 = getenv("GRAFP_GEMM_L3") == nullptr;
-    if (p.large) {
-        if (pro && stats) GM_LAUNCH(GemmL, 3, true, true);
-        else if (pro) GM_LAUNCH(GemmL, 3, true, false);
-        else if (stats && l4) GM_LAUNCH(GemmL, 4, false, true);
-        else if (stats) GM_LAUNCH(GemmL, 3, false, true);
-        else if (l4) GM_LAUNCH(GemmL, 4, false, false);
-        else GM_LAUNCH(GemmL, 3, false, false);
-    } else {
-        if (pro && stats) GM_LAUNCH(GemmS, 3, true, true);
-        else if (pro) GM_LAUNCH(GemmS, 3, true, false);
-        else if (stats) GM_LAUNCH(GemmS, 4, false, true);
-        else GM_LAUNCH(GemmS, 4, false, false);
-    }
-#undef GM_LAUNCH
+    GRAFP_REQUIRE(!pro_tab || p.cfg != GM_CFG_N128 || Kg <= 1024, "conv1x1_gemm: normalise-on-load with <= 128 output rows takes at most 1024 operand rows");
+    GemmArgs a;
+    a.w = (const unsigned short *)w; a.x = (const unsigned short *)x; a.x2 = nullptr; a.y = (unsigned short *)y;
+    a.lda = Kg; a.K1 = 0; a.M = M; a.Rg = Rg; a.Kg = Kg; a.groups = groups; a.views = views;
+    a.pro_tab = (const float2 *)pro_tab; a.pro_act = pro_act; a.pro_slope = pro_slope; a.part = stats_part;
+    gemm_dispatch(p, a, (hipStream_t)stream);
     GRAFP_CHECK_LAUNCH("conv1x1_gemm_kernel");
     return GRAFP_OK;
 }
@@ -719,21 +764,11 @@ extern "C" int grafp_conv1x1_gemm_cat_bf16(const void *w, const void *x1, int K1
     GRAFP_REQUIRE((((uintptr_t)w | (uintptr_t)x1 | (uintptr_t)x2 | (uintptr_t)y) & 15) == 0,
                   "conv1x1_gemm_cat: operands must be 16-byte aligned");
     const GemmPlan p = gemm_plan(R, K, 1, M, 1);
-    hipStream_t s = (hipStream_t)stream;
-    const dim3 grid(p.nblocks, 1, 1);
-#define GM_LAUNCH_CAT(CFG, NS)                                                                                          \
-    do {                                                                                                                \
-        const size_t lds = (size_t)(NS) * CFG::STAGE + CFG::NW * GM_OUT_BYTES;                                          \
-        (void)hipFuncSetAttribute((const void *)conv1x1_gemm_kernel<CFG, NS, false, false, true>,                       \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                \
-        hipLaunchKernelGGL((conv1x1_gemm_kernel<CFG, NS, false, false, true>), grid, dim3(CFG::THREADS), lds, s,        \
-                           (const unsigned short *)w, K, (const unsigned short *)x1, (unsigned short *)y, M, R, K,      \
-                           p.row_tiles, p.ranges_view, p.tiles_range, p.col_tiles_view, 1, (const float2 *)nullptr, 0,  \
-                           0.0f, (float *)nullptr, p.P, p.nblocks, (const unsigned short *)x2, K1);                     \
-    } while (0)
-    if (p.large) GM_LAUNCH_CAT(GemmL, 4);
-    else GM_LAUNCH_CAT(GemmS, 4);
-#undef GM_LAUNCH_CAT
+    GemmArgs a;
+    a.w = (const unsigned short *)w; a.x = (const unsigned short *)x1; a.x2 = (const unsigned short *)x2;
+    a.y = (unsigned short *)y; a.lda = K; a.K1 = K1; a.M = M; a.Rg = R; a.Kg = K; a.groups = 1; a.views = 1;
+    a.pro_tab = nullptr; a.pro_act = 0; a.pro_slope = 0.0f; a.part = nullptr;
+    gemm_dispatch(p, a, (hipStream_t)stream);
     GRAFP_CHECK_LAUNCH("conv1x1_gemm_kernel (cat)");
     return GRAFP_OK;
 }
@@ -776,7 +811,7 @@ static int bn_affine_launch(const void *y, int C, int64_t M, int views, const fl
     // (swept 1024 ... 262144, tools/bn_bench.py --affine: the plain form gains 10 % from 64 k small workgroups at 2048
     // clip-views, but the training form re-combines its row's partial statistics in every workgroup and loses 20 %;
     // a separate finalize launch + 64 k workgroups ties with this at 1024 pairs and loses at 256)
-    static const int wgs = getenv("GRAFP_AFFINE_WGS") ? atoi(getenv("GRAFP_AFFINE_WGS")) : 2048;
+    const int wgs = GRAFP_TUNE_INT("GRAFP_AFFINE_WGS", 2048);
     int chunks_view = (int)((wgs + (int64_t)C * views - 1) / ((int64_t)C * views));
     const int64_t max_chunks = (Mg + 8191) / 8192;
     if (chunks_view > max_chunks) chunks_view = (int)max_chunks;

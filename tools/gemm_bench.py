@@ -1,9 +1,15 @@
-"""Shape-by-shape timing of the hand-written 1x1-conv GEMM (gemm.hip) against torch.mm (hipBLASLt) on the layer shapes
-of one training step at 256 pairs (512 clip-views): forward and data-gradient products of every stage.
+"""Shape-by-shape timing of the hand-written 1x1-conv GEMM (gemm.hip) on the layer shapes of one training step: the
+forward products (with the statistics epilogue), the data-gradient products and the concatenated-operand data
+gradients of every stage, per tile configuration.
 
-    python tools/gemm_bench.py [--stats] [--pro]      # on the GPU box
+    make -C grafp_amd/csrc measure                                   # libgrafp_hip_measure.so: plan overrides compiled in
+    GRAFP_HIP_LIB=$PWD/grafp_amd/libgrafp_hip_measure.so python tools/gemm_bench.py [--clips 2048] [--cfgs auto,S,L,N]
+    ... --wgrad [--stages 0123]                                       # the weight-gradient kernel instead
+
+Without the measurement library only the `auto` column (the shipping plan) can be timed.
 """
 import argparse
+import ctypes
 import os
 import sys
 
@@ -11,6 +17,10 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from grafp_amd import ops  # noqa: E402
+from grafp_amd._lib import lib  # noqa: E402
+
+CFG_IDS = {"S": 0, "L": 1, "N32": 2, "N64": 3, "N128": 4}
+CFG_NAMES = {v: k for k, v in CFG_IDS.items()}
 
 
 def timeit(fn, reps=20):
@@ -25,8 +35,21 @@ def timeit(fn, reps=20):
     return s.elapsed_time(e) / reps * 1e3          # us
 
 
+def plan_of(R, K, g, M, views):
+    info = (ctypes.c_int * 8)()
+    lib.grafp_conv1x1_gemm_plan(R, K, g, M, views, info)
+    return CFG_NAMES.get(info[0], "?"), info[1], info[2]
+
+
+def force(cfg):
+    if cfg is None:
+        os.environ.pop("GRAFP_GEMM_CFG", None)
+    else:
+        os.environ["GRAFP_GEMM_CFG"] = str(cfg)
+
+
 def wgrad(args, dev):
-    """dW = G X^T per layer shape (GRAFP_WGRAD_TILE=T/S/L/old selects a tile configuration / the register-staged kernel)."""
+    """dW = G X^T per layer shape (GRAFP_WGRAD_TILE in a measurement build selects a tile configuration)."""
     depth, tot = (2, 2, 6, 2), 0.0
     for stage, (C, N) in enumerate(((64, 1024), (128, 512), (256, 256), (512, 128))):
         M = args.clips * N
@@ -36,12 +59,10 @@ def wgrad(args, dev):
                                 ("ffn1", 4 * C, C, 1), ("ffn2", C, 4 * C, 1)):
             G = torch.randn(co, M, device=dev).to(torch.bfloat16)
             X = torch.randn(ci, M, device=dev).to(torch.bfloat16)
-            tab = torch.rand(ci, args.views, 2, device=dev)
-            t0 = timeit(lambda: ops.conv1x1_wgrad(G, X, co, ci, g, M, args.views))
-            t1 = 0.0 if args.no_pro else timeit(lambda: ops.conv1x1_wgrad(G, X, co, ci, g, M, args.views, tab, 1))
+            t0 = timeit(lambda: ops.conv1x1_wgrad(G, X, co, ci, g, M, 1))
             by, fl = (co + ci) * M * 2.0, 2.0 * co * (ci // g) * M
             tot += t0 * depth[stage]
-            print(f"s{stage} {name:9s} {co:5d} x {ci:5d} g={g} M={M:7d}  wgrad {t0:7.1f} us (+pro {t1:7.1f}) | "
+            print(f"s{stage} {name:9s} {co:5d} x {ci:5d} g={g} M={M:7d}  wgrad {t0:7.1f} us | "
                   f"{by / t0 / 1e6:5.2f} TB/s {fl / t0 / 1e6:7.1f} TF/s", flush=True)
     print(f"weighted by blocks per stage: {tot / 1e3:.2f} ms")
 
@@ -49,42 +70,71 @@ def wgrad(args, dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--views", type=int, default=2)
-    ap.add_argument("--clips", type=int, default=512)
+    ap.add_argument("--clips", type=int, default=2048)
+    ap.add_argument("--cfgs", default="auto,S,L,N", help="auto = the shipping plan; S, L, N (the 512-column tile that "
+                    "fits the rows: N32 / N64 / N128) need the measurement library")
     ap.add_argument("--wgrad", action="store_true", help="time the weight-gradient kernel instead")
-    ap.add_argument("--stages", default="0123", help="--wgrad: encoder stages to run")
-    ap.add_argument("--no-pro", action="store_true", help="--wgrad: skip the normalise-on-load variant")
+    ap.add_argument("--stages", default="0123", help="encoder stages to run")
+    ap.add_argument("--lib", action="store_true", help="also time torch.mm / torch.bmm (hipBLASLt) on the shape")
     args = ap.parse_args()
     dev = "cuda:0"
     if args.wgrad:
         return wgrad(args, dev)
-    rows = []
-    for stage, (C, N) in enumerate(((64, 1024), (128, 512), (256, 256), (512, 128))):
-        M = args.clips * N
-        shapes = [("fc1  CxC", C, C, 1), ("gconv 2Cx2C g4", 2 * C, 2 * C, 4), ("gfc2 Cx2C", C, 2 * C, 1),
-                  ("ffn1 4CxC", 4 * C, C, 1), ("ffn2 Cx4C", C, 4 * C, 1), ("d_gfc2 2CxC", 2 * C, C, 1)]
-        for name, R, K, g in shapes:
-            w = (0.1 * torch.randn(R, K // g, device=dev)).to(torch.bfloat16)
-            x = torch.randn(K, M, device=dev).to(torch.bfloat16)
-            tab = torch.rand(K, args.views, 2, device=dev)
-            t_plain = timeit(lambda: ops.conv1x1_gemm(w, x, g, args.views))
-            t_stats = timeit(lambda: ops.conv1x1_gemm(w, x, g, args.views, stats=True))
-            t_pro = timeit(lambda: ops.conv1x1_gemm(w, x, g, args.views, pro_tab=tab, pro_act=1, stats=True))
-            if g == 1:
-                t_lib = timeit(lambda: torch.mm(w, x))
-            else:
-                w3 = w.reshape(g, R // g, K // g)
-                t_lib = timeit(lambda: torch.bmm(w3, x.reshape(g, K // g, M)))
-            by = (R + K) * M * 2.0
-            fl = 2.0 * R * (K // g) * M
-            rows.append((stage, name, R, K, g, M, t_lib, t_plain, t_stats, t_pro, by, fl))
-            print(f"s{stage} {name:16s} R={R:5d} K={K:5d} g={g} M={M:7d}  lib {t_lib:7.1f} us | gemm {t_plain:7.1f} "
-                  f"(+stats {t_stats:7.1f}, +pro {t_pro:7.1f}) us | {by / t_plain / 1e6:6.2f} TB/s {fl / t_plain / 1e6:7.1f} TF/s",
-                  flush=True)
-    # blocks per stage: 2, 2, 6, 2
+    cfgs = args.cfgs.split(",")
     depth = (2, 2, 6, 2)
-    tot_lib = sum(r[6] * depth[r[0]] for r in rows)
-    tot = sum(r[7] * depth[r[0]] for r in rows)
-    print(f"weighted by blocks per stage: library {tot_lib / 1e3:.2f} ms, gemm.hip {tot / 1e3:.2f} ms")
+    totals = {c: 0.0 for c in cfgs}
+    floor_tot = 0.0
+    for stage, (C, N) in enumerate(((64, 1024), (128, 512), (256, 256), (512, 128))):
+        if str(stage) not in args.stages:
+            continue
+        M = args.clips * N
+        # (name, R, K, groups, stats?, cat: rows of the second operand)
+        shapes = [("fc1", C, C, 1, True, 0), ("gconv g4", 2 * C, 2 * C, 4, True, 0), ("gfc2", C, 2 * C, 1, True, 0),
+                  ("ffn1", 4 * C, C, 1, True, 0), ("ffn2", C, 4 * C, 1, True, 0),
+                  ("d_fc1 cat", C, C, 1, False, C), ("d_gconv g4", 2 * C, 2 * C, 4, False, 0),
+                  ("d_gfc2", 2 * C, C, 1, False, 0), ("d_ffn1 cat", C, 4 * C, 1, False, C), ("d_ffn2", 4 * C, C, 1, False, 0)]
+        for name, R, K, g, stats, cat in shapes:
+            w = (0.1 * torch.randn(R, (K + cat) // g, device=dev)).to(torch.bfloat16)
+            x = torch.randn(K, M, device=dev).to(torch.bfloat16)
+            x2 = torch.randn(cat, M, device=dev).to(torch.bfloat16) if cat else None
+            views = args.views if stats else 1
+            by = (R + K + cat) * M * 2.0
+            fl = 2.0 * R * ((K + cat) // g) * M
+            floor = max(by / 8e12, fl / 2.5e15) * 1e6
+            floor_tot += floor * depth[stage]
+            rg = R // g
+            ncfg = "N32" if rg <= 32 else "N64" if rg <= 64 else "N128"
+            cols, t_auto = [], None
+            for c in cfgs:
+                if c == "N" and rg > 128:
+                    cols.append(f"{'':>15s}")
+                    totals[c] += (t_auto or 0.0) * depth[stage]       # not applicable: the shipping plan's time
+                    continue
+                force(None if c == "auto" else CFG_IDS[ncfg if c == "N" else c])
+                if cat:
+                    t = timeit(lambda: ops.conv1x1_gemm_cat(w, x, x2))
+                else:
+                    t = timeit(lambda: ops.conv1x1_gemm(w, x, g, views, stats=stats))
+                totals[c] += t * depth[stage]
+                if c == "auto":
+                    t_auto = t
+                tag = plan_of(R, K + cat, g, M, views)[0] if c == "auto" else (ncfg if c == "N" else c)
+                cols.append(f"{tag:>4s} {t:7.1f} us")
+            force(None)
+            extra = ""
+            if args.lib and not cat:
+                if g == 1:
+                    t_lib = timeit(lambda: torch.mm(w, x))
+                else:
+                    w3 = w.reshape(g, R // g, K // g)
+                    t_lib = timeit(lambda: torch.bmm(w3, x.reshape(g, K // g, M)))
+                extra = f" | lib {t_lib:7.1f}"
+            best = min(float(c.split()[1]) for c in cols if c.strip())
+            print(f"s{stage} {name:11s} R={R:5d} K={K + cat:5d} g={g} M={M:7d} {'st' if stats else '  '} | "
+                  + " | ".join(cols) + f" | floor {floor:6.1f} | best {by / best / 1e6:5.2f} TB/s {fl / best / 1e6:7.1f} TF/s"
+                  + extra, flush=True)
+    print("weighted by blocks per stage (ms): " + ", ".join(f"{c} {v / 1e3:.2f}" for c, v in totals.items())
+          + f", two-ceiling floor {floor_tot / 1e3:.2f}")
 
 
 if __name__ == "__main__":
