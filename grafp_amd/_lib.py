@@ -52,11 +52,9 @@ SIGNATURES = {
     "grafp_bn_fwd": (_I, [_P, _I, _I, _L, _I, _P, _P, _P, _P, _I, _F, _F, _F, _I, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "grafp_bn_bwd": (_I, [_P, _P, _I, _I, _L, _I, _P, _P, _P, _P, _P, _I, _F, _I, _P, _P, _P, _P, _P, _Z, _P]),
     "grafp_bn_sync_bytes": (_Z, [_I, _L]),
-    "grafp_bn_fwd_1pass": (_I, [_P, _I, _I, _L, _I, _P, _P, _P, _P, _I, _F, _F, _F, _I, _P, _P, _P, _P, _P, _P, _Z, _P, _P]),
-    "grafp_bn_bwd_1pass": (_I, [_P, _P, _I, _I, _L, _I, _P, _P, _P, _P, _P, _I, _F, _I, _P, _P, _P, _P, _P, _Z, _P, _P]),
+    "grafp_bn_fwd_1pass": (_I, [_P, _I, _I, _L, _I, _P, _P, _P, _P, _I, _F, _F, _F, _I, _P, _P, _P, _P, _P, _P, _Z, _P, _I, _P]),
+    "grafp_bn_bwd_1pass": (_I, [_P, _P, _I, _I, _L, _I, _P, _P, _P, _P, _P, _I, _F, _I, _P, _P, _P, _P, _P, _Z, _P, _I, _P]),
     "grafp_ivfpq_scan_f32": (_I, [_P, _I, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _L, _P, _P, _P]),
-    "grafp_bn_debug_spin_limit": (_I, [_I]),
-    "grafp_debug_wgrad_tile": (_I, [_I]),
     "grafp_debug_occupy": (_I, [_I, _I, _L, _P]),
     "grafp_conv1x1_gemm_supported": (_I, [_I, _I, _I, _L, _I]),
     "grafp_conv1x1_gemm_partials": (_I, [_I, _I, _I, _L, _I]),
@@ -72,6 +70,8 @@ SIGNATURES = {
     "grafp_conv1x1_wgrad_pro_workspace": (_Z, [_I, _I, _I, _L, _I]),
     "grafp_conv1x1_wgrad_plan": (_I, [_I, _I, _I, _L, _I, _P]),
     "grafp_conv1x1_wgrad_pro_bf16": (_I, [_P, _P, _I, _I, _I, _L, _I, _P, _I, _F, _P, _P, _Z, _P]),
+    "grafp_conv1x1_wgrad_tile_workspace": (_Z, [_I, _I, _I, _L, _I, _I]),
+    "grafp_conv1x1_wgrad_tile_bf16": (_I, [_P, _P, _I, _I, _I, _L, _I, _P, _I, _F, _I, _P, _P, _Z, _P]),
     "grafp_conv1x1_wgrad_f32_workspace": (_Z, [_I, _I, _I, _L]),
     "grafp_conv1x1_wgrad_f32": (_I, [_P, _P, _I, _I, _I, _L, _P, _P, _Z, _P]),
     "grafp_ntxent_workspace": (_Z, [_I]),

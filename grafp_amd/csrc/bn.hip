@@ -16,6 +16,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "tuning.h"
 
 namespace grafp {
 
@@ -756,13 +757,9 @@ static bool bn_vec_ok(const void *a, const void *b, const void *c, const void *d
 
 }  // namespace grafp
 
-static int g_bn_spin_limit = 1 << 12;       // polls (~1 us each) before a workgroup stops waiting for its row-mates
-
-extern "C" int grafp_bn_debug_spin_limit(int polls) {
-    const int old = g_bn_spin_limit;
-    if (polls >= 0) g_bn_spin_limit = polls;
-    return old;
-}
+// polls (~1 us each) before a workgroup stops waiting for its row-mates and recomputes their partial sums itself; a
+// per-call argument of the *_1pass entry points (negative = this default; 0 = never wait)
+static inline int bn_spin(int spin_limit) { return spin_limit < 0 ? (1 << 12) : spin_limit; }
 
 extern "C" size_t grafp_bn_workspace(int C, int64_t M) {
     if (C <= 0 || M <= 0) return 0;
@@ -780,8 +777,9 @@ extern "C" int grafp_bn_fwd_1pass(const void *x, int dtype, int C, int64_t M, in
                                   const float *gamma, const float *beta, const void *residual, int act, float slope,
                                   float eps, float momentum, int training, float *running_mean, float *running_var,
                                   void *out, float *save_mean, float *save_invstd, void *ws, size_t ws_bytes,
-                                  int32_t *sync, grafp_stream_t stream) {
+                                  int32_t *sync, int spin_limit, grafp_stream_t stream) {
     using namespace grafp;
+    const int spin = bn_spin(spin_limit);
     GRAFP_REQUIRE(x && gamma && beta && out && save_mean && save_invstd, "bn_fwd: null pointer");
     GRAFP_REQUIRE(C > 0 && M > 0 && C <= 65535, "bn_fwd: bad shape C=%d M=%lld", C, (long long)M);
     GRAFP_REQUIRE(groups >= 1 && groups <= 8 && M % groups == 0, "bn_fwd: groups=%d must be in [1,8] and divide M=%lld", groups, (long long)M);
@@ -805,7 +803,7 @@ extern "C" int grafp_bn_fwd_1pass(const void *x, int dtype, int C, int64_t M, in
 #define BN_FWD1(T, RES)                                                                                                \
     hipLaunchKernelGGL((bn_fwd1_kernel<T, RES>), grid, dim3(BN1_THREADS), 0, s, (const T *)x, M, Mg, Sg, G, pre_bias,  \
                        gamma, beta, (const T *)residual, act, slope, eps, momentum, running_mean, running_var,         \
-                       (int *)sync, (T *)out, save_mean, save_invstd, g_bn_spin_limit)
+                       (int *)sync, (T *)out, save_mean, save_invstd, spin)
             if (f32) { if (residual) BN_FWD1(float, true); else BN_FWD1(float, false); }
             else { if (residual) BN_FWD1(unsigned short, true); else BN_FWD1(unsigned short, false); }
 #undef BN_FWD1
@@ -839,15 +837,16 @@ extern "C" int grafp_bn_fwd(const void *x, int dtype, int C, int64_t M, int grou
                             int training, float *running_mean, float *running_var, void *out, float *save_mean,
                             float *save_invstd, void *ws, size_t ws_bytes, grafp_stream_t stream) {
     return grafp_bn_fwd_1pass(x, dtype, C, M, groups, pre_bias, gamma, beta, residual, act, slope, eps, momentum, training,
-                              running_mean, running_var, out, save_mean, save_invstd, ws, ws_bytes, nullptr, stream);
+                              running_mean, running_var, out, save_mean, save_invstd, ws, ws_bytes, nullptr, -1, stream);
 }
 
 extern "C" int grafp_bn_bwd_1pass(const void *x, const void *dz, int dtype, int C, int64_t M, int groups,
                                   const float *pre_bias, const float *gamma, const float *beta, const float *save_mean,
                                   const float *save_invstd, int act, float slope, int training, void *dx,
                                   float *dgamma, float *dbeta, float *dpre_bias, void *ws, size_t ws_bytes,
-                                  int32_t *sync, grafp_stream_t stream) {
+                                  int32_t *sync, int spin_limit, grafp_stream_t stream) {
     using namespace grafp;
+    const int spin = bn_spin(spin_limit);
     GRAFP_REQUIRE(x && dz && gamma && beta && save_mean && save_invstd && dx && dgamma && dbeta, "bn_bwd: null pointer");
     GRAFP_REQUIRE(C > 0 && M > 0 && C <= 65535, "bn_bwd: bad shape C=%d M=%lld", C, (long long)M);
     GRAFP_REQUIRE(groups >= 1 && groups <= 8 && M % groups == 0, "bn_bwd: groups=%d must be in [1,8] and divide M=%lld", groups, (long long)M);
@@ -869,8 +868,8 @@ extern "C" int grafp_bn_bwd_1pass(const void *x, const void *dz, int dtype, int 
         // operands fenced across the wait -- bn_opaque -- this variant needs 122 VGPRs, 4 workgroups per CU)
         int items = BN1_ITEMS_BWD;
         int Sg = ok ? bn1_plan(Mg, G, f32 ? 4 : 8, items) : 0;
-        static const int items8_from = getenv("GRAFP_BN_BWD_ITEMS8_FROM") ? atoi(getenv("GRAFP_BN_BWD_ITEMS8_FROM")) : 16;
-        if (ok && !f32 && (Sg == 0 || Sg * G > items8_from) && getenv("GRAFP_BN_BWD_ITEMS4") == nullptr) {
+        const int items8_from = GRAFP_TUNE_INT("GRAFP_BN_BWD_ITEMS8_FROM", 16);
+        if (ok && !f32 && (Sg == 0 || Sg * G > items8_from)) {
             items = 2 * BN1_ITEMS_BWD;
             Sg = bn1_plan(Mg, G, 8, items);
         }
@@ -879,17 +878,17 @@ extern "C" int grafp_bn_bwd_1pass(const void *x, const void *dz, int dtype, int 
             if (f32)
                 hipLaunchKernelGGL((bn_bwd1_kernel<float, BN1_ITEMS_BWD>), grid, dim3(BN1_THREADS), 0, s, (const float *)x,
                                    (const float *)dz, M, Mg, Sg, G, pre_bias, gamma, beta, save_mean, save_invstd, act,
-                                   slope, (int *)sync, (float *)dx, dgamma, dbeta, dpre_bias, g_bn_spin_limit);
+                                   slope, (int *)sync, (float *)dx, dgamma, dbeta, dpre_bias, spin);
             else if (items == BN1_ITEMS_BWD)
                 hipLaunchKernelGGL((bn_bwd1_kernel<unsigned short, BN1_ITEMS_BWD>), grid, dim3(BN1_THREADS), 0, s,
                                    (const unsigned short *)x, (const unsigned short *)dz, M, Mg, Sg, G, pre_bias, gamma,
                                    beta, save_mean, save_invstd, act, slope, (int *)sync, (unsigned short *)dx,
-                                   dgamma, dbeta, dpre_bias, g_bn_spin_limit);
+                                   dgamma, dbeta, dpre_bias, spin);
             else
                 hipLaunchKernelGGL((bn_bwd1_kernel<unsigned short, 2 * BN1_ITEMS_BWD>), grid, dim3(BN1_THREADS), 0, s,
                                    (const unsigned short *)x, (const unsigned short *)dz, M, Mg, Sg, G, pre_bias, gamma,
                                    beta, save_mean, save_invstd, act, slope, (int *)sync, (unsigned short *)dx,
-                                   dgamma, dbeta, dpre_bias, g_bn_spin_limit);
+                                   dgamma, dbeta, dpre_bias, spin);
             GRAFP_CHECK_LAUNCH("bn_bwd1_kernel");
             return GRAFP_OK;
         }
@@ -919,5 +918,5 @@ extern "C" int grafp_bn_bwd(const void *x, const void *dz, int dtype, int C, int
                             int act, float slope, int training, void *dx, float *dgamma, float *dbeta,
                             float *dpre_bias, void *ws, size_t ws_bytes, grafp_stream_t stream) {
     return grafp_bn_bwd_1pass(x, dz, dtype, C, M, groups, pre_bias, gamma, beta, save_mean, save_invstd, act, slope,
-                              training, dx, dgamma, dbeta, dpre_bias, ws, ws_bytes, nullptr, stream);
+                              training, dx, dgamma, dbeta, dpre_bias, ws, ws_bytes, nullptr, -1, stream);
 }

@@ -76,19 +76,28 @@ struct GemmPlan {
 static GemmPlan gemm_plan(int Rg, int K, int groups, int64_t M, int views) {
     GemmPlan p;
     const int64_t Mg = M / views;
-    // measured crossover (tools/gemm_bench.py at 512 and 2048 clip-views): the large tile for >= 512 output rows per
-    // group; for 256 rows when the operand is deep (K >= 512: matrix-heavy), shallow (4K <= R: X is then read once for
-    // all 256 rows of a write-bound product) or the rows are long (>= 2^18 columns per view: the tensors no longer fit
-    // the Infinity Cache and the small tile's second pass over X goes to HBM); and for everything once a view has
-    // >= 2^20 columns (stage 0 at 1024 pairs per GPU), where its 512-byte row segments stream best
-    bool large = (Rg >= 512 || (Rg >= 256 && (K >= 512 || 4 * K <= Rg || Mg >= (1 << 18))) || Mg >= (1 << 20)) &&
-                 Mg % GemmL::TN == 0;
+    // measured (tools/gemm_bench.py: every configuration on the forward, data-gradient and concatenated-operand shapes
+    // of a step at 256, 512 and 2048 clip-views; profiles/r03_gemm_sweep.txt).  >= 256 rows per group: the large tile
+    // for >= 512 rows; for 256 rows when the operand is deep (K >= 512: matrix-heavy), shallow (4K <= R: X is then read
+    // once for all 256 rows of a write-bound product) or the rows are long (>= 2^18 columns per view: the tensors no
+    // longer fit the Infinity Cache and the small tile's second pass over X goes to HBM).  (Round 2 also sent every
+    // shape with >= 2^20 columns per view to the large tile; against the S tile that loses 3-10 % on seven of the ten
+    // stage-0 shapes at 2048 clip-views -- 4 x the MFMA work on rows that do not exist -- and is gone.)
+    const bool large = (Rg >= 512 || (Rg >= 256 && (K >= 512 || 4 * K <= Rg || Mg >= (1 << 18)))) && Mg % GemmL::TN == 0;
     p.cfg = large ? GM_CFG_L : GM_CFG_S;
-    // <= 128 rows per group: the 512-column tiles (see above), from 2^16 columns per view (below that the S tile's many
-    // small workgroups fill the chip better)
+    // <= 128 rows per group: the 512-column tiles where they measured faster than both --
+    //   N128 (65 ... 128 rows, ungrouped): from 128 operand rows and 2^17 columns per view (-15 ... -25 % on the stage-1
+    //        shapes at every size; R = 128, K = 64 and the short rows of 128 pairs per GPU stay on the S tile);
+    //   N64 / N32 (<= 64 / <= 32 rows): from 2^16 columns per view (-10 ... -27 % at 256 and 512 clip-views); beyond
+    //        2^20 columns per view only the ungrouped shapes with K = 64 or K >= 256 (the others tie or lose 5 %).
     const int64_t n_from = GRAFP_TUNE_INT("GRAFP_GEMM_N_FROM", 1 << 16);
-    if (Rg <= 128 && Mg % GemmN64::TN == 0 && Mg >= n_from)
-        p.cfg = Rg <= 32 ? GM_CFG_N32 : Rg <= 64 ? GM_CFG_N64 : GM_CFG_N128;
+    if (Rg <= 128 && Mg % GemmN64::TN == 0 && Mg >= n_from) {
+        if (Rg > 64) {
+            if (groups == 1 && K >= 128 && Mg >= 2 * n_from) p.cfg = GM_CFG_N128;
+        } else if (Mg < (1 << 20) || (groups == 1 && (K <= 64 || K >= 256))) {
+            p.cfg = Rg <= 32 ? GM_CFG_N32 : GM_CFG_N64;
+        }
+    }
     const int force = GRAFP_TUNE_INT("GRAFP_GEMM_CFG", -1);                 // measurement builds only (tuning.h)
     if (force == GM_CFG_S || (force == GM_CFG_L && Mg % GemmL::TN == 0) ||
         (force >= GM_CFG_N32 && force <= GM_CFG_N128 && Mg % GemmN64::TN == 0))
@@ -396,6 +405,10 @@ __global__ __launch_bounds__(CFG::THREADS) void conv1x1_gemm_kernel(
                                         make_uint2(pk0[mi][rg], pk1[mi][rg]);
                                 }
                         }
+                        // convergent no-op: without it hipcc (ROCm 7.2) sinks the reads below INTO the divergent block
+                        // above (seen in the .s: ds_read_b128 under the half-wave exec mask, skipped on execz) -- the
+                        // rows of the second half came back half garbage
+                        if (OR != 32) __builtin_amdgcn_wave_barrier();
 #pragma unroll
                         for (int it = 0; it < OR / 8; ++it) {
                             const int row = it * 8 + (lane >> 3), p16 = lane & 7;

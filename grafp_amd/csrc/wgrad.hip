@@ -16,6 +16,7 @@
 // HBM-bound: (Cout + Cin) * M * 2 bytes per launch (+ re-reads of the smaller operand across output tiles).
 #include "common.h"
 #include "dma_ring.h"
+#include "tuning.h"
 
 namespace grafp {
 
@@ -581,21 +582,18 @@ struct WgDmaPlan {
     int to, tc, tiles_o, tiles_c, slices_view, nslices;
     int64_t cols;
 };
-static int g_wg_force = -2;            // -2: not read yet; -1: heuristic; 0 ... 7: that configuration; 9: register-staged
-static int wg_force_cfg() {
-    if (g_wg_force == -2) {
-        // GRAFP_WGRAD_TILE = T / S / L / s / m / l / G / H / old: measurements (tools/wgrad_sweep.sh)
-        const char *e = getenv("GRAFP_WGRAD_TILE");
-        g_wg_force = !e ? -1 : (e[0] == 'T' ? 0 : e[0] == 'S' ? 1 : e[0] == 'L' ? 2 : e[0] == 's' ? 3 : e[0] == 'm' ? 4 :
-                                e[0] == 'l' ? 5 : e[0] == 'G' ? 6 : e[0] == 'H' ? 7 : 9);
-    }
-    return g_wg_force;
+// tile: -1 = the measured heuristic below; 0 ... 7 = that configuration (T, S, L, S32, M32, L32, SG, LG); 9 = the
+// register-staged split-K kernel of round 1 (wgrad_partial_kernel).  A per-call argument of the *_tile entry points
+// (tests force every configuration on small cases); GRAFP_WGRAD_TILE only in measurement builds (tuning.h).
+static int wg_tile(int tile) {
+    if (tile < 0) tile = GRAFP_TUNE_INT("GRAFP_WGRAD_TILE", -1);
+    return ((tile >= 0 && tile <= 7) || tile == 9) ? tile : -1;
 }
-static bool wgrad_dma_ok(int cout_g, int cin_g, int64_t M, int views) {
-    return wg_force_cfg() != 9 && cout_g % 32 == 0 && cin_g % 32 == 0 && views >= 1 && M % views == 0 &&
+static bool wgrad_dma_ok(int cout_g, int cin_g, int64_t M, int views, int tile) {
+    return wg_tile(tile) != 9 && cout_g % 32 == 0 && cin_g % 32 == 0 && views >= 1 && M % views == 0 &&
            (M / views) % 64 == 0;
 }
-static WgDmaPlan wgrad_dma_plan(int cout_g, int cin_g, int groups, int64_t M, int views, bool pro) {
+static WgDmaPlan wgrad_dma_plan(int cout_g, int cin_g, int groups, int64_t M, int views, bool pro, int tile) {
     WgDmaPlan p;
     const int64_t outs = (int64_t)cout_g * cin_g;
     // Measured (tools/wgrad_sweep.sh: every configuration on every layer shape at 256 / 512 / 1024 / 2048 clip-views;
@@ -617,7 +615,7 @@ static WgDmaPlan wgrad_dma_plan(int cout_g, int cin_g, int groups, int64_t M, in
     if (lo >= 128 && (outs >= (1 << 19) || (big && groups == 1))) p.cfg = 1;
     if (big && groups == 1 && cout_g >= 64 && cin_g >= 2 * cout_g) p.cfg = 1;
     if (pro && cin_g >= 256 && cout_g >= 128) p.cfg = 1;
-    static const bool no_wide = getenv("GRAFP_WGRAD_NO_WIDE") != nullptr;      // A/B: the three DMA tiles only
+    const bool no_wide = GRAFP_TUNE_INT("GRAFP_WGRAD_NO_WIDE", 0) != 0;        // A/B: the three DMA tiles only
     if (!pro && !no_wide) {
         const bool wide = (lo >= 256 && hi >= 1024 && opbytes >= 200e6) || (lo >= 128 && hi >= 256 && opbytes >= 400e6) ||
                           (lo >= 512 && opbytes >= 250e6);
@@ -628,7 +626,8 @@ static WgDmaPlan wgrad_dma_plan(int cout_g, int cin_g, int groups, int64_t M, in
             p.cfg = opbytes >= 750e6 ? 6 : 5;
         }
     }
-    if (wg_force_cfg() >= 0 && wg_force_cfg() <= 7 && !(pro && wg_force_cfg() >= 6)) p.cfg = wg_force_cfg();
+    const int forced = wg_tile(tile);
+    if (forced >= 0 && forced <= 7 && !(pro && forced >= 6)) p.cfg = forced;
     static const int tile_o[8] = {64, 128, 256, 128, 256, 256, 128, 256}, tile_c[8] = {64, 128, 256, 128, 128, 256, 128, 256};
     p.to = tile_o[p.cfg];
     p.tc = tile_c[p.cfg];
@@ -644,7 +643,7 @@ static WgDmaPlan wgrad_dma_plan(int cout_g, int cin_g, int groups, int64_t M, in
     static const int64_t targets[8] = {512, 512, 512, 1024, 512, 256, 512, 256};
     int64_t target = targets[p.cfg];
     if (p.cfg <= 1 && opbytes >= 750e6) target = 1024;        // the small tiles at 1024 pairs per GPU: two rounds (+2 %)
-    if (const char *e = getenv("GRAFP_WGRAD_TARGET")) target = atoi(e);
+    if (GRAFP_TUNE_INT("GRAFP_WGRAD_TARGET", 0) > 0) target = GRAFP_TUNE_INT("GRAFP_WGRAD_TARGET", 0);
     int64_t sv = (target + tiles * views - 1) / (tiles * views);
     const int64_t max_sv = (Mv / 64 + 7) / 8;
     if (sv > max_sv) sv = max_sv;
@@ -709,14 +708,6 @@ static WgradPlan wgrad_plan(int cout_g, int cin_g, int groups, int64_t M) {
 
 }  // namespace grafp
 
-// test hook: force a tile configuration of the LDS-DMA weight gradient (0 = T ... 7 = LG, 9 = the register-staged
-// kernels of round 1, -1 = the measured heuristic); returns the previous setting
-extern "C" int grafp_debug_wgrad_tile(int cfg) {
-    const int prev = grafp::wg_force_cfg();
-    grafp::g_wg_force = (cfg >= 0 && cfg <= 7) || cfg == 9 ? cfg : -1;
-    return prev;
-}
-
 extern "C" int grafp_conv1x1_wgrad_plan(int Cout, int Cin, int groups, int64_t M, int views, int *info) {
     using namespace grafp;
     GRAFP_REQUIRE(info, "conv1x1_wgrad_plan: null pointer");
@@ -724,8 +715,8 @@ extern "C" int grafp_conv1x1_wgrad_plan(int Cout, int Cin, int groups, int64_t M
                   "conv1x1_wgrad_plan: bad shape");
     const int cout_g = Cout / groups, cin_g = Cin / groups;
     for (int i = 0; i < 8; ++i) info[i] = 0;
-    if (wgrad_dma_ok(cout_g, cin_g, M, views)) {
-        const WgDmaPlan p = wgrad_dma_plan(cout_g, cin_g, groups, M, views, false);
+    if (wgrad_dma_ok(cout_g, cin_g, M, views, -1)) {
+        const WgDmaPlan p = wgrad_dma_plan(cout_g, cin_g, groups, M, views, false, -1);
         info[0] = p.cfg; info[1] = p.to; info[2] = p.tc; info[3] = p.nslices; info[4] = p.tiles_o * p.tiles_c * groups;
     } else {
         const WgradPlan p = wgrad_plan(cout_g, cin_g, groups, M);
@@ -734,33 +725,37 @@ extern "C" int grafp_conv1x1_wgrad_plan(int Cout, int Cin, int groups, int64_t M
     return GRAFP_OK;
 }
 
-extern "C" size_t grafp_conv1x1_wgrad_pro_workspace(int Cout, int Cin, int groups, int64_t M, int views) {
+extern "C" size_t grafp_conv1x1_wgrad_tile_workspace(int Cout, int Cin, int groups, int64_t M, int views, int tile) {
     using namespace grafp;
     if (Cout <= 0 || Cin <= 0 || groups <= 0 || M <= 0 || Cout % groups || Cin % groups) return 0;
     const int cout_g = Cout / groups, cin_g = Cin / groups;
-    if (wgrad_dma_ok(cout_g, cin_g, M, views)) {
-        const WgDmaPlan p = wgrad_dma_plan(cout_g, cin_g, groups, M, views, false);
-        const WgDmaPlan q = wgrad_dma_plan(cout_g, cin_g, groups, M, views, true);
+    if (wgrad_dma_ok(cout_g, cin_g, M, views, tile)) {
+        const WgDmaPlan p = wgrad_dma_plan(cout_g, cin_g, groups, M, views, false, tile);
+        const WgDmaPlan q = wgrad_dma_plan(cout_g, cin_g, groups, M, views, true, tile);
         return (size_t)(p.nslices > q.nslices ? p.nslices : q.nslices) * Cout * cin_g * sizeof(float);
     }
     const WgradPlan p = wgrad_plan(cout_g, cin_g, groups, M);
     return (size_t)p.S * Cout * cin_g * sizeof(float);
 }
 
+extern "C" size_t grafp_conv1x1_wgrad_pro_workspace(int Cout, int Cin, int groups, int64_t M, int views) {
+    return grafp_conv1x1_wgrad_tile_workspace(Cout, Cin, groups, M, views, -1);
+}
+
 extern "C" size_t grafp_conv1x1_wgrad_workspace(int Cout, int Cin, int groups, int64_t M) {
     return grafp_conv1x1_wgrad_pro_workspace(Cout, Cin, groups, M, 1);
 }
 
-extern "C" int grafp_conv1x1_wgrad_pro_bf16(const void *grad_out, const void *x, int Cout, int Cin, int groups,
-                                            int64_t M, int views, const float *pro_tab, int pro_act, float pro_slope,
-                                            float *dweight, void *ws, size_t ws_bytes, grafp_stream_t stream) {
+extern "C" int grafp_conv1x1_wgrad_tile_bf16(const void *grad_out, const void *x, int Cout, int Cin, int groups,
+                                             int64_t M, int views, const float *pro_tab, int pro_act, float pro_slope,
+                                             int tile, float *dweight, void *ws, size_t ws_bytes, grafp_stream_t stream) {
     using namespace grafp;
     GRAFP_REQUIRE(grad_out && x && dweight, "conv1x1_wgrad: null pointer");
     GRAFP_REQUIRE(Cout > 0 && Cin > 0 && groups > 0 && M > 0 && Cout % groups == 0 && Cin % groups == 0,
                   "conv1x1_wgrad: bad shape Cout=%d Cin=%d groups=%d M=%lld", Cout, Cin, groups, (long long)M);
     GRAFP_REQUIRE((((uintptr_t)grad_out | (uintptr_t)x) & 15) == 0, "conv1x1_wgrad: operands must be 16-byte aligned");
     GRAFP_REQUIRE(pro_act >= 0 && pro_act <= 2, "conv1x1_wgrad: bad activation %d", pro_act);
-    const size_t need = grafp_conv1x1_wgrad_pro_workspace(Cout, Cin, groups, M, views);
+    const size_t need = grafp_conv1x1_wgrad_tile_workspace(Cout, Cin, groups, M, views, tile);
     if (!ws || ws_bytes < need) {
         set_error("conv1x1_wgrad: workspace %zu bytes < required %zu", ws_bytes, need);
         return GRAFP_ERR_WORKSPACE;
@@ -768,8 +763,8 @@ extern "C" int grafp_conv1x1_wgrad_pro_bf16(const void *grad_out, const void *x,
     const int cout_g = Cout / groups, cin_g = Cin / groups;
     hipStream_t s = (hipStream_t)stream;
     const int64_t n = (int64_t)Cout * cin_g;
-    if (wgrad_dma_ok(cout_g, cin_g, M, views)) {
-        const WgDmaPlan p = wgrad_dma_plan(cout_g, cin_g, groups, M, views, pro_tab != nullptr);
+    if (wgrad_dma_ok(cout_g, cin_g, M, views, tile)) {
+        const WgDmaPlan p = wgrad_dma_plan(cout_g, cin_g, groups, M, views, pro_tab != nullptr, tile);
         const int nblocks = p.nslices * p.tiles_o * p.tiles_c;
         const dim3 grid(nblocks, 1, groups);
 #define WG_LAUNCH(CFG, PRO)                                                                                              \
@@ -841,10 +836,17 @@ extern "C" int grafp_conv1x1_wgrad_pro_bf16(const void *grad_out, const void *x,
     return GRAFP_OK;
 }
 
+extern "C" int grafp_conv1x1_wgrad_pro_bf16(const void *grad_out, const void *x, int Cout, int Cin, int groups,
+                                            int64_t M, int views, const float *pro_tab, int pro_act, float pro_slope,
+                                            float *dweight, void *ws, size_t ws_bytes, grafp_stream_t stream) {
+    return grafp_conv1x1_wgrad_tile_bf16(grad_out, x, Cout, Cin, groups, M, views, pro_tab, pro_act, pro_slope, -1, dweight,
+                                         ws, ws_bytes, stream);
+}
+
 extern "C" int grafp_conv1x1_wgrad_bf16(const void *grad_out, const void *x, int Cout, int Cin, int groups, int64_t M,
                                         float *dweight, void *ws, size_t ws_bytes, grafp_stream_t stream) {
-    return grafp_conv1x1_wgrad_pro_bf16(grad_out, x, Cout, Cin, groups, M, 1, nullptr, 0, 0.0f, dweight, ws, ws_bytes,
-                                        stream);
+    return grafp_conv1x1_wgrad_tile_bf16(grad_out, x, Cout, Cin, groups, M, 1, nullptr, 0, 0.0f, -1, dweight, ws, ws_bytes,
+                                         stream);
 }
 
 static grafp::WgradPlan wgrad3_plan(int cout_g, int cin_g, int groups, int64_t M) {

@@ -46,6 +46,7 @@ class _Switches:
     wgrad_f32_library = False     # True: f32 weight gradients by the library GEMM instead of the split-bf16 kernel
     fused_conv_bn = True          # False: library GEMM + fused BatchNorm kernel pair instead of conv1x1_gemm (bf16 mode)
     shortcut_fusion = True        # False: autograd's accumulate kernel instead of the [W^T | I] data-gradient product
+    bn_spin_limit = -1            # polls of the single-pass BatchNorm rendezvous (-1: the library default; 0: never wait)
 
 
 switches = _Switches()
@@ -415,7 +416,7 @@ class _BnAct(torch.autograd.Function):
             check(lib.grafp_bn_fwd_1pass(_p(x), _DT[x.dtype], C, M, groups, _p(pb), _p(g32), _p(b32), _p(res), act,
                                          float(slope), float(eps), float(momentum), int(bool(training)),
                                          _p(running_mean), _p(running_var), _p(out), _p(mean), _p(invstd), _p(ws),
-                                         nbytes, _p(_bn_sync(x.device, C, M)), _stream()), "bn_fwd")
+                                         nbytes, _p(_bn_sync(x.device, C, M)), switches.bn_spin_limit, _stream()), "bn_fwd")
         ctx.save_for_backward(x, g32, b32, pb if pb is not None else mean.new_empty(0), mean, invstd)
         ctx.cfg = (C, M, act, float(slope), bool(training), pre_bias is not None, residual is not None, groups)
         return out
@@ -437,7 +438,7 @@ class _BnAct(torch.autograd.Function):
             check(lib.grafp_bn_bwd_1pass(_p(x), _p(dz), _DT[x.dtype], C, M, groups, _p(pb) if has_pb else None, _p(g32),
                                          _p(b32), _p(mean), _p(invstd), act, slope, int(training), _p(dx), _p(dgamma),
                                          _p(dbeta), _p(dpb) if has_pb else None, _p(ws), nbytes,
-                                         _p(_bn_sync(x.device, C, M)), _stream()), "bn_bwd")
+                                         _p(_bn_sync(x.device, C, M)), switches.bn_spin_limit, _stream()), "bn_bwd")
         return dx, dgamma, dbeta, dpb, (dz if has_res else None), None, None, None, None, None, None, None, None
 
 
@@ -790,20 +791,22 @@ def _bn_bwd(y, dz, C, M, views, pb, g32, b32, mean, invstd, act, slope, training
     with _timed("bn_bwd", (C, M, y.element_size())):
         check(lib.grafp_bn_bwd_1pass(_p(y), _p(dz), _DT[y.dtype], C, M, views, _p(pb), _p(g32), _p(b32), _p(mean),
                                      _p(invstd), act, slope, int(training), _p(dy), _p(dgamma), _p(dbeta), _p(dpb),
-                                     _p(ws), nbytes, _p(_bn_sync(y.device, C, M)), _stream()), "bn_bwd")
+                                     _p(ws), nbytes, _p(_bn_sync(y.device, C, M)), switches.bn_spin_limit, _stream()), "bn_bwd")
     return dy, dgamma, dbeta, dpb
 
 
-def _wgrad_bf16(g, x, cout, cin, groups, M, views=1, pro_tab=None, pro_act=ACT_NONE, pro_slope=0.0):
+def _wgrad_bf16(g, x, cout, cin, groups, M, views=1, pro_tab=None, pro_act=ACT_NONE, pro_slope=0.0, tile=-1):
     """dW = g f(x)^T for bf16 (rows, M) operands -> (cout, cin/groups) f32; pro_tab (cin, views, 2): f = the BatchNorm
-    + activation of the layer that produced x, applied on the fly (see conv1x1_gemm)."""
+    + activation of the layer that produced x, applied on the fly (see conv1x1_gemm).  tile: -1 = the library's rule,
+    otherwise that tile configuration (grafp_conv1x1_wgrad_tile_bf16; tests)."""
     dw = torch.empty((cout, cin // groups), dtype=torch.float32, device=x.device)
-    nbytes = lib.grafp_conv1x1_wgrad_pro_workspace(cout, cin, groups, M, views)
+    nbytes = lib.grafp_conv1x1_wgrad_tile_workspace(cout, cin, groups, M, views, int(tile))
     ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
     tab = None if pro_tab is None else _f32c(pro_tab)
     with _timed("conv1x1_wgrad", (cout, cin, groups, M)):
-        check(lib.grafp_conv1x1_wgrad_pro_bf16(_p(g), _p(x), cout, cin, groups, M, views, _p(tab), int(pro_act),
-                                               float(pro_slope), _p(dw), _p(ws), nbytes, _stream()), "conv1x1_wgrad")
+        check(lib.grafp_conv1x1_wgrad_tile_bf16(_p(g), _p(x), cout, cin, groups, M, views, _p(tab), int(pro_act),
+                                                float(pro_slope), int(tile), _p(dw), _p(ws), nbytes, _stream()),
+              "conv1x1_wgrad")
     return dw
 
 

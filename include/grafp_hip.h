@@ -9,7 +9,8 @@
  *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless it says "host";
  *   - the CALLER owns every buffer, including the scratch `ws` whose size the matching
  *     *_workspace() function returns (bytes; 256-byte alignment is sufficient);
- *   - no allocation, no global mutable state, no implicit synchronisation: work is enqueued on
+ *   - no allocation, no global mutable state, no environment variable read (the launch plan of a call is a pure
+ *     function of its arguments), no implicit synchronisation: work is enqueued on
  *     `stream` (a hipStream_t passed as void*; NULL = the default stream) and is hipGraph-capturable;
  *   - returns GRAFP_OK (0) or a negative GRAFP_ERR_* code; grafp_last_error() then holds a
  *     thread-local human-readable message;
@@ -170,17 +171,19 @@ int grafp_bn_bwd(const void *x, const void *dz, int dtype, int C, int64_t M, int
  *   sync  grafp_bn_sync_bytes(C, M) bytes, 8-byte aligned, ALL ONES (0xff) on entry; the call leaves it all ones
  *         again (so one buffer, filled once, serves every call enqueued on the same stream).  NULL, eval mode, rows
  *         that are not 16-byte aligned multiples of the vector width, or more than 256 chunks per row select the
- *         two-pass kernels. */
+ *         two-pass kernels.
+ *   spin_limit  polls after which a workgroup stops waiting for the other workgroups of its row and recomputes their
+ *         partial sums itself (same bits, more time): negative = the default (4096, ~4 ms), 0 = never wait. */
 size_t grafp_bn_sync_bytes(int C, int64_t M);
 int grafp_bn_fwd_1pass(const void *x, int dtype, int C, int64_t M, int groups, const float *pre_bias,
                        const float *gamma, const float *beta, const void *residual, int act, float slope, float eps,
                        float momentum, int training, float *running_mean, float *running_var, void *out,
-                       float *save_mean, float *save_invstd, void *ws, size_t ws_bytes, int32_t *sync,
+                       float *save_mean, float *save_invstd, void *ws, size_t ws_bytes, int32_t *sync, int spin_limit,
                        grafp_stream_t stream);
 int grafp_bn_bwd_1pass(const void *x, const void *dz, int dtype, int C, int64_t M, int groups, const float *pre_bias,
                        const float *gamma, const float *beta, const float *save_mean, const float *save_invstd,
                        int act, float slope, int training, void *dx, float *dgamma, float *dbeta,
-                       float *dpre_bias /* (C) or NULL */, void *ws, size_t ws_bytes, int32_t *sync,
+                       float *dpre_bias /* (C) or NULL */, void *ws, size_t ws_bytes, int32_t *sync, int spin_limit,
                        grafp_stream_t stream);
 
 /* ---- IVF-PQ parity index: asymmetric-distance scan ----------------------------------------------------------------
@@ -197,11 +200,8 @@ int grafp_ivfpq_scan_f32(const float *q, int nq, int d, const float *centroids, 
                          const int64_t *out_start, int64_t row_stride, float *out_dist, int32_t *out_pos,
                          grafp_stream_t stream);
 
-/* Test hooks of the single-pass BatchNorm (no reference counterpart): the number of polls after which a workgroup stops
- * waiting for its row-mates and recomputes their partial sums itself (returns the previous value; < 0 only reads it;
- * 0 = never wait), and a kernel that merely occupies `blocks` x `threads` CU slots for `clocks` shader cycles. */
-int grafp_bn_debug_spin_limit(int polls);
-int grafp_debug_wgrad_tile(int cfg);   /* force a tile configuration of grafp_conv1x1_wgrad_bf16 (0..7, 9; -1 = heuristic); returns the previous one */
+/* Test helper (no reference counterpart, no state): a kernel that merely occupies `blocks` x `threads` CU slots for
+ * `clocks` shader cycles -- the BatchNorm rendezvous is tested next to it. */
 int grafp_debug_occupy(int blocks, int threads, int64_t clocks, grafp_stream_t stream);
 
 /* ---- K9 forward / data gradient: the 1x1 convolution itself as a streaming bf16 GEMM, BatchNorm folded in ----
@@ -290,6 +290,14 @@ int grafp_conv1x1_wgrad_plan(int Cout, int Cin, int groups, int64_t M, int views
 int grafp_conv1x1_wgrad_pro_bf16(const void *grad_out, const void *x, int Cout, int Cin, int groups, int64_t M,
                                  int views, const float *pro_tab, int pro_act, float pro_slope, float *dweight,
                                  void *ws, size_t ws_bytes, grafp_stream_t stream);
+/* The same with the tile configuration as an explicit per-call argument (tile = -1: the measured rule, what the
+ * entries above use; 0 ... 7: T 64x64, S 128x128, L 256x256, S32, M32 256x128, L32 (64-byte row pieces), SG, LG (G
+ * operand through registers); 9: the register-staged split-K kernel).  The rule picks the wide configurations only at
+ * sizes a test cannot afford for every shape, so the tests force each one on small cases through this entry. */
+size_t grafp_conv1x1_wgrad_tile_workspace(int Cout, int Cin, int groups, int64_t M, int views, int tile);
+int grafp_conv1x1_wgrad_tile_bf16(const void *grad_out, const void *x, int Cout, int Cin, int groups, int64_t M,
+                                  int views, const float *pro_tab, int pro_act, float pro_slope, int tile,
+                                  float *dweight, void *ws, size_t ws_bytes, grafp_stream_t stream);
 /* f32 operands (the f32 "parity" mode of the step): the same split-K streaming reduction with each value split into
  * hi = bf16(v), lo = bf16(v - hi) on the way into LDS and three bf16 MFMAs per tile step (Gh Xh + Gh Xl + Gl Xh; the
  * dropped Gl Xl term and the 16-bit representation are ~2^-16 relative, f32 accumulation).  Same layouts as above

@@ -862,21 +862,18 @@ def test_bn_single_pass_never_depends_on_absent_row_mates(dev):
         return z.detach(), xg.grad, g.grad, rm
 
     want = run()
-    old = lib.grafp_bn_debug_spin_limit(0)
-    try:
+    monkeypatch.setattr(ops.switches, "bn_spin_limit", 0)          # the spin_limit argument of grafp_bn_*_1pass
+    got = run()
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    monkeypatch.setattr(ops.switches, "bn_spin_limit", 16)
+    side = torch.cuda.Stream()
+    for blocks in (256, 480):
+        check(lib.grafp_debug_occupy(blocks, 1024, 60_000_000, ctypes.c_void_p(side.cuda_stream)), "occupy")
         got = run()
+        side.synchronize()
         for a, b in zip(got, want):
             assert torch.equal(a, b)
-        lib.grafp_bn_debug_spin_limit(16)
-        side = torch.cuda.Stream()
-        for blocks in (256, 480):
-            check(lib.grafp_debug_occupy(blocks, 1024, 60_000_000, ctypes.c_void_p(side.cuda_stream)), "occupy")
-            got = run()
-            side.synchronize()
-            for a, b in zip(got, want):
-                assert torch.equal(a, b)
-    finally:
-        lib.grafp_bn_debug_spin_limit(old)
 
 
 # =============================================================== IVF-PQ parity index

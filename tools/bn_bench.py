@@ -33,8 +33,7 @@ def main():
     ap.add_argument("--pad", type=int, default=None, help="elements between the three tensors (one allocation)")
     ap.add_argument("--affine", action="store_true", help="time the normalise pass (bn_affine_bf16_kernel) instead")
     args = ap.parse_args()
-    if args.spin is not None:
-        lib.grafp_bn_debug_spin_limit(args.spin)
+    spin = -1 if args.spin is None else args.spin
     dev, tot = "cuda:0", 0.0
     depth = (2, 2, 6, 2)
     if args.affine:
@@ -69,7 +68,7 @@ def main():
                 ws = torch.empty(nb, dtype=torch.uint8, device=dev)
                 sync = ops._bn_sync(yy.device, rows, M)
                 P = ops._p
-                t = timeit(lambda: ops.check(lib.grafp_bn_bwd_1pass(P(yy), P(dd), ops._DT[yy.dtype], rows, M, args.views, None, P(g), P(b), P(mean), P(invstd), ops.ACT_RELU, 0.0, 1, P(dx), P(dg), P(db), None, P(ws), nb, P(sync), ops._stream()), "bn_bwd"))
+                t = timeit(lambda: ops.check(lib.grafp_bn_bwd_1pass(P(yy), P(dd), ops._DT[yy.dtype], rows, M, args.views, None, P(g), P(b), P(mean), P(invstd), ops.ACT_RELU, 0.0, 1, P(dx), P(dg), P(db), None, P(ws), nb, P(sync), spin, ops._stream()), "bn_bwd"))
                 del buf
             tot += t * n * depth[stage]
             print(f"s{stage} rows {rows:5d} M {M:8d}: {t:8.1f} us  {3.0 * rows * M * 2 / t / 1e6:5.2f} TB/s", flush=True)
