@@ -19,6 +19,8 @@ the largest measured time, a step-level bytes / time figure, and the retrieval /
 """
 import argparse
 import contextlib
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -56,6 +58,17 @@ def parse():
     ap.add_argument("--backend", default=None, help="test hook: process-group backend (default nccl = RCCL)")
     ap.add_argument("--local-device", type=int, default=None, help="test hook: device index of every rank (ranks share a GPU)")
     return ap.parse_args()
+
+
+def kernel_sources_sha16():
+    """Fingerprint of the HIP sources (csrc/*.hip, *.h): tools/pmc_summary.py stamps it into profiles/pmc_*.json, and a
+    counter summary whose stamp differs from the sources of this run is NOT reported as `roofline.traffic`."""
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(ROOT, "grafp_amd", "csrc", "*.hip")) +
+                       glob.glob(os.path.join(ROOT, "grafp_amd", "csrc", "*.h"))):
+        with open(path, "rb") as f:
+            h.update(os.path.basename(path).encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
 
 
 def knn_flops(meta):
@@ -107,15 +120,28 @@ def summarise_kernels(timed, esize=4):
             row["two_ceiling_frac"] = round(ideal / (tot * 1e-3), 4)
         elif name == "conv1x1_gemm":
             # forward and data-gradient products of every 1x1 convolution: read W (small) and X (K rows), write Y (R rows)
-            by = sum((R + K) * M * 2.0 for _, _, (R, K, g, M) in ev)
-            fl = sum(2.0 * R * (K // g) * M for _, _, (R, K, g, M) in ev)
+            # (the concatenated-operand data gradients carry a fifth entry: operand rows that meet the identity block of
+            # [W^T | I] -- they are bytes, not useful flops)
+            shapes = [(m[0], m[1], m[2], m[3], m[4] if len(m) > 4 else 0) for _, _, m in ev]
+            by = sum((R + K) * M * 2.0 for R, K, g, M, ident in shapes)
+            fl = sum(2.0 * R * ((K - ident) // g) * M for R, K, g, M, ident in shapes)
             row["tflops"] = round(fl / (tot * 1e-3) / 1e12, 1)
             row["mfma_frac"] = round(fl / (tot * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)
             # the family mixes HBM-bound and matrix-bound shapes: per launch the roofline time is the LARGER of
             # bytes / HBM peak and flops / matrix peak; their sum over the measured time is the two-ceiling fraction
-            ideal = sum(max((R + K) * M * 2.0 / (PEAK_HBM_GBS * 1e9), 2.0 * R * (K // g) * M / (PEAK_BF16_MFMA_TFLOPS * 1e12))
-                        for _, _, (R, K, g, M) in ev)
+            ideal = sum(max((R + K) * M * 2.0 / (PEAK_HBM_GBS * 1e9),
+                            2.0 * R * ((K - ident) // g) * M / (PEAK_BF16_MFMA_TFLOPS * 1e12))
+                        for R, K, g, M, ident in shapes)
             row["two_ceiling_frac"] = round(ideal / (tot * 1e-3), 4)
+        elif name == "ntxent":
+            # S = Z Z^T tiles by exact-f32 MFMA, forward (log-sum-exp) + backward (dZ += W^T Z, two products): 3 x
+            # 2 (2 n_local)(2 B_all) D flops; 2 x 2 B D x 4 bytes in, the same out.  Latency-bound (one launch of a few
+            # hundred microseconds per step): the fraction says so
+            fl = sum(3.0 * 2.0 * (2 * nl) * (2 * Ba) * D for _, _, (Ba, nl, D) in ev)
+            by = sum(2.0 * (2 * Ba) * D * 4.0 + 2.0 * (2 * nl) * D * 4.0 for _, _, (Ba, nl, D) in ev)
+            row.update(bound="mfma", achieved=round(fl / (tot * 1e-3) / 1e12, 3), unit="TFLOP/s",
+                       peak=PEAK_F32_MATRIX_TFLOPS, tflops=round(fl / (tot * 1e-3) / 1e12, 3),
+                       note="exact-f32 MFMA; launch/latency-bound at these sizes")
         elif name == "logmel":
             by = sum(B * (4.0 * T + 4.0 * 64 * (1 + T // 512)) for _, _, (B, T) in ev)
         elif name == "peak_extract_fwd":
@@ -205,6 +231,19 @@ def retrieval_probe(device, cpu_check=True):
             res["tflops_nq4096"] = round(2.0 * 128 * n * nq / dt / 1e12, 2)
         if nq == 1:
             res["db_stream_GBps_nq1"] = round(n * 260.0 / dt / 1e9, 1)      # bf16 rows + norms
+        # roofline of one batched search: the pre-filter scan streams the bf16 rows + f32 norms once
+        # (n * 260 B) + queries and results; its 2*128*n*nq flops run on the bf16 matrix cores.  Small batches are
+        # bound by the stream (and by the launch chain around it), large ones by the matrix/epilogue side.
+        by = n * 260.0 + nq * 512.0 + nq * 20 * 12.0
+        fl = 2.0 * 128 * n * nq
+        t_hbm, t_mfma = by / (PEAK_HBM_GBS * 1e9), fl / (PEAK_BF16_MFMA_TFLOPS * 1e12)
+        if t_hbm >= t_mfma:
+            roof = {"bound": "hbm", "achieved": round(by / dt / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s"}
+        else:
+            roof = {"bound": "mfma", "achieved": round(fl / dt / 1e12, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s"}
+        roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
+        roof["floor_us"] = round(max(t_hbm, t_mfma) * 1e6, 1)
+        res.setdefault("roofline", {})[f"nq{nq}"] = roof
     # BASELINE config 4 end to end: 2000 test ids x 41-segment runs = 82 000 query segments, one batched search, then
     # ONE rerank launch over the 8000 (test id, length) items for lengths 1/11/21/41 (eval.py:262-301)
     n_ids, lens = 2000, (1, 11, 21, 41)
@@ -366,13 +405,48 @@ def main():
                    "query_sigma": QUERY_SIGMA}
         del index, rows
 
+    # ---- what RCCL itself costs at this world size: the two collectives of a step, timed alone (HIP events, 20 calls) ----
+    collectives = None
+    if world > 1:
+        def timed_coll(fn, reps=20):
+            fn()
+            barrier()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(reps):
+                fn()
+            e.record()
+            torch.cuda.synchronize()
+            return max_over_ranks(s.elapsed_time(e) / reps * 1e-3) * 1e6        # microseconds, slowest rank
+        mine = torch.randn(2, B, 128, device=device)
+        gathered = torch.empty((2 * world, B, 128), device=device)
+        sync = trainer.sync
+        collectives = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                       "all_gather_z_bytes_per_rank": int(mine.numel() * 4),
+                       "all_gather_z_us": round(timed_coll(lambda: dist.all_gather_into_tensor(gathered, mine)), 1),
+                       "bucket_bytes": [int((hi - lo) * 4) for lo, hi in sync.bounds],
+                       "bucket_all_reduce_us": [round(timed_coll(lambda lo=lo, hi=hi: dist.all_reduce(sync.flat[lo:hi])), 1)
+                                                for lo, hi in sync.bounds],
+                       "note": "each collective alone on an idle GPU, max over ranks; in a step the bucket all-reduces "
+                               "overlap backward (eager) or follow it (step_graph)"}
+        sync.flat.zero_()
+
     # ---- the same data-parallel step replayed from HIP graphs (forward | loss + backward + pack | Adam, the two
     #      collectives eager between them): every rank takes the same path, so the collectives stay aligned ----
     # (last of the legs: whatever happens here, everything above is already measured)
     hip_graph = None
     if world > 1 and not args.no_graph:
         try:
-            trainer.step_graph(x_i, x_j)
+            err = None
+            try:
+                trainer.step_graph(x_i, x_j)
+            except Exception as exc:      # noqa: BLE001
+                err = exc
+            # a rank that failed to capture must not leave the others waiting in the first collective of the timed loop
+            ok = torch.tensor([0.0 if err is not None else 1.0], device=device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if float(ok.item()) < 1.0:
+                raise err if err is not None else RuntimeError("step_graph failed on another rank")
             dt, _ = timed_steps(lambda: trainer.step_graph(x_i, x_j), args.steps, barrier)
             dt = max_over_ranks(dt)
             hip_graph = {"value": round(B * world * args.steps / dt, 2), "unit": "clips/s",
@@ -406,7 +480,10 @@ def main():
         if os.path.exists(pmc_path):
             with open(pmc_path) as f:
                 pmc = json.load(f)
-            if pmc.get("batch_per_gpu") == B and pmc.get("dtype") == args.dtype:
+            if pmc.get("kernel_sources_sha16") != kernel_sources_sha16():
+                roof["traffic_note"] = ("profiles/pmc_%s.json was collected on other kernel sources (stamp %s): not "
+                                        "reported" % (dom_name, pmc.get("kernel_sources_sha16")))
+            elif pmc.get("batch_per_gpu") == B and pmc.get("dtype") == args.dtype:
                 # gfx950: FETCH_SIZE tallies the 128-B requests of 16 B/lane streams at 64 B -> doubled
                 roof["traffic"] = int((2 * pmc["fetch_kb_per_launch"] + pmc["write_kb_per_launch"]) * 1024)
                 roof["traffic_unit"] = "bytes/launch"
@@ -436,8 +513,50 @@ def main():
         }
         if hip_graph is not None:
             line["hip_graph"] = hip_graph
+        if collectives is not None:
+            line["collectives"] = collectives
         if weak is not None:
             line["weak_scaling_256_per_gpu"] = weak
+        if world == 1 and not args.no_config2:
+            # BASELINE config 3's PER-GPU shape on this one GPU (128 pairs, no collectives): the compute part of one
+            # rank of the 8-GPU run, eager and as one HIP graph.  8-GPU scaling >= 6x over the N = 1 line needs this
+            # + the z all-gather + the 73.5 MB gradient all-reduce <= ms_per_step / 6.
+            B3 = 128
+            x3_i, x3_j = synthetic_batch(B3, seed=100, device=device)
+            t3 = Trainer(dict(cfg, bsz_train=B3), model, device, amp_dtype=amp)
+            for _ in range(3):
+                t3.step(x3_i, x3_j)
+            dt, _ = timed_steps(lambda: t3.step(x3_i, x3_j), args.steps, barrier)
+            c3 = {"pairs_per_gpu": B3, "ms_per_step": round(1e3 * dt / args.steps, 3),
+                  "clips_per_s_per_gpu": round(B3 * args.steps / dt, 2), "steps": args.steps,
+                  "budget_ms_for_6x_at_8_gpus": round(1e3 * elapsed / args.steps / 6.0, 3),
+                  "note": "one rank's compute at global batch 1024 on 8 GPUs, no collectives (measured on one GPU)"}
+            if not args.no_graph:
+                try:
+                    t3.step_graph(x3_i, x3_j)
+                    dt, _ = timed_steps(lambda: t3.step_graph(x3_i, x3_j), args.steps, barrier)
+                    c3["hip_graph_ms_per_step"] = round(1e3 * dt / args.steps, 3)
+                except Exception as exc:      # noqa: BLE001 -- report, do not fail the bench line
+                    c3["hip_graph_error"] = f"{type(exc).__name__}: {exc}"[:200]
+            del t3
+            line["config3_per_gpu_128"] = c3
+            # measured parity figures of THIS model and build (numbers, not prose): the free-running distance of the bf16
+            # mode from the f32 mode on 256 clip-views (eval mode, random-init weights) -- see tests/test_gpu_bf16.py for
+            # the teacher-forced <= 1e-3 bars against the oracle's bf16-storage restatement
+            model.eval()
+            with torch.no_grad():
+                segs_p = trainer.augment(x_i[:128], x_j[:128])
+                segs_p = torch.cat(segs_p, dim=0)
+                z32 = model.embed(segs_p)[1].float()
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    z16 = model.embed(segs_p)[1].float()
+            model.train()
+            rel = torch.linalg.norm(z16 - z32, dim=1) / torch.linalg.norm(z32, dim=1)
+            line["parity_measured"] = {"bf16_vs_f32_embedding_rel_l2_max": round(float(rel.max()), 5),
+                                       "bf16_vs_f32_embedding_rel_l2_mean": round(float(rel.mean()), 5),
+                                       "clip_views": int(segs_p.shape[0]),
+                                       "note": "free-running, eval mode, random-init weights; teacher-forced per-layer "
+                                               "bars (<= 1e-3 forward, <= 5e-3 backward) are in tests/test_gpu_bf16*.py"}
         if world == 1 and not args.no_config2:
             # BASELINE config 2: 256 pairs on one GPU -- eager, replayed from ONE HIP graph, and in f32
             B2 = 256

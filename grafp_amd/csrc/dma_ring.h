@@ -27,6 +27,12 @@ __device__ __forceinline__ void gm_dma16(const void *gsrc, unsigned lds_base) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_base) : "memory", "m0");
 }
 
+// the 4-bytes-per-lane form (256 bytes per instruction): small vectors that must not pass through the compiler's own
+// wait counting while 16-byte DMAs are in flight
+__device__ __forceinline__ void gm_dma4(const void *gsrc, unsigned lds_base) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(gsrc), "s"(lds_base) : "memory", "m0");
+}
+
 template <int N> __device__ __forceinline__ void gm_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 // at most `allowed` of this wave's newest vector-memory operations may still be in flight (rounded DOWN to a step)
 __device__ __forceinline__ void gm_wait_allowed(int allowed) {

@@ -140,7 +140,7 @@ class GraphEncoder(nn.Module):
         # of the (C,B,N) activations (graph_encoder.py:187-188 projects first: same result, 128x the work)
         # Always f32, also under bf16 autocast: B*512 numbers per step, and it keeps the embedding one rounding-free
         # function of the last block's (bf16-stored) node features.
-        with torch.autocast("cuda", enabled=False):
+        with torch.autocast(x.device.type, enabled=False):
             pooled = x.float().mean(dim=2)                                          # (C, B)
             w = self.proj.weight.reshape(self.proj.out_channels, -1)
             h = torch.mm(w.float(), pooled) + self.proj.bias.float().reshape(-1, 1)

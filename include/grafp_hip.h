@@ -117,6 +117,21 @@ size_t grafp_knn_pre_workspace(int B, int C, int N);
 int grafp_knn_graph_pre(const void *x, int dtype, int64_t stride_b, int64_t stride_c, int B, int C, int N, int k,
                         int normalize, void *idx, int idx_is_i32, void *ws, size_t ws_bytes, grafp_stream_t stream);
 
+/* ---- K3-K5 through a split-bf16 Gram matrix with certified results (knn_split.hip) -------------------------------
+ * The same (B, N, k) neighbour indices as grafp_knn_graph_f32 with normalize = 1, bit for bit, for the shapes
+ * grafp_knn_split_supported accepts (C % 32 == 0, N % 128 == 0, N <= 4096, k <= 4): every normalised feature is split
+ * into two bf16 halves, the Gram matrix runs on the bf16 matrix cores (three products per 16 channels), each query
+ * keeps its k + 1 smallest approximate distances, and a query whose consecutive distances are closer than twice the
+ * rigorous error bound of the approximation (near-ties, duplicates) is recomputed with the exact f32 arithmetic of
+ * grafp_knn_topk_f32.  x: any (b, c)-strided view with N contiguous, f32 or bf16 (as grafp_knn_normalize_strided);
+ * idx int64 or int32 (idx_is_i32); n_uncertified: NULL, or one device int that receives the number of queries that
+ * took the exact path (diagnostics). */
+int grafp_knn_split_supported(int C, int N, int k);
+size_t grafp_knn_split_workspace(int B, int C, int N);
+int grafp_knn_graph_split(const void *x, int dtype, int64_t stride_b, int64_t stride_c, int B, int C, int N, int k,
+                          void *idx, int idx_is_i32, void *ws, size_t ws_bytes, int32_t *n_uncertified,
+                          grafp_stream_t stream);
+
 /* ---- K6-K7: edge gather + max-relative aggregation -------------------------------------------
  * Replaces batched_index_select x2 (encoder/gcn_lib/torch_nn.py:79-98) + max over k of (x_j - x_i)
  * + channel interleave (torch_vertex.py:21-32):

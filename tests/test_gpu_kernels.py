@@ -86,6 +86,57 @@ def test_knn_graph_prefilter_equals_f32_path(dev, C, N, B):
         assert torch.equal(ops.knn_graph(xt, k, prefilter=False), ops.knn_graph(xt, k, prefilter=True))
 
 
+@pytest.mark.parametrize("C,N,B", [(64, 1024, 3), (128, 512, 2), (256, 256, 3), (512, 128, 2), (64, 128, 5), (32, 256, 2)])
+def test_knn_graph_split_equals_f32_path(dev, C, N, B):
+    """knn_split.hip (split-bf16 Gram matrix, certified order, exact recomputation of the uncertified queries) -- the
+    DEFAULT path of ops.knn_graph -- against knn_graph.hip (all exact f32) and the C oracle: normal features, a tight
+    cluster (near-ties: uncertified), exact duplicates (ties -> lowest index), k = 1 ... 4, both layouts, bf16 input,
+    int32 / int64 indices.  Random features certify almost every query; duplicates must go through the exact path."""
+    from grafp_amd import ops
+    from oracle import native
+    assert ops.switches.knn_split
+    x = hash_normalish(f"gpu:knnsplit.{C}.{N}", (B, C, N)).astype(np.float32)
+    x[0, :, 40:100] = x[0, :, 40:41] + 1e-3 * hash_normalish(f"gpu:knnsplit.c.{C}.{N}", (C, 60))   # a tight cluster
+    x[1, :, 10:50] = x[1, :, 10:11]                                                                # exact duplicates
+    xt = t(x).to(dev)
+    for k in (3, 1, 2, 4):
+        a = ops.knn_graph(xt, k, prefilter=False)                     # exact-f32 MFMA kernel
+        b, unc = ops.knn_graph_split(xt, k, return_uncertified=True)
+        assert torch.equal(a, b), (k, int((a != b).sum()))
+        assert torch.equal(ops.knn_graph(xt, k), a)                  # the default route IS the split path
+        if k == 3:
+            assert np.array_equal(b.cpu().numpy(), native.knn_graph(x, 3))
+            # every duplicate sees >= 39 candidates at distance exactly 0: never certified
+            assert 40 <= int(unc) <= 0.25 * B * N, int(unc)
+    b32 = ops.knn_graph(xt, 3, index_dtype=torch.int32)
+    assert b32.dtype == torch.int32 and torch.equal(b32.to(torch.int64), ops.knn_graph(xt, 3, prefilter=False))
+    xc = xt.permute(1, 0, 2).contiguous()                               # (C, B, N) layout, bf16 activations
+    for dt in (torch.float32, torch.bfloat16):
+        assert torch.equal(ops.knn_graph(xc.to(dt), 3, layout="cbn", prefilter=False),
+                           ops.knn_graph(xc.to(dt), 3, layout="cbn"))
+    # plain random features: almost everything certifies (the exact path is the exception, not the rule)
+    y = t(hash_normalish(f"gpu:knnsplit.r.{C}.{N}", (B, C, N)).astype(np.float32)).to(dev)
+    idx, unc = ops.knn_graph_split(y, 3, return_uncertified=True)
+    assert torch.equal(idx, ops.knn_graph(y, 3, prefilter=False))
+    assert int(unc) <= 0.05 * B * N, (int(unc), B * N)
+
+
+def test_knn_graph_split_worst_cases(dev):
+    """All nodes identical (every distance ties: the whole clip takes the exact path, lowest indices win), one-hot
+    features (exact zeros / exact ties at distance 2) and features of wildly different scale before normalisation."""
+    from grafp_amd import ops
+    from oracle import native
+    B, C, N = 2, 64, 256
+    x = np.ones((B, C, N), dtype=np.float32)
+    x[1] = np.eye(C, dtype=np.float32)[:, np.arange(N) % C]
+    xt = t(x).to(dev)
+    idx, unc = ops.knn_graph_split(xt, 3, return_uncertified=True)
+    assert int(unc) == B * N
+    assert np.array_equal(idx.cpu().numpy(), native.knn_graph(x, 3))
+    z = hash_normalish("gpu:knnsplit.scale", (B, C, N)).astype(np.float32) * np.logspace(-20, 15, N, dtype=np.float32)[None, None, :]
+    assert np.array_equal(ops.knn_graph(t(z).to(dev), 3).cpu().numpy(), native.knn_graph(z, 3))
+
+
 def test_knn_graph_full_batch_properties(dev):
     """BASELINE config-2 size (B=256, stage 0): size-independent properties + a sampled exact check."""
     from grafp_amd import ops
