@@ -13,8 +13,8 @@
 //     selects) plus the smallest key that did not make the list (the (k+1)-th);
 //   * a query is CERTIFIED when consecutive entries of its (k+1)-list are more than 2 m (+ the key truncation) apart:
 //     then the oracle's f32 distances have the same strict order and no candidate outside the list can enter it.  The
-//     few uncertified queries (near-ties, duplicates: ~1 % on encoder features) go to a list and knn_exact_rows_kernel
-//     recomputes them with the oracle's exact arithmetic (c-ordered fmaf chains, (sq_i + (-2 g)) + sq_j, ties to the
+//     few uncertified queries (near-ties, duplicates: 1-3 % on encoder features) are flagged and knn_exact_clip_kernel
+//     recomputes them, clip by clip, with the oracle's exact arithmetic (c-ordered fmaf chains, (sq_i + (-2 g)) + sq_j, ties to the
 //     lowest index).
 // Error budget for unit-norm rows (|x| = |y| = 1 up to rounding; the entry requires normalize = 1), C channels:
 //   representation            3.01 * 2^-18                       = 1.15e-5
@@ -41,10 +41,12 @@ constexpr float KS_SHIFT = 9.765625e-4f;    // 2^-10
 __device__ __forceinline__ float ks_ld(const float *p) { return *p; }
 __device__ __forceinline__ float ks_ld(const unsigned short *p) { return __uint_as_float(((unsigned)*p) << 16); }
 
-// pass 1: channel-L2 normalisation exactly as knn_normalize_kernel (same chains, same bits in xn / sq) + the split planes
+// pass 1: channel-L2 normalisation exactly as knn_normalize_kernel (same chains, same bits) -- but the normalised f32
+// values are not written: only their two bf16 halves, the squared norms and the denominators (pass 3 re-derives any f32
+// value it needs as x / den, the same IEEE division)
 template <typename T>
 __global__ __launch_bounds__(256) void knn_normalize_split_kernel(const T *__restrict__ x, int64_t sb, int64_t sc,
-                                                                  float *__restrict__ xn, float *__restrict__ sq,
+                                                                  float *__restrict__ den_out, float *__restrict__ sq,
                                                                   unsigned short *__restrict__ xh,
                                                                   unsigned short *__restrict__ xl, int C, int N) {
     const int n = blockIdx.x * 256 + threadIdx.x;
@@ -74,7 +76,6 @@ __global__ __launch_bounds__(256) void knn_normalize_split_kernel(const T *__res
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             v[u] = __fdiv_rn(v[u], den);
-            xn[o + (size_t)(c + u) * N] = v[u];
             q = __builtin_fmaf(v[u], v[u], q);
             const unsigned h = gm_pack_bf16(v[u], 0.0f) & 0xffffu;
             const float r = v[u] - __uint_as_float(h << 16);          // exact
@@ -84,7 +85,6 @@ __global__ __launch_bounds__(256) void knn_normalize_split_kernel(const T *__res
     }
     for (; c < C; ++c) {
         const float v = __fdiv_rn(ks_ld(xb + (size_t)c * sc), den);
-        xn[o + (size_t)c * N] = v;
         q = __builtin_fmaf(v, v, q);
         const unsigned h = gm_pack_bf16(v, 0.0f) & 0xffffu;
         const float r = v - __uint_as_float(h << 16);
@@ -92,6 +92,14 @@ __global__ __launch_bounds__(256) void knn_normalize_split_kernel(const T *__res
         xl[o + (size_t)c * N] = (unsigned short)(gm_pack_bf16(r, 0.0f) & 0xffffu);
     }
     sq[(size_t)b * N + n] = q;
+    den_out[(size_t)b * N + n] = den;
+}
+
+// (distance, index) as one order-preserving 64-bit key (every finite float)
+__device__ __forceinline__ unsigned long long ks_key64(float d, int i) {
+    unsigned u = __float_as_uint(d);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((unsigned long long)u << 32) | (unsigned)i;
 }
 
 // K smallest keys, ascending, + the smallest key that left (or never entered) the list
@@ -123,7 +131,9 @@ template <int K, typename I>
 __global__ __launch_bounds__(256, 2) void knn_topk_split_kernel(const unsigned short *__restrict__ xh,
                                                                 const unsigned short *__restrict__ xl,
                                                                 const float *__restrict__ sq, I *__restrict__ idx,
-                                                                int *__restrict__ unc_count, int *__restrict__ unc_list,
+                                                                int *__restrict__ unc_count,
+                                                                unsigned char *__restrict__ unc_flag,
+                                                                int *__restrict__ extra, int *__restrict__ light_list,
                                                                 int C, int N, int tiles_per_clip, int nblocks,
                                                                 float margin2, unsigned key_mask) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -191,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void knn_topk_split_kernel(const unsigned s
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc[t][r] = 0.0f; prev[t][r] = 0.0f; }
-    KeyList<K> best;
+    KeyList<K + 1> best;                                       // the k + 1 smallest keys, + the next one
     best.init();
 
     // key of element e (tile e / 16, register e % 16) of a finished block: the index bits of a lane never overlap --
@@ -247,102 +257,239 @@ __global__ __launch_bounds__(256, 2) void knn_topk_split_kernel(const unsigned s
         for (int e = 0; e < 64; ++e) insert(prev, e, ((nblk + 2) % 3) * KS_TR, bits_last);
     }
     // the two half-waves saw disjoint candidate subsets of the same query
-    unsigned ok[K], onext = (unsigned)__shfl_xor((int)best.next, 32);
+    unsigned ok[K + 1], onext = (unsigned)__shfl_xor((int)best.next, 32);
 #pragma unroll
-    for (int t = 0; t < K; ++t) ok[t] = (unsigned)__shfl_xor((int)best.k[t], 32);
+    for (int t = 0; t <= K; ++t) ok[t] = (unsigned)__shfl_xor((int)best.k[t], 32);
 #pragma unroll
-    for (int t = 0; t < K; ++t) best.push(ok[t]);
+    for (int t = 0; t <= K; ++t) best.push(ok[t]);
     best.next = onext < best.next ? onext : best.next;
     if (half == 0) {
         const unsigned imask = ~key_mask;
-        I *o = idx + ((size_t)b * N + myq) * K;
-        bool certified = true;
-        // consecutive entries (the (k+1)-th included) further apart than 2 m + the truncation of the lower one's key
+        const size_t row = (size_t)b * N + myq;
+        I *o = idx + row * K;
+        // CERTIFIED: consecutive entries of the (k+1)-list further apart than 2 m (+ the truncation of the lower key):
+        // the oracle's distances have the same strict order and nothing outside the first k can enter.
+        // LIGHT: not certified, but the (k+2)-th smallest key is beyond 2 m of the k-th: the exact top k are among the
+        // k + 1 listed candidates (every unlisted one is strictly worse than the first k listed) -- pass 3a recomputes
+        // those k + 1 distances exactly.  HEAVY (>= 3 candidates inside the band of the k-th: clusters, duplicates):
+        // pass 3b rescans the whole clip for the query.
         const float trunc = __uint_as_float(0x3f800000u + imask) - 1.0f;       // relative size of the dropped mantissa bits
+        bool certified = true;
 #pragma unroll
         for (int t = 0; t < K; ++t) {
-            const float lo = __uint_as_float(best.k[t] & key_mask);
-            const float hi = __uint_as_float((t + 1 < K ? best.k[t + 1] : best.next) & key_mask);
+            const float lo = __uint_as_float(best.k[t] & key_mask), hi = __uint_as_float(best.k[t + 1] & key_mask);
             certified = certified && (hi - lo * (1.0f + trunc) > margin2);
             o[t] = (I)(best.k[t] & imask);
         }
-        if (!certified) unc_list[atomicAdd(unc_count, 1)] = b * N + myq;
+        const bool light = __uint_as_float(best.next & key_mask) -
+                               __uint_as_float(best.k[K - 1] & key_mask) * (1.0f + trunc) > margin2;
+        unc_flag[row] = certified ? 0 : (light ? 1 : 2);
+        if (!certified) {
+            atomicAdd(unc_count, 1);                                           // diagnostics: all uncertified queries
+            if (light) {
+                extra[row] = (int)(best.k[K] & imask);
+                light_list[atomicAdd(unc_count + 1, 1)] = (int)row;
+            }
+        }
     }
 }
 
-// pass 3: the uncertified queries with the oracle's exact arithmetic.  One wave per query; lane l takes candidates l, l + 64,
-// ... (ascending, so the strict-< insert keeps the lower index on ties), c-ordered fmaf chains, then K rounds of a
-// wave-wide (distance, index) minimum.
-__device__ __forceinline__ unsigned long long ks_key64(float d, int i) {
-    unsigned u = __float_as_uint(d);
-    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);                           // order-preserving for every finite float
-    return ((unsigned long long)u << 32) | (unsigned)i;
+// pass 3a: a LIGHT query -- exact distances to its k + 1 listed candidates only (c-ordered fmaf chains on x / den, the
+// oracle's arithmetic), ranked by (distance, index).  8 lanes per query (lane s < k + 1 takes candidate s).
+template <int K, typename I, typename T>
+__global__ __launch_bounds__(256) void knn_exact_pairs_kernel(const T *__restrict__ x, int64_t sb, int64_t sc,
+                                                              const float *__restrict__ den, const float *__restrict__ sq,
+                                                              const int *__restrict__ counts,
+                                                              const int *__restrict__ light_list,
+                                                              const int *__restrict__ extra, I *__restrict__ idx, int C,
+                                                              int N) {
+    const int lane = threadIdx.x & 63, sub = lane & 7;
+    const int slot = (blockIdx.x * 256 + threadIdx.x) >> 3, nslots = gridDim.x * 32;
+    const int count = counts[1];
+    for (int base = 0; base < count; base += nslots) {
+        const int e = base + slot;
+        const bool active = e < count && sub <= K;
+        unsigned long long key = ~0ull;
+        int row = 0, j = 0;
+        if (active) {
+            row = light_list[e];
+            const int b = row / N, q = row - b * N;
+            j = sub < K ? (int)idx[(size_t)row * K + sub] : extra[row];
+            const T *xb = x + (size_t)b * sb;
+            const float dq = den[row], dj = den[(size_t)b * N + j];
+            float g = 0.0f;
+            for (int c = 0; c < C; c += 8) {                   // C % 32 == 0
+                float vq[8], vj[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    vq[u] = ks_ld(xb + (size_t)(c + u) * sc + q);
+                    vj[u] = ks_ld(xb + (size_t)(c + u) * sc + j);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) g = __builtin_fmaf(__fdiv_rn(vj[u], dj), __fdiv_rn(vq[u], dq), g);
+            }
+            const float d = __builtin_fmaf(-2.0f, g, sq[row]) + sq[(size_t)b * N + j];   // (sq_i + (-2 g)) + sq_j
+            key = ks_key64(d, j);
+        }
+        // rank inside the 8-lane group (keys are distinct: the indices are)
+        int rank = 0;
+#pragma unroll
+        for (int t = 0; t <= K; ++t) {
+            const unsigned long long other = __shfl(key, (lane & ~7) + t);
+            rank += other < key ? 1 : 0;
+        }
+        if (active && rank < K) idx[(size_t)row * K + rank] = (I)j;
+    }
 }
 
-template <int K, typename I>
-__global__ __launch_bounds__(256) void knn_exact_rows_kernel(const float *__restrict__ xn, const float *__restrict__ sq,
-                                                             I *__restrict__ idx, const int *__restrict__ unc_count,
-                                                             const int *__restrict__ unc_list, int C, int N) {
-    const int lane = threadIdx.x & 63;
-    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
-    const int count = *unc_count;
-    for (int e = gw; e < count; e += nw) {
-        const int row = unc_list[e];
-        const int b = row / N, q = row - b * N;
-        const float *xb = xn + (size_t)b * C * N;
-        const float *sqb = sq + (size_t)b * N;
-        const float sq_q = sqb[q];
-        float bd[K];
-        int bi[K];
+// pass 3b: the HEAVY queries with the oracle's exact arithmetic against every candidate.  One workgroup per CLIP (its feature slab is read
+// once per group of 16 uncertified queries instead of once per query): the queries' normalised vectors sit in LDS, thread t
+// takes candidates t, t + 256, ... (ascending, so the strict-< insert keeps the lower index on ties), re-derives the
+// candidate's normalised features as x / den (the division of pass 1), runs the c-ordered fmaf chains of the 16 queries
+// side by side, and the block then takes K rounds of a (distance, index) minimum per query.
+constexpr int KX_QG = 16;        // uncertified queries per pass over the clip's features
+constexpr int KX_NU = 2;         // candidates per thread and pass (256 threads: column ranges of 512 nodes)
+constexpr int KX_CHUNK = 16384;  // bytes of one staged feature chunk (double buffered)
+
+template <int K, typename I, typename T>
+__global__ __launch_bounds__(256) void knn_exact_clip_kernel(const T *__restrict__ x, int64_t sb, int64_t sc,
+                                                             const float *__restrict__ den, const float *__restrict__ sq,
+                                                             const unsigned char *__restrict__ unc_flag,
+                                                             I *__restrict__ idx, int C, int N, int chc) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm_x[];
+    T *sX = reinterpret_cast<T *>(sm_x);                                       // [2][chc][W] feature chunks (W columns)
+    float *sQ = reinterpret_cast<float *>(sm_x + 2 * KX_CHUNK);                 // [KX_QG][C]
+    int *s_list = reinterpret_cast<int *>(sQ + KX_QG * C);                      // [N]
+    __shared__ int s_n;
+    __shared__ unsigned long long s_red[4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    for (int q = tid; q < N; q += 256)
+        if (unc_flag[(size_t)b * N + q] == 2) s_list[atomicAdd(&s_n, 1)] = q;          // the HEAVY queries of this clip
+    __syncthreads();
+    const int n = s_n;
+    if (n == 0) return;
+    const T *xb = x + (size_t)b * sb;
+    const float *denb = den + (size_t)b * N, *sqb = sq + (size_t)b * N;
+    const int W = N < 256 * KX_NU ? N : 256 * KX_NU;          // columns per range (N % 128 == 0)
+    constexpr int VE = 16 / (int)sizeof(T);                    // elements per 16-byte vector
+    const int vrow = W / VE, nvec = chc * vrow;                // vectors per row / per chunk
+    for (int g0 = 0; g0 < n; g0 += KX_QG) {
+        const int ng = n - g0 < KX_QG ? n - g0 : KX_QG;
+        __syncthreads();
+        for (int i = tid; i < ng * C; i += 256) {
+            const int qi = i / C, c = i - qi * C, q = s_list[g0 + qi];
+            sQ[qi * C + c] = __fdiv_rn(ks_ld(xb + (size_t)c * sc + q), denb[q]);
+        }
+        float sqq[KX_QG], bd[KX_QG][K];
+        int bi[KX_QG][K];
 #pragma unroll
-        for (int t = 0; t < K; ++t) { bd[t] = INFINITY; bi[t] = 0x7fffffff; }
-        for (int j0 = 0; j0 < N; j0 += 256) {
-            float g[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            for (int c = 0; c < C; ++c) {
-                const float a = xb[(size_t)c * N + q];
-                const float *r = xb + (size_t)c * N + j0 + lane;
+        for (int qi = 0; qi < KX_QG; ++qi) {
+            sqq[qi] = qi < ng ? sqb[s_list[g0 + qi]] : 0.0f;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int j = j0 + lane + 64 * u;
-                    const float v = j < N ? r[64 * u] : 0.0f;
-                    g[u] = __builtin_fmaf(v, a, g[u]);
+            for (int t = 0; t < K; ++t) { bd[qi][t] = INFINITY; bi[qi][t] = 0x7fffffff; }
+        }
+        for (int j0 = 0; j0 < N; j0 += W) {                    // candidate column ranges, ascending
+            float g[KX_NU][KX_QG], dj[KX_NU];
+#pragma unroll
+            for (int u = 0; u < KX_NU; ++u) {
+                const int j = j0 + tid + 256 * u;
+                dj[u] = (tid + 256 * u < W) ? denb[j] : 1.0f;
+#pragma unroll
+                for (int qi = 0; qi < KX_QG; ++qi) g[u][qi] = 0.0f;
+            }
+            // chunks of chc channels x W columns through LDS by LDS-DMA (1 KiB per wave instruction, lane-linear: vector
+            // v of the chunk lands at byte 16 v), the next chunk in flight while this one is consumed
+            const int nchunk = C / chc;
+            auto dma = [&](int ck) {
+                const unsigned dst = (unsigned)(uintptr_t)(gm_lptr)sm_x + (ck & 1) * KX_CHUNK;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int v0 = (r * 4 + wave) * 64;        // wave-uniform; nvec is a multiple of 64
+                    if (v0 < nvec) {
+                        const int v = v0 + lane, row = v / vrow, cv = v - row * vrow;
+                        gm_dma16(xb + (size_t)(ck * chc + row) * sc + j0 + cv * VE, dst + v0 * 16);
+                    }
                 }
+            };
+            dma(0);
+            gm_wait_vm<0>();
+            __syncthreads();                                   // chunk 0 landed; sQ is complete
+            for (int ck = 0; ck < nchunk; ++ck) {
+                const T *buf = sX + (size_t)(ck & 1) * (KX_CHUNK / sizeof(T));
+                if (ck + 1 < nchunk) dma(ck + 1);
+                for (int cc = 0; cc < chc; ++cc) {
+                    const int c = ck * chc + cc;
+                    float a[KX_QG];
+#pragma unroll
+                    for (int qi = 0; qi < KX_QG; ++qi) a[qi] = sQ[qi * C + c];
+#pragma unroll
+                    for (int u = 0; u < KX_NU; ++u) {
+                        if (tid + 256 * u < W) {
+                            const float v = __fdiv_rn(ks_ld(buf + (size_t)cc * W + tid + 256 * u), dj[u]);
+#pragma unroll
+                            for (int qi = 0; qi < KX_QG; ++qi) g[u][qi] = __builtin_fmaf(v, a[qi], g[u][qi]);
+                        }
+                    }
+                }
+                gm_wait_vm<0>();
+                __syncthreads();                               // next chunk landed; this buffer may be overwritten
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = j0 + lane + 64 * u;
-                if (j < N) {
-                    float v = __builtin_fmaf(-2.0f, g[u], sq_q) + sqb[j];      // (sq_i + (-2 g)) + sq_j
-                    int vi = j;
-                    const float v0 = v;
+            for (int u = 0; u < KX_NU; ++u) {
+                const int j = j0 + tid + 256 * u;
+                if (tid + 256 * u < W) {
+                    const float sqj = sqb[j];
 #pragma unroll
-                    for (int t = 0; t < K; ++t) {                              // TopK::push_ascending
-                        const bool take = v0 < bd[t];
-                        const float od = bd[t];
-                        const int oi = bi[t];
-                        bd[t] = take ? v : od;
-                        bi[t] = take ? vi : oi;
-                        v = take ? od : v;
-                        vi = take ? oi : vi;
+                    for (int qi = 0; qi < KX_QG; ++qi) {
+                        if (qi < ng) {
+                            float v = __builtin_fmaf(-2.0f, g[u][qi], sqq[qi]) + sqj;      // (sq_i + (-2 g)) + sq_j
+                            int vi = j;
+                            const float v0 = v;
+#pragma unroll
+                            for (int t = 0; t < K; ++t) {                              // TopK::push_ascending
+                                const bool take = v0 < bd[qi][t];
+                                const float od = bd[qi][t];
+                                const int oi = bi[qi][t];
+                                bd[qi][t] = take ? v : od;
+                                bi[qi][t] = take ? vi : oi;
+                                v = take ? od : v;
+                                vi = take ? oi : vi;
+                            }
+                        }
                     }
                 }
             }
         }
-        I *o = idx + (size_t)row * K;
 #pragma unroll
-        for (int t = 0; t < K; ++t) {
-            unsigned long long mine = bi[0] == 0x7fffffff ? ~0ull : ks_key64(bd[0], bi[0]), m = mine;
+        for (int qi = 0; qi < KX_QG; ++qi) {
+            if (qi < ng) {                                                     // block-uniform
+                I *o = idx + ((size_t)b * N + s_list[g0 + qi]) * K;
 #pragma unroll
-            for (int s = 1; s < 64; s <<= 1) {
-                const unsigned long long other = __shfl_xor(m, s);
-                m = other < m ? other : m;
-            }
-            if (lane == 0) o[t] = (I)(unsigned)(m & 0xffffffffull);
-            if (mine == m) {                                                   // the winner pops its head
+                for (int t = 0; t < K; ++t) {
+                    const unsigned long long mine = bi[qi][0] == 0x7fffffff ? ~0ull : ks_key64(bd[qi][0], bi[qi][0]);
+                    unsigned long long m = mine;
 #pragma unroll
-                for (int u = 0; u + 1 < K; ++u) { bd[u] = bd[u + 1]; bi[u] = bi[u + 1]; }
-                bd[K - 1] = INFINITY;
-                bi[K - 1] = 0x7fffffff;
+                    for (int s2 = 1; s2 < 64; s2 <<= 1) {
+                        const unsigned long long other = __shfl_xor(m, s2);
+                        m = other < m ? other : m;
+                    }
+                    if (lane == 0) s_red[wave] = m;
+                    __syncthreads();
+                    m = s_red[0];
+#pragma unroll
+                    for (int w = 1; w < 4; ++w) m = s_red[w] < m ? s_red[w] : m;
+                    __syncthreads();
+                    if (tid == 0) o[t] = (I)(unsigned)(m & 0xffffffffull);
+                    if (mine == m) {                                           // the winner pops its head
+#pragma unroll
+                        for (int u = 0; u + 1 < K; ++u) { bd[qi][u] = bd[qi][u + 1]; bi[qi][u] = bi[qi][u + 1]; }
+                        bd[qi][K - 1] = INFINITY;
+                        bi[qi][K - 1] = 0x7fffffff;
+                    }
+                }
             }
         }
     }
@@ -363,15 +510,65 @@ static bool ks_supported(int C, int N, int k) {
 }
 static size_t ks_align(size_t v) { return (v + 255) & ~(size_t)255; }
 
+struct KsArgs {
+    const void *x;
+    bool f32;
+    int64_t sb, sc;
+    const unsigned short *xh, *xl;
+    const float *sq, *den;
+    int *count, *extra, *light;
+    unsigned char *flag;
+    void *idx;
+    int B, C, N;
+    float margin2;
+    unsigned key_mask;
+};
+template <int K, typename I, typename T> static void ks_launch_exact(const KsArgs &a, hipStream_t s) {
+    // pass 3b stages chunks of `chc` channels x min(N, 512) columns (<= 16 KB; a power of two, C % 32 == 0)
+    const int wcols = a.N < 256 * KX_NU ? a.N : 256 * KX_NU;
+    int chc = 32;
+    while (chc > 1 && (size_t)chc * wcols * sizeof(T) > KX_CHUNK) chc >>= 1;
+    const size_t lds_x = (size_t)2 * KX_CHUNK + (size_t)KX_QG * a.C * 4 + (size_t)a.N * 4;
+    hipLaunchKernelGGL((knn_exact_pairs_kernel<K, I, T>), dim3(1024), dim3(256), 0, s, (const T *)a.x, a.sb, a.sc, a.den,
+                       a.sq, a.count, a.light, a.extra, (I *)a.idx, a.C, a.N);
+    (void)hipFuncSetAttribute((const void *)knn_exact_clip_kernel<K, I, T>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds_x);
+    hipLaunchKernelGGL((knn_exact_clip_kernel<K, I, T>), dim3(a.B), dim3(256), lds_x, s, (const T *)a.x, a.sb, a.sc, a.den,
+                       a.sq, a.flag, (I *)a.idx, a.C, a.N, chc);
+}
+template <int K, typename I> static void ks_launch(const KsArgs &a, hipStream_t s) {
+    const int tiles = a.N / KS_TQ, nblocks = a.B * tiles;
+    (void)hipFuncSetAttribute((const void *)knn_topk_split_kernel<K, I>, hipFuncAttributeMaxDynamicSharedMemorySize, KS_LDS);
+    hipLaunchKernelGGL((knn_topk_split_kernel<K, I>), dim3(nblocks), dim3(256), KS_LDS, s, a.xh, a.xl, a.sq, (I *)a.idx,
+                       a.count, a.flag, a.extra, a.light, a.C, a.N, tiles, nblocks, a.margin2, a.key_mask);
+    if (a.f32) ks_launch_exact<K, I, float>(a, s);
+    else ks_launch_exact<K, I, unsigned short>(a, s);
+}
+template <typename I> static void ks_launch_k(int k, const KsArgs &a, hipStream_t s) {
+    switch (k) {
+    case 1: ks_launch<1, I>(a, s); break;
+    case 2: ks_launch<2, I>(a, s); break;
+    case 3: ks_launch<3, I>(a, s); break;
+    default: ks_launch<4, I>(a, s); break;
+    }
+}
+
 }  // namespace grafp
 
 extern "C" int grafp_knn_split_supported(int C, int N, int k) { return grafp::ks_supported(C, N, k) ? 1 : 0; }
+
+// Where the split path measured faster than the exact-f32 MFMA kernel (tools/knn_bench.py, random unit features at 2048
+// clip-views and the encoder's own features at 256): C = 64: 1.69 vs 3.62 ms, C = 128: 0.98 vs 1.70 ms; C = 256 ties
+// (0.87 vs 0.90) and C = 512 loses (0.97 vs 0.60 ms: the error bound grows with C, 3-8 % of the queries take the exact
+// passes, which cost more than the 128-candidate scan they replace).
+extern "C" int grafp_knn_split_preferred(int C, int N, int k) { return grafp::ks_supported(C, N, k) && C <= 128 ? 1 : 0; }
 
 extern "C" size_t grafp_knn_split_workspace(int B, int C, int N) {
     using namespace grafp;
     if (B <= 0 || C <= 0 || N <= 0) return 0;
     const size_t e = (size_t)B * C * N;
-    return ks_align(e * 4) + ks_align((size_t)B * N * 4) + 2 * ks_align(e * 2) + 256 + ks_align((size_t)B * N * 4);
+    return 2 * ks_align((size_t)B * N * 4) + 2 * ks_align(e * 2) + 256 + ks_align((size_t)B * N) +
+           2 * ks_align((size_t)B * N * 4);
 }
 
 extern "C" int grafp_knn_graph_split(const void *x, int dtype, int64_t stride_b, int64_t stride_c, int B, int C, int N,
@@ -391,47 +588,36 @@ extern "C" int grafp_knn_graph_split(const void *x, int dtype, int64_t stride_b,
     hipStream_t s = (hipStream_t)stream;
     const size_t e = (size_t)B * C * N;
     char *p = (char *)ws;
-    float *xn = (float *)p;                       p += ks_align(e * 4);
     float *sq = (float *)p;                       p += ks_align((size_t)B * N * 4);
+    float *den = (float *)p;                      p += ks_align((size_t)B * N * 4);
     unsigned short *xh = (unsigned short *)p;     p += ks_align(e * 2);
     unsigned short *xl = (unsigned short *)p;     p += ks_align(e * 2);
     int *count = (int *)p;                        p += 256;
-    int *list = (int *)p;
-    GRAFP_REQUIRE((((uintptr_t)xh | (uintptr_t)xl) & 15) == 0, "knn_graph_split: workspace must be 16-byte aligned");
-    if (hipMemsetAsync(count, 0, sizeof(int), s) != hipSuccess) {
+    unsigned char *flag = (unsigned char *)p;     p += ks_align((size_t)B * N);
+    int *extra = (int *)p;                        p += ks_align((size_t)B * N * 4);
+    int *light = (int *)p;
+    GRAFP_REQUIRE((((uintptr_t)xh | (uintptr_t)xl | (uintptr_t)x) & 15) == 0 && (stride_b * (dtype == GRAFP_F32 ? 4 : 2)) % 16 == 0 &&
+                      (stride_c * (dtype == GRAFP_F32 ? 4 : 2)) % 16 == 0,
+                  "knn_graph_split: input rows and workspace must be 16-byte aligned");
+    if (hipMemsetAsync(count, 0, 2 * sizeof(int), s) != hipSuccess) {       // [0] all uncertified, [1] the light ones
         set_error("knn_graph_split: hipMemsetAsync failed");
         return GRAFP_ERR_LAUNCH;
     }
     const dim3 gn((N + 255) / 256, B);
     if (dtype == GRAFP_F32)
         hipLaunchKernelGGL(knn_normalize_split_kernel<float>, gn, dim3(256), 0, s, (const float *)x, stride_b, stride_c,
-                           xn, sq, xh, xl, C, N);
+                           den, sq, xh, xl, C, N);
     else
         hipLaunchKernelGGL(knn_normalize_split_kernel<unsigned short>, gn, dim3(256), 0, s, (const unsigned short *)x,
-                           stride_b, stride_c, xn, sq, xh, xl, C, N);
+                           stride_b, stride_c, den, sq, xh, xl, C, N);
     GRAFP_CHECK_LAUNCH("knn_normalize_split_kernel");
-    const int tiles = N / KS_TQ, nblocks = B * tiles;
-    const unsigned key_mask = ~((1u << ks_index_bits(N)) - 1u);
-    const float margin2 = 2.0f * ks_margin(C);
-#define KS_LAUNCH(K, I)                                                                                                 \
-    do {                                                                                                                \
-        (void)hipFuncSetAttribute((const void *)knn_topk_split_kernel<K, I>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                  KS_LDS);                                                                              \
-        hipLaunchKernelGGL((knn_topk_split_kernel<K, I>), dim3(nblocks), dim3(256), KS_LDS, s, xh, xl, sq, (I *)idx,     \
-                           count, list, C, N, tiles, nblocks, margin2, key_mask);                                       \
-        hipLaunchKernelGGL((knn_exact_rows_kernel<K, I>), dim3(512), dim3(256), 0, s, xn, sq, (I *)idx, count, list, C,  \
-                           N);                                                                                          \
-    } while (0)
-#define KS_LAUNCH_K(I)                                  \
-    switch (k) {                                        \
-    case 1: KS_LAUNCH(1, I); break;                     \
-    case 2: KS_LAUNCH(2, I); break;                     \
-    case 3: KS_LAUNCH(3, I); break;                     \
-    default: KS_LAUNCH(4, I); break;                    \
-    }
-    if (idx_is_i32) { KS_LAUNCH_K(int32_t) } else { KS_LAUNCH_K(int64_t) }
-#undef KS_LAUNCH_K
-#undef KS_LAUNCH
+    KsArgs a;
+    a.x = x; a.f32 = dtype == GRAFP_F32; a.sb = stride_b; a.sc = stride_c; a.xh = xh; a.xl = xl; a.sq = sq; a.den = den;
+    a.count = count; a.flag = flag; a.extra = extra; a.light = light; a.idx = idx; a.B = B; a.C = C; a.N = N;
+    a.margin2 = 2.0f * ks_margin(C);
+    a.key_mask = ~((1u << ks_index_bits(N)) - 1u);
+    if (idx_is_i32) ks_launch_k<int32_t>(k, a, s);
+    else ks_launch_k<int64_t>(k, a, s);
     GRAFP_CHECK_LAUNCH("knn_topk_split_kernel");
     if (n_uncertified &&
         hipMemcpyAsync(n_uncertified, count, sizeof(int), hipMemcpyDeviceToDevice, s) != hipSuccess) {

@@ -304,9 +304,9 @@ def knn_graph(x, k, normalize=True, layout="bcn", index_dtype=torch.int64, prefi
     x, B, C, N, sb, sc = _act_view(x.detach(), layout)
     idx = torch.empty((B, N, k), dtype=index_dtype, device=x.device)
     if (prefilter is None and switches.knn_split and normalize and index_dtype in (torch.int32, torch.int64)
-            and lib.grafp_knn_split_supported(C, N, k)):
+            and lib.grafp_knn_split_preferred(C, N, k)):
         # split-bf16 Gram matrix + certified order, exact recomputation of the near-ties (knn_split.hip): the same
-        # indices bit for bit, 2.5-4x faster than the exact-f32 MFMA kernel below
+        # indices bit for bit, ~2x faster than the exact-f32 MFMA kernel below where the library prefers it (C <= 128)
         knn_graph_split(x, k, layout="raw", index_dtype=index_dtype, _view=(x, B, C, N, sb, sc), _out=idx)
         return idx
     if prefilter is None:

@@ -127,6 +127,7 @@ int grafp_knn_graph_pre(const void *x, int dtype, int64_t stride_b, int64_t stri
  * idx int64 or int32 (idx_is_i32); n_uncertified: NULL, or one device int that receives the number of queries that
  * took the exact path (diagnostics). */
 int grafp_knn_split_supported(int C, int N, int k);
+int grafp_knn_split_preferred(int C, int N, int k);   /* supported AND measured faster than grafp_knn_topk_f32 (C <= 128) */
 size_t grafp_knn_split_workspace(int B, int C, int N);
 int grafp_knn_graph_split(const void *x, int dtype, int64_t stride_b, int64_t stride_c, int B, int C, int N, int k,
                           void *idx, int idx_is_i32, void *ws, size_t ws_bytes, int32_t *n_uncertified,

