@@ -889,7 +889,7 @@ def test_augmentation_ragged_banks_equal_padded(dev):
     np.testing.assert_allclose(c.cpu().numpy(), on.mix_snr(x, flat, lens, idx, off, snr, starts), rtol=0, atol=2e-6 * np.abs(x).max())
 
 
-def test_bn_single_pass_never_depends_on_absent_row_mates(dev):
+def test_bn_single_pass_never_depends_on_absent_row_mates(dev, monkeypatch):
     """The rendezvous of bn_fwd1 / bn_bwd1 is bounded and falls back to recomputing the missing partial sums (it used
     to trap): (1) with a spin limit of 0 every workgroup fills in whatever is not yet published -- results must be the
     same BITS as the normal run; (2) the same while a second stream holds 15/16 of the chip's wave slots for tens of
