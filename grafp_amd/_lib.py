@@ -12,7 +12,7 @@ import torch  # noqa: F401  -- FIRST: the library must bind to the HIP runtime t
 #                               loaded the other way round the process holds two runtimes and launches find no device
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# GRAFP_HIP_LIB: another build of the same ABI (measurement builds of tools/gemm_ablate.sh)
+# GRAFP_HIP_LIB: another build of the same ABI (the measurement build: make -C grafp_amd/csrc measure)
 LIB_PATH = os.environ.get("GRAFP_HIP_LIB") or os.path.join(_HERE, "libgrafp_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "grafp_hip.h")
 

@@ -123,8 +123,9 @@ class GraphEncoder(nn.Module):
         g = int(views)
         if torch.is_autocast_enabled() and x.is_cuda:      # all 1x1 conv weights to the autocast dtype in one launch
             if self._lowp is None:
-                self._lowp = ops.lowp_weights([m for m in self.modules()
-                                               if isinstance(m, nn.Conv2d) and m.kernel_size == (1, 1)])
+                # (self.proj is not in the list: the readout runs in f32 on the pooled means)
+                self._lowp = ops.lowp_weights([m for m in self.modules() if isinstance(m, nn.Conv2d)
+                                               and m.kernel_size == (1, 1) and m is not self.proj])
             self._lowp.refresh(torch.get_autocast_dtype("cuda"))
         elif self._lowp is not None:
             self._lowp.clear()

@@ -70,12 +70,16 @@ class IVFPQIndex:
 
     # ---- training: coarse k-means, then one k-means per sub-space on the residuals (by_residual = True) ---------------
     def train(self, x):
+        # faiss subsamples its training set to max_points_per_centroid * max(nlist, 256) rows; the selection happens on
+        # the HOST side (array or memmap) so that only those rows ever reach the device
+        cap = self.max_ppc * max(self.nlist, 256)
+        n_rows = (x.numel() if torch.is_tensor(x) else int(np.prod(x.shape))) // self.d
+        if n_rows > cap:
+            gen = torch.Generator().manual_seed(self.seed + 1)
+            sel = torch.sort(torch.randperm(n_rows, generator=gen)[:cap]).values
+            x = x.reshape(-1, self.d)[sel.to(x.device)] if torch.is_tensor(x) else np.asarray(x).reshape(-1, self.d)[sel.numpy()]
         x = torch.as_tensor(np.ascontiguousarray(x) if isinstance(x, np.ndarray) else x).to(self.device, torch.float32)
         x = x.reshape(-1, self.d)
-        cap = self.max_ppc * max(self.nlist, 256)
-        if x.shape[0] > cap:                              # faiss subsamples its training set the same way
-            gen = torch.Generator().manual_seed(self.seed + 1)
-            x = x[torch.randperm(x.shape[0], generator=gen)[:cap].to(self.device)]
         self.centroids = kmeans(x, self.nlist, self.niter, self.seed).contiguous()
         res = x - self.centroids[self._assign_lists(x)]
         sub = res.reshape(-1, self.M, self.dsub).permute(1, 0, 2).contiguous()          # (M, n, dsub)

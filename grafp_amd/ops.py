@@ -622,11 +622,16 @@ class lowp_weights:
     _shortcut_first), [W^T | I] -- ONE launch of grafp_weights_prepare for every layer whose rows and columns per
     group are multiples of 32, one multi-tensor cast for the rest (the 8-channel stem).  `refresh()` before the layers
     run; conv._w_lowp, conv._w_t and conv._w_aug are picked up by encoder/_dense.conv_bn_act.
-    The buffers are overwritten by the next refresh(): fine as long as the weights do not change between a forward
-    pass and its backward pass."""
+    The buffers are shared between passes and overwritten when the weights change: refresh() notices a change by the
+    parameters' version counters, re-prepares only then (a fingerprinting loop pays no launch), and advances a generation
+    number; a backward pass whose forward pass saw an older generation (an optimizer step between the two) raises
+    instead of differentiating against the new weights."""
+
+    generation = 0                  # advanced whenever any lowp_weights instance re-prepares changed weights
 
     def __init__(self, convs):
         self.convs = list(convs)
+        self._versions = None
         self._dtype, self._dev = None, None
         self._fast, self._slow, self._slow_bufs = [], [], []
         self._table = self._tile_entry = None
@@ -671,12 +676,21 @@ class lowp_weights:
         if stale:
             self._build(dtype, dev)
             self._src_ptrs = [c.weight.data_ptr() for c in self.convs]
+        versions = tuple(c.weight._version for c in self.convs)
+        if not stale and versions == self._versions:
+            self._publish()                                   # (a clear() in between dropped the attributes)
+            return
+        self._versions = versions
+        lowp_weights.generation += 1
         with torch.no_grad():
             if self._table is not None:
                 check(lib.grafp_weights_prepare(_p(self._table), _p(self._tile_entry), int(self._tile_entry.numel()),
                                                 _stream()), "weights_prepare")
             if self._slow:
                 torch._foreach_copy_(self._slow_bufs, [c.weight for c in self._slow])
+        self._publish()
+
+    def _publish(self):
         for c, lo, wt, aug, Rg in self._fast:
             c._w_lowp = lo.view(c.weight.shape) if c.weight.dim() == 4 else lo
             c._w_t, c._w_aug = (None, wt) if aug else (wt, None)
@@ -855,6 +869,8 @@ class _ConvBnAct(torch.autograd.Function):
         x = x.detach()
         ctx.token, ctx.token_role = token, token_role        # 1: first layer of the block (consumes), 2: last (provides)
         ctx.w_t, ctx.w_aug = w_t, w_aug                      # prepared with the forward operand (lowp_weights), or None
+        # shared prepared buffers in use: remember which preparation this forward pass saw
+        ctx.lowp_gen = lowp_weights.generation if (w_lowp is not None or w_t is not None or w_aug is not None) else None
         K, M = x.shape
         R = w.shape[0]
         if w_lowp is not None and w_lowp.dtype == torch.bfloat16 and w_lowp.numel() == w.numel():
@@ -884,6 +900,10 @@ class _ConvBnAct(torch.autograd.Function):
     def backward(ctx, dz):
         x, wl, y, mean, invstd, g32, b32, pb = ctx.saved_tensors
         R, K, M, cg, views, act, slope, training, has_pb, has_res, wfull = ctx.cfg
+        if ctx.lowp_gen is not None and ctx.lowp_gen != lowp_weights.generation:
+            raise RuntimeError("conv_bn_act backward: the shared low-precision weight buffers were re-prepared from CHANGED "
+                               "weights after this forward pass (an optimizer step or weight load between forward and "
+                               "backward); run backward before changing the weights")
         dz = dz.detach().to(torch.bfloat16).contiguous()
         dy, dgamma, dbeta, dpb = _bn_bwd(y, dz, R, M, views, pb if has_pb else None, g32, b32, mean, invstd, act, slope,
                                          training)

@@ -1,0 +1,52 @@
+"""CPU test of the build-time register contract of wgrad_gr_kernel (tools/check_kernel_regs.py): the shipped source
+passes, and the checker does flag a compiler-generated use of the staging registers or a wrong allocation."""
+import importlib.util
+import os
+
+from _common import ROOT
+
+
+def _tool():
+    spec = importlib.util.spec_from_file_location("check_kernel_regs", os.path.join(ROOT, "tools", "check_kernel_regs.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_wgrad_staging_registers_are_left_alone_by_the_compiler():
+    assert _tool().main.__call__ is not None
+    import subprocess
+    import sys
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_kernel_regs.py")], stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT, text=True)
+    assert res.returncode == 0, res.stdout
+    assert "contract holds for 2 instantiations" in res.stdout
+
+
+_FAKE = """
+_ZN5grafp15wgrad_gr_kernelINS_5WgCfgILi2EEEEEvPKt: ; @fake
+\tv_mov_b32_e32 v3, v1
+\t;;#ASMSTART
+\tglobal_load_dwordx4 v[224:227], v[4:5], off
+\t;;#ASMEND
+{extra}
+\ts_endpgm
+  - .agpr_count:     {agpr}
+    .name:           _ZN5grafp15wgrad_gr_kernelINS_5WgCfgILi2EEEEEvPKt
+    .private_segment_fixed_size: 0
+    .vgpr_count:     {vgpr}
+    .vgpr_spill_count: 0
+    .wavefront_size: 64
+"""
+
+
+def test_checker_flags_violations():
+    tool = _tool()
+    assert tool.check(_FAKE.format(extra="", agpr=0, vgpr=256)) == (1, [])
+    _, errs = tool.check(_FAKE.format(extra="\tv_mov_b32_e32 v230, v1", agpr=0, vgpr=256))
+    assert len(errs) == 1 and "v224+" in errs[0]
+    _, errs = tool.check(_FAKE.format(extra="\tv_pk_add_f32 v[222:225], v[0:3], v[4:7]", agpr=0, vgpr=256))
+    assert len(errs) == 1
+    _, errs = tool.check(_FAKE.format(extra="", agpr=16, vgpr=224))
+    assert len(errs) == 2
+    assert tool.check("nothing here")[1]

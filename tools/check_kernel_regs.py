@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Build-time check of the register contract of wgrad_gr_kernel (grafp_amd/csrc/wgrad.hip).
+
+That kernel keeps in-flight G-operand loads in the PHYSICAL registers v224-v255, named inside inline asm, and relies on
+`amdgpu_num_vgpr(224)` keeping the compiler out of them.  A compiler or flag change that breaks any of the following
+would give silently wrong weight gradients, so `make check` (and __graft_entry__.build(), and the CPU test-suite)
+compile wgrad.hip to assembly and verify, for every instantiation:
+  * the kernel descriptor allocates 256 VGPRs (so v224-v255 exist), no AGPRs, no scratch, no spills;
+  * outside the `;;#ASMSTART ... ;;#ASMEND` blocks no instruction mentions v224 ... v255 (alone or inside a range).
+Usage: check_kernel_regs.py [--hipcc PATH]      (exit status 0 = contract holds)."""
+import argparse
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "grafp_amd", "csrc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+         "-fhip-fp32-correctly-rounded-divide-sqrt", "-I" + os.path.join(ROOT, "include"), "-Wno-inline-asm",
+         "--cuda-device-only", "-S"]
+
+
+def high_regs(line):
+    """True if an instruction line touches a VGPR >= 224 (v230, or a range like v[220:227])."""
+    for m in re.finditer(r"\bv(\d+)\b", line):
+        if int(m.group(1)) >= 224:
+            return True
+    for m in re.finditer(r"\bv\[(\d+):(\d+)\]", line):
+        if int(m.group(2)) >= 224:
+            return True
+    return False
+
+
+def check(asm):
+    errors, kernels = [], 0
+    for m in re.finditer(r"^(_ZN5grafp15wgrad_gr_kernel\w+):\s*;[^\n]*\n(.*?)^\s*s_endpgm", asm, flags=re.S | re.M):
+        name, body = m.group(1), m.group(2)
+        kernels += 1
+        in_asm = False
+        for ln in body.split("\n"):
+            s = ln.strip()
+            if s.startswith(";;#ASMSTART"):
+                in_asm = True
+            elif s.startswith(";;#ASMEND"):
+                in_asm = False
+            elif not in_asm and s and not s.startswith((";", ".")) and high_regs(s.split(";")[0]):
+                errors.append(f"{name}: compiler-generated instruction touches v224+: {s}")
+        meta = re.search(r"\.name:\s+" + re.escape(name) + r"\n(.*?)\.wavefront_size", asm, flags=re.S)
+        before = asm[:meta.start()] if meta else ""
+        blk = (before[before.rfind("- .agpr_count"):] if meta else "") + (meta.group(0) if meta else "")
+        def field(key):
+            f = re.search(r"\." + key + r":\s+(\d+)", blk)
+            return int(f.group(1)) if f else None
+        want = {"vgpr_count": 256, "agpr_count": 0, "vgpr_spill_count": 0, "private_segment_fixed_size": 0}
+        for key, val in want.items():
+            got = field(key)
+            if got != val:
+                errors.append(f"{name}: .{key} = {got}, expected {val}")
+    if kernels == 0:
+        errors.append("no wgrad_gr_kernel instantiation found in the assembly")
+    return kernels, errors
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--hipcc", default=os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"))
+    args = ap.parse_args()
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "wgrad.s")
+        res = subprocess.run([args.hipcc] + FLAGS + [os.path.join(CSRC, "wgrad.hip"), "-o", out],
+                             stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if res.returncode != 0:
+            print(res.stdout)
+            return 2
+        asm = open(out).read()
+    kernels, errors = check(asm)
+    for e in errors:
+        print("REGISTER CONTRACT VIOLATED:", e)
+    if not errors:
+        print(f"wgrad_gr_kernel register contract holds for {kernels} instantiations")
+    return 1 if errors else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
