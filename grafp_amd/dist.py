@@ -121,7 +121,8 @@ class GradSync:
         self._left, self._handles, self._fired = list(self._size), [], [False] * len(self.bounds)
         self._hooks = []
         self.paused = False            # Trainer.step_graph: backward is being captured, the buckets are reduced afterwards
-        if overlap and self.world > 1:
+        self.capturing = False         # ... and each bucket marks its completion with an external event (begin_capture)
+        if overlap and (self.world > 1 or force_flat):
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
@@ -167,7 +168,53 @@ class GradSync:
                                                  async_op=True))
         self._fired[b] = True
 
+    def begin_capture(self):
+        """Backward is about to be recorded into a HIP graph (Trainer.step_graph).  The hooks then do not launch
+        collectives; when a bucket's last gradient arrives they record the bucket's pack (one multi-tensor copy into the
+        flat buffer) and an EXTERNAL event (hipEventRecordExternal: an event-record node of the graph).  On replay a
+        communication stream waits for event b and all-reduces bucket b while the rest of the backward graph is still
+        running -- overlap without capturing RCCL."""
+        self._cap_events = [torch.cuda.Event(external=True) for _ in self.bounds]
+        self._cap_left, self._cap_done = list(self._size), [False] * len(self.bounds)
+        self.capturing = True
+
+    def end_capture(self):
+        """Still inside the capture, after backward: buckets whose parameters did not all receive a gradient are packed
+        and marked now.  Returns the per-bucket events (in bucket order = completion order of a backward pass)."""
+        for b in range(len(self.bounds)):
+            if not self._cap_done[b]:
+                self._pack(b)
+                self._cap_events[b].record()
+                self._cap_done[b] = True
+        self.capturing = False
+        return self._cap_events
+
+    def reduce_buckets_after(self, events, comm_stream):
+        """The replay side of begin_capture(): bucket b's all-reduce is enqueued on `comm_stream` behind event b; the
+        CURRENT stream then waits for all of them (RCCL backends; host-staged ones use reduce_all())."""
+        if self.world > 1:
+            hs = []
+            for (lo, hi), ev in zip(self.bounds, events):
+                comm_stream.wait_event(ev)
+                with torch.cuda.stream(comm_stream):
+                    hs.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            for h in hs:
+                h.wait()
+        else:
+            for ev in events:
+                torch.cuda.current_stream().wait_event(ev)
+        for p in self.params:
+            p.grad = self._view[id(p)]
+
     def _on_grad(self, p):
+        if self.capturing:
+            b = self._bucket_of[id(p)]
+            self._cap_left[b] -= 1
+            if self._cap_left[b] == 0 and not self._cap_done[b]:
+                self._pack(b)
+                self._cap_events[b].record()
+                self._cap_done[b] = True
+            return
         if self.paused:
             return
         b = self._bucket_of[id(p)]

@@ -23,10 +23,14 @@ def build_model(cfg, k=3, device=None):
 
 class Trainer:
     def __init__(self, cfg, model, device, amp_dtype=None, group=None, lr=None, n_buckets=4, ir_dir=None,
-                 noise_dir=None, aug_seed=None):
+                 noise_dir=None, aug_seed=None, data_parallel_graphs=None):
         self.cfg, self.model, self.device, self.group = cfg, model, device, group
         self.amp_dtype = amp_dtype
         self.world = gdist.world_size(group)
+        # step_graph's data-parallel form (three graphs, eager collectives): by default whenever there is more than one
+        # rank; True forces it for a one-rank process group too (the tests run RCCL that way on a one-GPU box)
+        self._dp_graphs = self.world > 1 if data_parallel_graphs is None else bool(data_parallel_graphs)
+        self._comm = None
         # ir_dir / noise_dir: recordings for the batched device-side augmentation of the second view (train.py:150-151)
         self.augment = GPUTransformNeuralfp(dict(cfg, aug_seed=aug_seed), ir_dir, noise_dir, train=True).to(device)
         # train.py:174 (same Adam, defaults); on the GPU the update of all 271 parameter tensors is one fused launch
@@ -42,7 +46,8 @@ class Trainer:
         self.opt = torch.optim.Adam(model.parameters(), lr=lr0, fused=on_gpu, capturable=on_gpu)
         self._graph = None                     # (hipGraph, static x_i, static x_j, static loss) once captured
         self.sched = torch.optim.lr_scheduler.CosineAnnealingLR(self.opt, T_max=cfg["T_max"], eta_min=cfg["min_lr"])
-        self.sync = gdist.GradSync(model.parameters(), group=group, n_buckets=n_buckets)
+        self.sync = gdist.GradSync(model.parameters(), group=group, n_buckets=n_buckets,
+                                   force_flat=self._dp_graphs and self.world == 1)
 
     def _autocast(self):
         if self.amp_dtype is None:
@@ -91,8 +96,10 @@ class Trainer:
           * data parallel: THREE graphs with the two collectives between them, eager, exactly where step() has them --
             [augment + forward] -> all-gather of (z_i, z_j) -> [global-negative loss + backward + pack of the gradient
             buckets] -> bucket all-reduces -> [Adam].  The collectives are not captured (RCCL kernels inside a graph
-            are untested on this stack), so the all-reduce no longer overlaps backward; at 128 pairs per GPU the launch
-            gaps it removes are worth more than that overlap (~0.9 ms of xGMI time)."""
+            are untested on this stack); the backward graph carries one EXTERNAL event per gradient bucket
+            (GradSync.begin_capture), so on an RCCL backend bucket b's all-reduce starts on a communication stream as
+            soon as the graph has packed it, under the rest of backward -- the overlap of the eager step, with the ~700
+            launches of a step still folded into three graph launches."""
         if self._graph is None:
             if getattr(self.augment, "seed", None) is not None:
                 raise RuntimeError("step_graph: a private augmentation generator (aug_seed) is eager-only -- its draws "
@@ -109,7 +116,7 @@ class Trainer:
                     for _ in range(3):
                         self.step(sx_i, sx_j)
                 torch.cuda.current_stream().wait_stream(side)
-                if self.world == 1:
+                if not self._dp_graphs:
                     graph = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(graph):
                         loss = self.step(sx_i, sx_j)
@@ -134,7 +141,7 @@ class Trainer:
         R, rank = self.world, gdist.rank_of(self.group)
         self.model.train()
         self.sync.zero()
-        self.sync.paused = True                      # no collective from the autograd hooks while backward is recorded
+        self.sync.paused = True                      # no collective from the autograd hooks while the graphs are recorded
         try:
             g_fwd = torch.cuda.CUDAGraph()
             # thread_local: the process group's watchdog thread may query events while this thread records
@@ -152,8 +159,9 @@ class Trainer:
                 zi_all = both[0].reshape(-1, mine.shape[2]).contiguous()
                 zj_all = both[1].reshape(-1, mine.shape[2]).contiguous()
                 loss = ops.ntxent(z_i, z_j, self.cfg["tau"], zi_all, zj_all, rank * z_i.shape[0])
+                self.sync.begin_capture()             # hooks: pack bucket b + external event b when it completes
                 loss.backward()
-                self.sync.pack_all()
+                events = self.sync.end_capture()
                 loss = loss.detach()
             self.sync.reduce_all()
             g_opt = torch.cuda.CUDAGraph()
@@ -161,7 +169,8 @@ class Trainer:
                 self.opt.step()
         finally:
             self.sync.paused = False
-        return ("dp", (g_fwd, g_bwd, g_opt), sx_i, sx_j, loss, mine, gathered)
+            self.sync.capturing = False
+        return ("dp", (g_fwd, g_bwd, g_opt), sx_i, sx_j, loss, mine, gathered, events)
 
     def _replay(self):
         if self._graph[0] == "single":
@@ -181,7 +190,11 @@ class Trainer:
         g_bwd.replay()
         if host_staged:
             torch.cuda.current_stream().synchronize()
-        self.sync.reduce_all()
+            self.sync.reduce_all()
+        else:
+            if self._comm is None:
+                self._comm = torch.cuda.Stream()
+            self.sync.reduce_buckets_after(self._graph[7], self._comm)
         g_opt.replay()
         return loss.clone()
 

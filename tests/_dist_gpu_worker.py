@@ -13,15 +13,23 @@ from grafp_amd.train import Trainer, build_model, synthetic_batch      # noqa: E
 from grafp_amd.util import load_config                                 # noqa: E402
 
 
-def graph_mode(out, B):
+def graph_mode(out, B, rccl_one_rank=False):
     """Trainer.step_graph under data parallelism (three graphs, eager collectives between) against Trainer.step from
-    the same weights and optimizer state, on this rank's shard: losses and parameter updates."""
-    rank, world, device = gdist.init_from_env(backend="gloo", local_device=0)
+    the same weights and optimizer state, on this rank's shard: losses and parameter updates.
+    rccl_one_rank: a ONE-rank process group on the `nccl` (= RCCL) backend with the data-parallel graph form forced --
+    the only way to run RCCL's kernels, the external bucket events and the communication stream on a one-GPU box."""
+    if rccl_one_rank:
+        rank, world, device = 0, 1, torch.device("cuda", 0)
+        torch.cuda.set_device(0)
+        torch.distributed.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+    else:
+        rank, world, device = gdist.init_from_env(backend="gloo", local_device=0)
     cfg = load_config()
     cfg["bsz_train"] = B
     torch.manual_seed(1234)
     model = build_model(cfg, device=device)
-    tr = Trainer(cfg, model, device, amp_dtype=torch.bfloat16)
+    tr = Trainer(cfg, model, device, amp_dtype=torch.bfloat16, data_parallel_graphs=True if rccl_one_rank else None)
+    assert tr._dp_graphs
     per = B // world
     sl = slice(rank * per, (rank + 1) * per)
     x_i, x_j = synthetic_batch(B, 7, device)
@@ -61,8 +69,8 @@ def graph_mode(out, B):
 
 def main():
     out, B = sys.argv[1], int(sys.argv[2])
-    if len(sys.argv) > 3 and sys.argv[3] == "graph":
-        return graph_mode(out, B)
+    if len(sys.argv) > 3 and sys.argv[3] in ("graph", "graph_rccl1"):
+        return graph_mode(out, B, rccl_one_rank=sys.argv[3] == "graph_rccl1")
     rank, world, device = gdist.init_from_env(backend="gloo", local_device=0)
     cfg = load_config()
     cfg["bsz_train"] = B

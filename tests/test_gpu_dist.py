@@ -155,6 +155,54 @@ def test_step_graph_data_parallel(tmp_path):
         assert a["p_sum"] == b["p_sum"]                 # replicas stay in step (same reduced gradients, same update)
 
 
+def test_step_graph_data_parallel_over_rccl_one_rank(tmp_path):
+    """The same comparison on the RCCL backend (a one-rank process group: the most a one-GPU box can do): the all-gather
+    and the four bucket all-reduces are RCCL launches, and each all-reduce is enqueued on the communication stream behind
+    the EXTERNAL event its bucket records inside the replayed backward graph (GradSync.begin_capture)."""
+    out = str(tmp_path / "g1")
+    _launch(1, out, 16, extra=("graph_rccl1",))
+    for step in torch.load(f"{out}.0.pt", weights_only=False):
+        assert abs(step["loss_g"] - step["loss_e"]) <= 2e-3 * max(1.0, abs(step["loss_e"])), step
+        assert step["d_e"] > 0 and step["d_diff"] < 0.05 * step["d_e"], step
+
+
+def test_external_event_of_a_replayed_graph_releases_a_side_stream_early():
+    """What the overlap above rests on: an event recorded with external=True inside a captured graph is an event-record
+    NODE -- a stream that waits for it after the replay was enqueued runs as soon as that node has executed, not when
+    the whole graph has."""
+    d = torch.device("cuda:0")
+    a = torch.zeros(1 << 22, device=d)
+    b = torch.zeros(1 << 22, device=d)
+    ev = torch.cuda.Event(external=True)
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    warm = torch.cuda.Stream()
+    warm.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(warm):
+        a.add_(1.0)
+        b.add_(1.0)
+    torch.cuda.current_stream().wait_stream(warm)
+    a.zero_()
+    b.zero_()
+    n_tail = 400
+    with torch.cuda.graph(g):
+        a.add_(1.0)
+        ev.record()
+        for _ in range(n_tail):
+            b.add_(1.0)
+    a.zero_()
+    b.zero_()
+    torch.cuda.synchronize()
+    g.replay()
+    side.wait_event(ev)
+    with torch.cuda.stream(side):
+        seen_a, seen_b = a[:1].clone(), b[:1].clone()
+    torch.cuda.synchronize()
+    assert float(seen_a) == 1.0                     # after the node in front of the event
+    assert float(seen_b) < n_tail                   # ... and before the end of the graph
+    assert float(b[0]) == n_tail
+
+
 def test_bench_two_ranks_one_gpu(tmp_path):
     """bench.py's N > 1 path end to end (barriers, MAX over ranks, rank-0 JSON line, sharded retrieval leg) with both
     ranks on cuda:0."""
