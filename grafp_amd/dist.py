@@ -78,6 +78,29 @@ def ntxent_global(z_i, z_j, tau, group=None, loss_fn=None):
     return loss_fn(z_i, z_j, tau, zi_all, zj_all, rank_of(group) * z_i.shape[0])
 
 
+class ProgressFlag:
+    """A device counter a replayed HIP graph bumps when it passes a certain point (grafp_flag_bump, recorded into the
+    graph) and another stream waits for (grafp_flag_wait, enqueued after the replay): the stand-in for an external event,
+    which the HIP runtime of this image refuses under capture (include/grafp_hip.h)."""
+
+    def __init__(self, device):
+        from ._lib import check, lib
+        self._lib, self._check = lib, check
+        self.value = torch.zeros((), dtype=torch.int32, device=device)
+        self.bumps = 0                                   # how often the bump has EXECUTED (replays so far)
+
+    def record(self):
+        """Inside a capture: the bump becomes a node of the graph (it does not run now)."""
+        import ctypes
+        self._check(self._lib.grafp_flag_bump(ctypes.c_void_p(self.value.data_ptr()),
+                                              ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "flag_bump")
+
+    def make_wait(self, stream, count):
+        import ctypes
+        self._check(self._lib.grafp_flag_wait(ctypes.c_void_p(self.value.data_ptr()), int(count),
+                                              ctypes.c_void_p(stream.cuda_stream)), "flag_wait")
+
+
 class GradSync:
     """Flat-buffer gradient all-reduce (SUM) with bucketed launch from autograd hooks.
 
@@ -171,10 +194,9 @@ class GradSync:
     def begin_capture(self):
         """Backward is about to be recorded into a HIP graph (Trainer.step_graph).  The hooks then do not launch
         collectives; when a bucket's last gradient arrives they record the bucket's pack (one multi-tensor copy into the
-        flat buffer) and an EXTERNAL event (hipEventRecordExternal: an event-record node of the graph).  On replay a
-        communication stream waits for event b and all-reduces bucket b while the rest of the backward graph is still
-        running -- overlap without capturing RCCL."""
-        self._cap_events = [torch.cuda.Event(external=True) for _ in self.bounds]
+        flat buffer) and the bump of the bucket's ProgressFlag.  On replay a communication stream waits for flag b and
+        all-reduces bucket b while the rest of the backward graph is still running -- overlap without capturing RCCL."""
+        self._cap_events = [ProgressFlag(self.flat.device) for _ in self.bounds]
         self._cap_left, self._cap_done = list(self._size), [False] * len(self.bounds)
         self.capturing = True
 
@@ -190,19 +212,17 @@ class GradSync:
         return self._cap_events
 
     def reduce_buckets_after(self, events, comm_stream):
-        """The replay side of begin_capture(): bucket b's all-reduce is enqueued on `comm_stream` behind event b; the
-        CURRENT stream then waits for all of them (RCCL backends; host-staged ones use reduce_all())."""
-        if self.world > 1:
-            hs = []
-            for (lo, hi), ev in zip(self.bounds, events):
-                comm_stream.wait_event(ev)
-                with torch.cuda.stream(comm_stream):
-                    hs.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-            for h in hs:
-                h.wait()
-        else:
-            for ev in events:
-                torch.cuda.current_stream().wait_event(ev)
+        """The replay side of begin_capture(), called right AFTER the backward graph's replay was enqueued: bucket b's
+        all-reduce goes to `comm_stream` behind the wait for flag b; the CURRENT stream then waits for all of them (RCCL
+        backends; host-staged ones use reduce_all())."""
+        hs = []
+        for (lo, hi), ev in zip(self.bounds, events):
+            ev.bumps += 1
+            ev.make_wait(comm_stream, ev.bumps)
+            with torch.cuda.stream(comm_stream):
+                hs.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        for h in hs:
+            h.wait()
         for p in self.params:
             p.grad = self._view[id(p)]
 

@@ -96,7 +96,7 @@ class Trainer:
           * data parallel: THREE graphs with the two collectives between them, eager, exactly where step() has them --
             [augment + forward] -> all-gather of (z_i, z_j) -> [global-negative loss + backward + pack of the gradient
             buckets] -> bucket all-reduces -> [Adam].  The collectives are not captured (RCCL kernels inside a graph
-            are untested on this stack); the backward graph carries one EXTERNAL event per gradient bucket
+            are untested on this stack); the backward graph bumps one progress flag per gradient bucket
             (GradSync.begin_capture), so on an RCCL backend bucket b's all-reduce starts on a communication stream as
             soon as the graph has packed it, under the rest of backward -- the overlap of the eager step, with the ~700
             launches of a step still folded into three graph launches."""
@@ -159,7 +159,7 @@ class Trainer:
                 zi_all = both[0].reshape(-1, mine.shape[2]).contiguous()
                 zj_all = both[1].reshape(-1, mine.shape[2]).contiguous()
                 loss = ops.ntxent(z_i, z_j, self.cfg["tau"], zi_all, zj_all, rank * z_i.shape[0])
-                self.sync.begin_capture()             # hooks: pack bucket b + external event b when it completes
+                self.sync.begin_capture()             # hooks: pack bucket b + bump flag b when it completes
                 loss.backward()
                 events = self.sync.end_capture()
                 loss = loss.detach()
