@@ -65,6 +65,9 @@ typedef GemmCfg<2, 4, 4> GemmL;
 typedef GemmCfg<1, 8, 1, 16> GemmN32;
 typedef GemmCfg<1, 8, 2, 16> GemmN64;
 typedef GemmCfg<1, 8, 4, 32> GemmN128;
+// (Measured and dropped, round 3: M = 2 x 2 waves, RT 4 -> 256 x 128 with THREE 24 KB stages + 2 KB staging slabs = 80 KB,
+//  i.e. two workgroups per CU that run out of phase by themselves, one's MFMA chain under the other's epilogue and store
+//  drain: 10-15 % SLOWER than L on every stage 2-3 shape, 37.6 vs 34.0 ms over a step's products at 2048 clip-views.)
 enum { GM_CFG_S = 0, GM_CFG_L = 1, GM_CFG_N32 = 2, GM_CFG_N64 = 3, GM_CFG_N128 = 4 };
 
 struct GemmPlan {
@@ -83,17 +86,21 @@ static GemmPlan gemm_plan(int Rg, int K, int groups, int64_t M, int views) {
     // longer fit the Infinity Cache and the small tile's second pass over X goes to HBM).  (Round 2 also sent every
     // shape with >= 2^20 columns per view to the large tile; against the S tile that loses 3-10 % on seven of the ten
     // stage-0 shapes at 2048 clip-views -- 4 x the MFMA work on rows that do not exist -- and is gone.)
-    const bool large = (Rg >= 512 || (Rg >= 256 && (K >= 512 || 4 * K <= Rg || Mg >= (1 << 18)))) && Mg % GemmL::TN == 0;
+    // (with the S tile at two workgroups per CU by launch bounds -- 140-156 VGPRs instead of 200-228, 5-10 % faster -- a
+    //  256-row shallow product, K < 128, moves to the large tile only from 2^19 columns per view)
+    const bool large = (Rg >= 512 || (Rg >= 256 && (K >= 512 || Mg >= (1 << 19) || (K >= 128 && Mg >= (1 << 18))))) &&
+                       Mg % GemmL::TN == 0;
     p.cfg = large ? GM_CFG_L : GM_CFG_S;
     // <= 128 rows per group: the 512-column tiles where they measured faster than both --
-    //   N128 (65 ... 128 rows, ungrouped): from 128 operand rows and 2^17 columns per view (-15 ... -25 % on the stage-1
-    //        shapes at every size; R = 128, K = 64 and the short rows of 128 pairs per GPU stay on the S tile);
+    //   N128 (65 ... 128 rows, ungrouped): from 512 operand rows at 2^17 columns per view, from 128 operand rows at 2^19
+    //        (-15 ... -25 % on the stage-1 shapes at 2048 clip-views, -10 % on the deep ones at 512; the shallow ones at
+    //        512 clip-views and R = 128, K = 64 stay on the S tile);
     //   N64 / N32 (<= 64 / <= 32 rows): from 2^16 columns per view (-10 ... -27 % at 256 and 512 clip-views); beyond
     //        2^20 columns per view only the ungrouped shapes with K = 64 or K >= 256 (the others tie or lose 5 %).
     const int64_t n_from = GRAFP_TUNE_INT("GRAFP_GEMM_N_FROM", 1 << 16);
     if (Rg <= 128 && Mg % GemmN64::TN == 0 && Mg >= n_from) {
         if (Rg > 64) {
-            if (groups == 1 && K >= 128 && Mg >= 2 * n_from) p.cfg = GM_CFG_N128;
+            if (groups == 1 && ((K >= 512 && Mg >= 2 * n_from) || (K >= 128 && Mg >= 8 * n_from))) p.cfg = GM_CFG_N128;
         } else if (Mg < (1 << 20) || (groups == 1 && (K <= 64 || K >= 256))) {
             p.cfg = Rg <= 32 ? GM_CFG_N32 : GM_CFG_N64;
         }
@@ -149,7 +156,7 @@ __device__ __forceinline__ void gm_chan(float &n, float &mean, float &m2, float 
 // against an identity block of the weight, dX = [W^T | I] [dY; dZ] -- the sum is rounded once and the separate
 // gradient-accumulation add (two reads, one write of C x M) is gone.
 template <typename CFG, int NS, bool PRO, bool STATS, bool CAT = false>
-__global__ __launch_bounds__(CFG::THREADS) void conv1x1_gemm_kernel(
+__global__ __launch_bounds__(CFG::THREADS, CFG::NW == 4 ? 2 : 1) void conv1x1_gemm_kernel(
     const unsigned short *__restrict__ A, int lda, const unsigned short *__restrict__ X, unsigned short *__restrict__ Y,
     int64_t M, int Rg, int K, int row_tiles, int ranges_view, int tiles_range, int col_tiles_view, int views,
     const float2 *__restrict__ pro_tab, int pro_act, float pro_slope, float *__restrict__ part, int P, int nblocks,

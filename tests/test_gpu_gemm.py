@@ -29,7 +29,7 @@ SHAPES = [(64, 64, 1, 8192, 2), (256, 64, 1, 8192, 2), (64, 256, 1, 8192, 2), (1
           (1024, 1024, 4, 2048, 2), (96, 32, 1, 1280, 1), (64, 64, 1, 128 * 2 * 37, 2),
           # the 512-column tiles of round 3 (<= 128 rows per group, >= 2^16 columns per view): N64, N32 (grouped: one
           # chunk per tile), N128, N128 with ragged rows, N64 with a ragged last column range, one-view N32
-          (64, 256, 1, 131072, 2), (128, 128, 4, 131072, 2), (128, 256, 1, 262144, 2), (96, 160, 1, 131072, 1),
+          (64, 256, 1, 131072, 2), (128, 128, 4, 131072, 2), (128, 512, 1, 262144, 2), (96, 160, 1, 524288, 1),
           (64, 64, 1, 2 * 512 * 131, 2), (32, 96, 1, 65536, 1)]
 
 
@@ -101,7 +101,7 @@ def test_gemm_statistics_with_large_mean():
 
 
 @pytest.mark.parametrize("R,K,groups,M,views,act", [(64, 128, 1, 4096, 2, 1), (128, 256, 1, 2048, 2, 1),
-                                                    (64, 128, 1, 131072, 2, 1), (128, 128, 1, 131072, 1, 2),
+                                                    (64, 128, 1, 131072, 2, 1), (128, 512, 1, 131072, 1, 2),
                                                     (512, 2048, 1, 1024, 2, 1), (64, 64, 1, 2048, 1, 2),
                                                     (128, 128, 4, 2048, 2, 0)])
 def test_gemm_normalise_on_load(R, K, groups, M, views, act):
@@ -185,7 +185,7 @@ def test_gemm_cat_equals_product_plus_shortcut():
     """conv1x1_gemm_cat(W | I, dY, dZ) = W dY + dZ with ONE rounding (the data gradient of a residual block's first
     layer with the shortcut's gradient as extra operand rows), for an S-tile and an L-tile shape."""
     from grafp_amd import ops
-    for R, K1, M in ((64, 64, 4096), (256, 1024, 2048), (128, 128, 1024), (64, 256, 65536), (128, 128, 131072 + 512)):
+    for R, K1, M in ((64, 64, 4096), (256, 1024, 2048), (128, 128, 1024), (64, 256, 65536), (128, 384, 131072 + 512)):
         wt = _rand((R, K1), 41, 0.1)
         dy, dz = _rand((K1, M), 42), _rand((R, M), 43)
         w_aug = torch.cat((wt, torch.eye(R, dtype=torch.bfloat16, device=DEV)), dim=1)
