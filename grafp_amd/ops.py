@@ -622,16 +622,17 @@ class lowp_weights:
     _shortcut_first), [W^T | I] -- ONE launch of grafp_weights_prepare for every layer whose rows and columns per
     group are multiples of 32, one multi-tensor cast for the rest (the 8-channel stem).  `refresh()` before the layers
     run; conv._w_lowp, conv._w_t and conv._w_aug are picked up by encoder/_dense.conv_bn_act.
-    The buffers are shared between passes and overwritten when the weights change: refresh() notices a change by the
-    parameters' version counters, re-prepares only then (a fingerprinting loop pays no launch), and advances a generation
-    number; a backward pass whose forward pass saw an older generation (an optimizer step between the two) raises
-    instead of differentiating against the new weights."""
+    The buffers are shared between passes and rewritten by EVERY refresh() (one launch; whether the weights changed
+    cannot be seen from the host: fused optimizers and replayed graphs update parameters without touching their version
+    counters -- a skip-when-unchanged variant trained on stale copies and was caught by the hit-rate test).  Each refresh
+    advances a generation number; a backward pass whose forward pass saw an older generation (another encoder forward,
+    possibly after an optimizer step, between the two) raises instead of differentiating against whatever the buffers
+    hold by then."""
 
-    generation = 0                  # advanced whenever any lowp_weights instance re-prepares changed weights
+    generation = 0                  # advanced by every refresh() of any instance
 
     def __init__(self, convs):
         self.convs = list(convs)
-        self._versions = None
         self._dtype, self._dev = None, None
         self._fast, self._slow, self._slow_bufs = [], [], []
         self._table = self._tile_entry = None
@@ -676,11 +677,6 @@ class lowp_weights:
         if stale:
             self._build(dtype, dev)
             self._src_ptrs = [c.weight.data_ptr() for c in self.convs]
-        versions = tuple(c.weight._version for c in self.convs)
-        if not stale and versions == self._versions:
-            self._publish()                                   # (a clear() in between dropped the attributes)
-            return
-        self._versions = versions
         lowp_weights.generation += 1
         with torch.no_grad():
             if self._table is not None:
@@ -901,9 +897,9 @@ class _ConvBnAct(torch.autograd.Function):
         x, wl, y, mean, invstd, g32, b32, pb = ctx.saved_tensors
         R, K, M, cg, views, act, slope, training, has_pb, has_res, wfull = ctx.cfg
         if ctx.lowp_gen is not None and ctx.lowp_gen != lowp_weights.generation:
-            raise RuntimeError("conv_bn_act backward: the shared low-precision weight buffers were re-prepared from CHANGED "
-                               "weights after this forward pass (an optimizer step or weight load between forward and "
-                               "backward); run backward before changing the weights")
+            raise RuntimeError("conv_bn_act backward: the shared low-precision weight buffers were re-prepared (another encoder "
+                               "forward under autocast, possibly after an optimizer step) between this layer's forward "
+                               "and backward pass; run backward before the next forward")
         dz = dz.detach().to(torch.bfloat16).contiguous()
         dy, dgamma, dbeta, dpb = _bn_bwd(y, dz, R, M, views, pb if has_pb else None, g32, b32, mean, invstd, act, slope,
                                          training)

@@ -111,7 +111,7 @@ def test_headline_step_kernels_vs_references(dev):
             m64 = torch.stack([yv[:, v].double().mean(dim=1) for v in range(views)], dim=1)
             v64 = torch.stack([yv[:, v].double().var(dim=1, unbiased=False) for v in range(views)], dim=1)
             pb = 0.0 if pre_bias is None else pre_bias.double()[:, None]
-            np.testing.assert_allclose(mean.double().cpu().numpy(), (m64 + pb).cpu().numpy(), rtol=2e-5, atol=2e-5)
+            np.testing.assert_allclose(mean.double().cpu().numpy(), (m64 + pb).cpu().numpy(), rtol=1e-4, atol=1e-4)       # f32 partial sums over 2^20 columns
             np.testing.assert_allclose(invstd.double().cpu().numpy(), (1.0 / torch.sqrt(v64 + eps)).cpu().numpy(), rtol=2e-4)   # f32 Chan combination over 2^20 columns
             cols = _slabs(M, views, 7 * len(ck.seen["affine"])).to(y.device)
             t = tab.reshape(C, views, 2)

@@ -403,6 +403,24 @@ def test_step_graph_follows_the_scheduler_and_restores_on_failure(dev, monkeypat
     assert 0.0 < moved <= 10.0 * float(lr)                   # Adam: |update| ~ lr per element
 
 
+def test_backward_after_another_forward_refuses_the_shared_weight_copies(dev):
+    """The bf16 / transposed weight copies of ops.lowp_weights are shared between passes and rewritten by every encoder
+    forward under autocast: a backward pass whose forward saw an older preparation raises instead of
+    differentiating against whatever the buffers hold by then; the normal order works."""
+    cfg, model = _filled_model(dev)
+    model.train()
+    xi, xj = simclr_inputs()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        _, _, z_i, _ = model(xi.to(dev), xj.to(dev))
+        model(xi.to(dev), xj.to(dev))                      # e.g. an interleaved validation / fingerprint pass
+    with pytest.raises(RuntimeError, match="re-prepared"):
+        z_i.sum().backward()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        _, _, z_i, _ = model(xi.to(dev), xj.to(dev))
+    z_i.sum().backward()
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+
+
 def test_trainer_with_device_augmentation_eager_and_graph(dev):
     """The training step with the second view augmented on the device (impulse responses + background noise for
     every clip): runs eagerly and replayed from one HIP graph (the per-clip draws use the device generator, which
