@@ -160,7 +160,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::NW == 4 ? 2 : 1) void conv1x1_ge
     const unsigned short *__restrict__ A, int lda, const unsigned short *__restrict__ X, unsigned short *__restrict__ Y,
     int64_t M, int Rg, int K, int row_tiles, int ranges_view, int tiles_range, int col_tiles_view, int views,
     const float2 *__restrict__ pro_tab, int pro_act, float pro_slope, float *__restrict__ part, int P, int nblocks,
-    const unsigned short *__restrict__ X2 = nullptr, int K1 = 0, int w_cm = 0) {
+    const unsigned short *__restrict__ X2 = nullptr, int K1 = 0) {
     constexpr int D = NS - 1;                               // chunks in flight
     constexpr int RT = CFG::RT, TN = CFG::TN, ROWB = CFG::ROWB, PER = CFG::PER, OR = CFG::OR;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -208,9 +208,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::NW == 4 ? 2 : 1) void conv1x1_ge
             int row = r0 + 16 * q + (lane >> 2);
             if (row > Rg - 1) row = Rg - 1;                  // rows beyond R: duplicates, never stored
             const int slot = (lane & 3) ^ ((lane >> 4) & 3);
-            // w_cm: W stored chunk-major, [K / 32][R][32] -- a chunk's W tile is ONE contiguous block (full 128-byte lines
-            // per DMA instruction instead of 64-byte row pieces at a stride of K)
-            src[j] = w_cm ? A + (size_t)row * GM_KC + slot * 8 : A + (size_t)row * lda + slot * 8;
+            src[j] = A + (size_t)row * lda + slot * 8;
         } else {
             const int row = CFG::RPI * (q - CFG::NA) + lane / CFG::SLOTS;
             const int sl = lane % CFG::SLOTS;
@@ -227,7 +225,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::NW == 4 ? 2 : 1) void conv1x1_ge
         for (int j = 0; j < PER; ++j) {
             if (wave + j * CFG::NW < CFG::NI) {              // scalar: false only for the last piece of some waves
                 const unsigned short *g;
-                if (is_w[j]) g = w_cm ? src[j] + (size_t)is_ch * Rg * GM_KC : src[j] + is_ch * GM_KC;
+                if (is_w[j]) g = src[j] + is_ch * GM_KC;
                 else if (CAT && is_ch >= nch1) g = src2[j] + (size_t)(is_ch - nch1) * GM_KC * M;
                 else g = src[j] + (size_t)is_ch * GM_KC * M;
                 gm_dma16(g, st + j * (CFG::NW * 1024));
@@ -303,6 +301,10 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::NW == 4 ? 2 : 1) void conv1x1_ge
         }
 
     unsigned char *const my_out = s_out + wave * CFG::OUT_BYTES;
+    // (Measured and dropped, round 3: the upper four waves of an eight-wave tile issuing their DMA pieces AFTER their
+    //  MFMAs, so that on every SIMD one wave's issue phase runs under the other's products: 33.65 vs 33.39 ms over a step's
+    //  products at 2048 clip-views, the deepest shape 15 % slower.  Likewise W stored chunk-major -- full 128-byte lines
+    //  per DMA piece instead of 64-byte row pieces: -2.7 %, not worth a second weight layout.)
     int ch = 0, tile = 0;
     for (int t = 0; t < T; ++t) {
         {   // chunk t landed (this wave's part), then everybody's; the stage of chunk t-1 is free after the barrier
@@ -719,8 +721,7 @@ static void gemm_launch(const GemmPlan &p, const GemmArgs &a, hipStream_t s) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((conv1x1_gemm_kernel<CFG, NS, PRO, STATS, CAT>), dim3(p.nblocks, 1, a.groups), dim3(CFG::THREADS),
                        lds, s, a.w, a.lda, a.x, a.y, a.M, a.Rg, a.Kg, p.row_tiles, p.ranges_view, p.tiles_range,
-                       p.col_tiles_view, a.views, a.pro_tab, a.pro_act, a.pro_slope, a.part, p.P, p.nblocks, a.x2, a.K1,
-                       GRAFP_TUNE_INT("GRAFP_GEMM_WCM", 0));
+                       p.col_tiles_view, a.views, a.pro_tab, a.pro_act, a.pro_slope, a.part, p.P, p.nblocks, a.x2, a.K1);
 }
 // plain / statistics / concatenated-operand forms of one tile configuration
 template <typename CFG, int NS> static void gemm_launch_cfg(const GemmPlan &p, const GemmArgs &a, hipStream_t s) {

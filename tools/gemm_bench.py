@@ -110,8 +110,7 @@ def main():
                     cols.append(f"{'':>15s}")
                     totals[c] += (t_auto or 0.0) * depth[stage]       # not applicable: the shipping plan's time
                     continue
-                os.environ["GRAFP_GEMM_WCM"] = "1" if c == "wcm" else "0"   # timing only: W addressed as if stored chunk-major
-                force(None if c in ("auto", "wcm") else CFG_IDS[ncfg if c == "N" else c])
+                force(None if c == "auto" else CFG_IDS[ncfg if c == "N" else c])
                 if cat:
                     t = timeit(lambda: ops.conv1x1_gemm_cat(w, x, x2))
                 else:
@@ -119,7 +118,7 @@ def main():
                 totals[c] += t * depth[stage]
                 if c == "auto":
                     t_auto = t
-                tag = plan_of(R, K + cat, g, M, views)[0] if c in ("auto", "wcm") else (ncfg if c == "N" else c)
+                tag = plan_of(R, K + cat, g, M, views)[0] if c == "auto" else (ncfg if c == "N" else c)
                 cols.append(f"{tag:>4s} {t:7.1f} us")
             force(None)
             extra = ""
