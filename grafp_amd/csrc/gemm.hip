@@ -155,12 +155,16 @@ __device__ __forceinline__ void gm_chan(float &n, float &mean, float &m2, float 
 // the data gradient of the first layer of a residual block takes the shortcut's gradient as extra operand rows
 // against an identity block of the weight, dX = [W^T | I] [dY; dZ] -- the sum is rounded once and the separate
 // gradient-accumulation add (two reads, one write of C x M) is gone.
-template <typename CFG, int NS, bool PRO, bool STATS, bool CAT = false>
+// EPI: inference (eval-mode BatchNorm: scale and shift known before the product): z = act(bf16(W x) * scale + shift) is
+// formed in the epilogue -- the same arithmetic on the same rounded value as bn_affine_bf16_kernel, so the result is
+// bit-identical to GEMM + normalise pass, without writing and re-reading y (fingerprint generation: generate.py:34-57).
+template <typename CFG, int NS, bool PRO, bool STATS, bool CAT = false, bool EPI = false>
 __global__ __launch_bounds__(CFG::THREADS, CFG::NW == 4 ? 2 : 1) void conv1x1_gemm_kernel(
     const unsigned short *__restrict__ A, int lda, const unsigned short *__restrict__ X, unsigned short *__restrict__ Y,
     int64_t M, int Rg, int K, int row_tiles, int ranges_view, int tiles_range, int col_tiles_view, int views,
     const float2 *__restrict__ pro_tab, int pro_act, float pro_slope, float *__restrict__ part, int P, int nblocks,
-    const unsigned short *__restrict__ X2 = nullptr, int K1 = 0) {
+    const unsigned short *__restrict__ X2 = nullptr, int K1 = 0, const float2 *__restrict__ epi_tab = nullptr,
+    int epi_act = 0, float epi_slope = 0.0f) {
     constexpr int D = NS - 1;                               // chunks in flight
     constexpr int RT = CFG::RT, TN = CFG::TN, ROWB = CFG::ROWB, PER = CFG::PER, OR = CFG::OR;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -283,6 +287,17 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::NW == 4 ? 2 : 1) void conv1x1_ge
         stores_per_epi += rt_valid[ri] ? GM_STORES_PER_RT : 0;
     }
 
+    float2 esc[RT];                                          // EPI: (scale, shift) of the lane's row of each 32-row tile
+#pragma unroll
+    for (int ri = 0; ri < RT; ++ri) {
+        esc[ri] = make_float2(1.0f, 0.0f);
+        if (EPI) {
+            int r = r0 + wr * 32 * RT + ri * 32 + l31;
+            if (r > Rg - 1) r = Rg - 1;
+            esc[ri] = epi_tab[((size_t)grp * Rg + r) * views + view];
+        }
+    }
+
     // vector-memory operations issued AFTER the DMA of chunk t, by iteration: dma_hist[j] / st_hist[j] = issued in
     // iteration t-1-j (the wait for chunk t may leave exactly those in flight)
     int dma_hist[D], st_hist[D + 1];
@@ -383,8 +398,20 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::NW == 4 ? 2 : 1) void conv1x1_ge
                     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                         for (int rg = 0; rg < 4; ++rg) {
-                            const unsigned p0 = gm_pack_bf16(acc[mi][ri][4 * rg + 0], acc[mi][ri][4 * rg + 1]);
-                            const unsigned p1 = gm_pack_bf16(acc[mi][ri][4 * rg + 2], acc[mi][ri][4 * rg + 3]);
+                            unsigned p0 = gm_pack_bf16(acc[mi][ri][4 * rg + 0], acc[mi][ri][4 * rg + 1]);
+                            unsigned p1 = gm_pack_bf16(acc[mi][ri][4 * rg + 2], acc[mi][ri][4 * rg + 3]);
+                            if (EPI) {
+                                float v[4] = {__uint_as_float(p0 << 16), __uint_as_float(p0 & 0xffff0000u),
+                                              __uint_as_float(p1 << 16), __uint_as_float(p1 & 0xffff0000u)};
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    v[e] = __builtin_fmaf(v[e], esc[ri].x, esc[ri].y);
+                                    if (epi_act == 1) v[e] = fmaxf(v[e], 0.f);
+                                    else if (epi_act == 2) v[e] = v[e] > 0.f ? v[e] : v[e] * epi_slope;
+                                }
+                                p0 = gm_pack_bf16(v[0], v[1]);
+                                p1 = gm_pack_bf16(v[2], v[3]);
+                            }
                             if (STATS) {
                                 // two elements per VALU instruction (v_pk_add_f32 / v_pk_fma_f32): the statistics
                                 // are VALU work the MFMAs wait for -- 4 instructions per output element cost as
@@ -713,19 +740,24 @@ struct GemmArgs {
     int pro_act;
     float pro_slope;
     float *part;
+    const float2 *epi_tab = nullptr;
+    int epi_act = 0;
+    float epi_slope = 0.0f;
 };
-template <typename CFG, int NS, bool PRO, bool STATS, bool CAT>
+template <typename CFG, int NS, bool PRO, bool STATS, bool CAT, bool EPI = false>
 static void gemm_launch(const GemmPlan &p, const GemmArgs &a, hipStream_t s) {
     const size_t lds = (size_t)NS * CFG::STAGE + CFG::NW * CFG::OUT_BYTES + (PRO ? (size_t)a.Kg * 8 : 0);
-    (void)hipFuncSetAttribute((const void *)conv1x1_gemm_kernel<CFG, NS, PRO, STATS, CAT>,
+    (void)hipFuncSetAttribute((const void *)conv1x1_gemm_kernel<CFG, NS, PRO, STATS, CAT, EPI>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((conv1x1_gemm_kernel<CFG, NS, PRO, STATS, CAT>), dim3(p.nblocks, 1, a.groups), dim3(CFG::THREADS),
-                       lds, s, a.w, a.lda, a.x, a.y, a.M, a.Rg, a.Kg, p.row_tiles, p.ranges_view, p.tiles_range,
-                       p.col_tiles_view, a.views, a.pro_tab, a.pro_act, a.pro_slope, a.part, p.P, p.nblocks, a.x2, a.K1);
+    hipLaunchKernelGGL((conv1x1_gemm_kernel<CFG, NS, PRO, STATS, CAT, EPI>), dim3(p.nblocks, 1, a.groups),
+                       dim3(CFG::THREADS), lds, s, a.w, a.lda, a.x, a.y, a.M, a.Rg, a.Kg, p.row_tiles, p.ranges_view,
+                       p.tiles_range, p.col_tiles_view, a.views, a.pro_tab, a.pro_act, a.pro_slope, a.part, p.P, p.nblocks,
+                       a.x2, a.K1, a.epi_tab, a.epi_act, a.epi_slope);
 }
 // plain / statistics / concatenated-operand forms of one tile configuration
 template <typename CFG, int NS> static void gemm_launch_cfg(const GemmPlan &p, const GemmArgs &a, hipStream_t s) {
-    if (a.x2) gemm_launch<CFG, NS, false, false, true>(p, a, s);
+    if (a.epi_tab) gemm_launch<CFG, NS, false, false, false, true>(p, a, s);
+    else if (a.x2) gemm_launch<CFG, NS, false, false, true>(p, a, s);
     else if (a.part) gemm_launch<CFG, NS, false, true, false>(p, a, s);
     else gemm_launch<CFG, NS, false, false, false>(p, a, s);
 }
@@ -775,6 +807,26 @@ extern "C" int grafp_conv1x1_gemm_bf16(const void *w, const void *x, int R, int 
     a.pro_tab = (const float2 *)pro_tab; a.pro_act = pro_act; a.pro_slope = pro_slope; a.part = stats_part;
     gemm_dispatch(p, a, (hipStream_t)stream);
     GRAFP_CHECK_LAUNCH("conv1x1_gemm_kernel");
+    return GRAFP_OK;
+}
+
+extern "C" int grafp_conv1x1_gemm_affine_bf16(const void *w, const void *x, int R, int K, int groups, int64_t M, int views,
+                                              const float *tab, int act, float slope, void *z, grafp_stream_t stream) {
+    using namespace grafp;
+    GRAFP_REQUIRE(w && x && z && tab, "conv1x1_gemm_affine: null pointer");
+    GRAFP_REQUIRE(gemm_shape_ok(R, K, groups, M, views), "conv1x1_gemm_affine: unsupported shape R=%d K=%d groups=%d M=%lld "
+                  "views=%d", R, K, groups, (long long)M, views);
+    GRAFP_REQUIRE((((uintptr_t)w | (uintptr_t)x | (uintptr_t)z) & 15) == 0, "conv1x1_gemm_affine: operands must be 16-byte aligned");
+    GRAFP_REQUIRE(act >= 0 && act <= 2, "conv1x1_gemm_affine: bad activation %d", act);
+    const int Rg = R / groups, Kg = K / groups;
+    const GemmPlan p = gemm_plan(Rg, Kg, groups, M, views);
+    GemmArgs a;
+    a.w = (const unsigned short *)w; a.x = (const unsigned short *)x; a.x2 = nullptr; a.y = (unsigned short *)z;
+    a.lda = Kg; a.K1 = 0; a.M = M; a.Rg = Rg; a.Kg = Kg; a.groups = groups; a.views = views;
+    a.pro_tab = nullptr; a.pro_act = 0; a.pro_slope = 0.0f; a.part = nullptr;
+    a.epi_tab = (const float2 *)tab; a.epi_act = act; a.epi_slope = slope;
+    gemm_dispatch(p, a, (hipStream_t)stream);
+    GRAFP_CHECK_LAUNCH("conv1x1_gemm_kernel (affine epilogue)");
     return GRAFP_OK;
 }
 

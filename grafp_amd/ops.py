@@ -48,6 +48,7 @@ class _Switches:
     shortcut_fusion = True        # False: autograd's accumulate kernel instead of the [W^T | I] data-gradient product
     bn_spin_limit = -1            # polls of the single-pass BatchNorm rendezvous (-1: the library default; 0: never wait)
     knn_split = True              # False: every k-NN graph by the exact-f32 MFMA kernel (knn_graph.hip) -- same indices
+    fused_eval_affine = True      # False: eval-mode conv+BN+act as GEMM + normalise pass (same bits) instead of one kernel
 
 
 switches = _Switches()
@@ -728,6 +729,24 @@ def conv1x1_gemm(w, x, groups=1, views=1, pro_tab=None, pro_act=ACT_NONE, pro_sl
     return (y, part) if stats else y
 
 
+def conv1x1_gemm_affine(w, x, tab, groups=1, views=1, act=ACT_NONE, slope=0.0):
+    """z = act(bf16(W x) * scale + shift): the eval-mode [1x1 conv -> BatchNorm -> activation] chain in one kernel
+    (tab (R, views, 2) from bn_finalize(training=False)); bit-identical to conv1x1_gemm + bn_affine."""
+    _require_gpu(w, x, tab)
+    if w.dtype != torch.bfloat16 or x.dtype != torch.bfloat16:
+        raise TypeError("conv1x1_gemm_affine: bf16 operands")
+    w, x = w.contiguous(), x.contiguous()
+    R, K, M = w.shape[0], x.shape[0], x.shape[1]
+    if w.shape[1] * groups != K:
+        raise ValueError(f"conv1x1_gemm_affine: weight {tuple(w.shape)} x groups {groups} does not match {K} operand rows")
+    z = torch.empty((R, M), dtype=torch.bfloat16, device=x.device)
+    tab = _f32c(tab)
+    with _timed("conv1x1_gemm", (R, K, groups, M)):
+        check(lib.grafp_conv1x1_gemm_affine_bf16(_p(w), _p(x), R, K, groups, M, views, _p(tab), int(act), float(slope),
+                                                 _p(z), _stream()), "conv1x1_gemm_affine")
+    return z
+
+
 def conv1x1_gemm_cat(w, x1, x2):
     """y = W [x1; x2] for bf16 rows x1 (K1, M), x2 (K2, M) and w (R, K1 + K2): the concatenation is never materialised."""
     _require_gpu(w, x1, x2)
@@ -875,6 +894,13 @@ class _ConvBnAct(torch.autograd.Function):
             wl = w.detach().reshape(R, -1).to(torch.bfloat16)
         g32, b32 = _f32c(gamma), _f32c(beta)
         pb = None if pre_bias is None else _f32c(pre_bias)
+        if (not training and residual is None and switches.fused_eval_affine and not any(ctx.needs_input_grad)):
+            # inference without a shortcut (fc1, the grouped conv, ffn1, Downsample): the normalisation rides the GEMM's
+            # epilogue -- no y, no second pass (nothing is saved: no gradient will be asked for)
+            mean, invstd, tab = bn_finalize(None, R, K, conv_groups, M, views, g32, b32, pb, running_mean, running_var,
+                                            False, momentum, eps)
+            ctx.cfg = None
+            return conv1x1_gemm_affine(wl, x, tab, conv_groups, views, act, slope)
         if training:
             y, part = conv1x1_gemm(wl, x, conv_groups, views, stats=True)
         else:

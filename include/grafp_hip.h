@@ -253,6 +253,13 @@ int grafp_conv1x1_gemm_bf16(const void *w, const void *x, int R, int K, int grou
                             const float *pro_tab, int pro_act, float pro_slope, void *y, float *stats_part,
                             grafp_stream_t stream);
 
+/* Inference form of [Conv2d(1x1) -> BatchNorm2d (eval: running statistics) -> activation] in ONE kernel (fingerprint
+ * generation, generate.py:34-57 / test_fp.py:87-158 run the model in eval mode): z = act(bf16(W x) * tab.x + tab.y) with
+ * tab (R, views, 2) from grafp_bn_finalize(training = 0).  Bit-identical to grafp_conv1x1_gemm_bf16 followed by
+ * grafp_bn_affine_bf16 (the same arithmetic on the same rounded product); y is neither written nor re-read. */
+int grafp_conv1x1_gemm_affine_bf16(const void *w, const void *x, int R, int K, int groups, int64_t M, int views,
+                                   const float *tab, int act, float slope, void *z, grafp_stream_t stream);
+
 /* y = W [x1; x2]: the operand is the row-wise concatenation of two (K1, M) / (K2, M) bf16 tensors (never materialised),
  * W (R, K1 + K2) bf16.  Used for the data gradient of the first layer of a residual block,
  * dX = [W^T | I] [dY; dZ]: the shortcut's gradient dZ (autograd's accumulate of

@@ -224,3 +224,19 @@ def test_weights_prepare_one_launch():
                 assert c._w_t is None and torch.equal(c._w_aug, torch.cat((want.reshape(R, Kg).t(), eye), dim=1))
             else:
                 assert c._w_aug is None and torch.equal(c._w_t, ops._group_transpose(want.reshape(R, Kg), c.groups))
+
+
+@pytest.mark.parametrize("R,K,groups,M,views,act", [(64, 64, 1, 8192, 2, 0), (256, 64, 1, 8192, 1, 1), (128, 128, 4, 4096, 2, 1),
+                                                    (1024, 256, 1, 2048, 1, 1), (64, 256, 1, 131072, 2, 2),
+                                                    (128, 512, 1, 262144, 1, 1), (96, 32, 1, 1280, 1, 1)])
+def test_gemm_affine_epilogue_equals_gemm_plus_affine(R, K, groups, M, views, act):
+    """Inference: z = act(bf16(W x) * scale + shift) formed in the GEMM's epilogue is bit-identical to the GEMM followed
+    by the normalise pass (every tile configuration, grouped, ragged rows, both activations, per-view tables)."""
+    from grafp_amd import ops
+    w = _rand((R, K // groups), 51, 0.2)
+    x = _rand((K, M), 52, 1.0, 0.3)
+    g = torch.Generator().manual_seed(53)
+    tab = torch.stack((torch.rand((R, views), generator=g) + 0.5, torch.randn((R, views), generator=g)), dim=-1).to(DEV)
+    want = ops.bn_affine(ops.conv1x1_gemm(w, x, groups, views), tab, views, act=act, slope=0.2)
+    got = ops.conv1x1_gemm_affine(w, x, tab, groups, views, act=act, slope=0.2)
+    assert torch.equal(got, want)

@@ -421,6 +421,25 @@ def test_backward_after_another_forward_refuses_the_shared_weight_copies(dev):
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
 
 
+def test_eval_mode_fused_affine_epilogue_equals_two_kernels(dev, monkeypatch):
+    """Fingerprint generation (eval mode, bf16): the layers without a shortcut take the GEMM with the normalisation in its
+    epilogue -- same embeddings, bit for bit, as GEMM + normalise pass."""
+    from grafp_amd import ops
+    cfg, model = _filled_model(dev)
+    model.eval()
+    xi, _ = simclr_inputs()
+    calls = []
+    orig = ops.conv1x1_gemm_affine
+    monkeypatch.setattr(ops, "conv1x1_gemm_affine", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        h1, z1 = model.embed(xi.to(dev))
+        n_fused = len(calls)
+        monkeypatch.setattr(ops.switches, "fused_eval_affine", False)
+        h0, z0 = model.embed(xi.to(dev))
+    assert n_fused == 12 * 3 + 3 and len(calls) == n_fused        # fc1, grouped conv, ffn1 of every block + 3 Downsamples
+    assert torch.equal(h1, h0) and torch.equal(z1, z0)
+
+
 def test_trainer_with_device_augmentation_eager_and_graph(dev):
     """The training step with the second view augmented on the device (impulse responses + background noise for
     every clip): runs eagerly and replayed from one HIP graph (the per-clip draws use the device generator, which
