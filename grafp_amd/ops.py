@@ -894,13 +894,6 @@ class _ConvBnAct(torch.autograd.Function):
             wl = w.detach().reshape(R, -1).to(torch.bfloat16)
         g32, b32 = _f32c(gamma), _f32c(beta)
         pb = None if pre_bias is None else _f32c(pre_bias)
-        if (not training and residual is None and switches.fused_eval_affine and not any(ctx.needs_input_grad)):
-            # inference without a shortcut (fc1, the grouped conv, ffn1, Downsample): the normalisation rides the GEMM's
-            # epilogue -- no y, no second pass (nothing is saved: no gradient will be asked for)
-            mean, invstd, tab = bn_finalize(None, R, K, conv_groups, M, views, g32, b32, pb, running_mean, running_var,
-                                            False, momentum, eps)
-            ctx.cfg = None
-            return conv1x1_gemm_affine(wl, x, tab, conv_groups, views, act, slope)
         if training:
             y, part = conv1x1_gemm(wl, x, conv_groups, views, stats=True)
         else:
@@ -974,6 +967,19 @@ def conv_bn_act(x, w, gamma, beta, running_mean, running_var, training, momentum
     """act(BatchNorm(W x + pre_bias)) + residual for bf16 (K, M) rows (see _ConvBnAct).  token / token_role: a
     ShortcutToken shared by the first (role 1: its input IS the shortcut) and the last layer (role 2: `residual` is that
     same input) of a residual block."""
+    if not training and residual is None and switches.fused_eval_affine and not torch.is_grad_enabled():
+        # inference without a shortcut (fc1, the grouped conv, ffn1, Downsample): the normalisation rides the GEMM's
+        # epilogue -- no y, no second pass, no autograd node
+        x = x.detach().contiguous()
+        K, M = x.shape
+        R = w.shape[0]
+        if w_lowp is not None and w_lowp.dtype == torch.bfloat16 and w_lowp.numel() == w.numel():
+            wl = w_lowp.detach().reshape(R, -1)
+        else:
+            wl = w.detach().reshape(R, -1).to(torch.bfloat16)
+        _, _, tab = bn_finalize(None, R, K, int(conv_groups), M, int(views), gamma, beta, pre_bias, running_mean,
+                                running_var, False, momentum, eps)
+        return conv1x1_gemm_affine(wl, x, tab, int(conv_groups), int(views), int(act), float(slope))
     return _ConvBnAct.apply(x.contiguous(), w, w_lowp, int(conv_groups), int(views), gamma, beta, pre_bias, residual,
                             running_mean, running_var, bool(training), float(momentum), float(eps), int(act),
                             float(slope), token, int(token_role), w_t, w_aug)
