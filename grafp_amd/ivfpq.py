@@ -128,7 +128,11 @@ class IVFPQIndex:
         return self._raw[0]
 
     # ---- search: nprobe nearest lists, asymmetric distances of their codes (csrc/ivfpq.hip), top-k --------------------
-    def search(self, q, k, max_queries_per_launch=256):
+    def search(self, q, k, max_queries_per_launch=None, scratch_bytes=1 << 30):
+        """max_queries_per_launch: None = as many queries per scan launch as `scratch_bytes` (default 1 GiB) of distance /
+        position scratch allow -- a launch needs 8 bytes per (query, code of a probed list), and the probed lists hold
+        about nprobe / nlist of the index, so the dense form grows with ntotal (at the protocol's dummy-DB sizes a fixed
+        256-query launch would ask for tens of GB)."""
         as_numpy = isinstance(q, np.ndarray)
         qt = torch.as_tensor(np.ascontiguousarray(q) if as_numpy else q).to(self.device, torch.float32).reshape(-1, self.d)
         nq = qt.shape[0]
@@ -141,6 +145,10 @@ class IVFPQIndex:
             coarse = (c * c).sum(1)[None, :] - 2.0 * qt @ c.t()
             probe = torch.topk(coarse, nprobe, dim=1, largest=False).indices.to(torch.int32).contiguous()
             stream = _vp(torch.cuda.current_stream().cuda_stream)
+            if max_queries_per_launch is None:
+                # upper bound of a query's probed codes without a device round trip: the nprobe longest lists
+                per_query = int(torch.topk(counts, nprobe).values.sum().item()) * 8
+                max_queries_per_launch = max(1, min(256, int(scratch_bytes // max(per_query, 1))))
             for lo in range(0, nq, max_queries_per_launch):
                 pb = probe[lo:lo + max_queries_per_launch]
                 qb = qt[lo:lo + max_queries_per_launch].contiguous()
