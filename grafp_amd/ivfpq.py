@@ -146,7 +146,7 @@ class IVFPQIndex:
             probe = torch.topk(coarse, nprobe, dim=1, largest=False).indices.to(torch.int32).contiguous()
             stream = _vp(torch.cuda.current_stream().cuda_stream)
             if max_queries_per_launch is None:
-                # upper bound of a query's probed codes without a device round trip: the nprobe longest lists
+                # upper bound of a query's probed codes (the nprobe longest lists): one host read per search() call
                 per_query = int(torch.topk(counts, nprobe).values.sum().item()) * 8
                 max_queries_per_launch = max(1, min(256, int(scratch_bytes // max(per_query, 1))))
             for lo in range(0, nq, max_queries_per_launch):
