@@ -143,6 +143,7 @@ class GradSync:
         self._size = [len(m) for m in self._members]
         self._left, self._handles, self._fired = list(self._size), [], [False] * len(self.bounds)
         self._hooks = []
+        self._cap_events = None
         self.paused = False            # Trainer.step_graph: backward is being captured, the buckets are reduced afterwards
         self.capturing = False         # ... and each bucket marks its completion with an external event (begin_capture)
         if overlap and (self.world > 1 or force_flat):
@@ -196,9 +197,17 @@ class GradSync:
         collectives; when a bucket's last gradient arrives they record the bucket's pack (one multi-tensor copy into the
         flat buffer) and the bump of the bucket's ProgressFlag.  On replay a communication stream waits for flag b and
         all-reduces bucket b while the rest of the backward graph is still running -- overlap without capturing RCCL."""
-        self._cap_events = [ProgressFlag(self.flat.device) for _ in self.bounds]
+        if not self._cap_events:
+            raise RuntimeError("GradSync.begin_capture: call prepare_capture() BEFORE the capture begins (the flags must "
+                               "not be allocated -- and zero-filled -- by the graph itself)")
         self._cap_left, self._cap_done = list(self._size), [False] * len(self.bounds)
         self.capturing = True
+
+    def prepare_capture(self):
+        """Outside any capture: the per-bucket progress flags (ordinary device memory that outlives the graphs; allocated
+        inside the capture they would come from the graph's private pool and their zero-fill would be replayed)."""
+        self._cap_events = [ProgressFlag(self.flat.device) for _ in self.bounds]
+        torch.cuda.current_stream().synchronize()
 
     def end_capture(self):
         """Still inside the capture, after backward: buckets whose parameters did not all receive a gradient are packed

@@ -142,6 +142,7 @@ class Trainer:
         self.model.train()
         self.sync.zero()
         self.sync.paused = True                      # no collective from the autograd hooks while the graphs are recorded
+        self.sync.prepare_capture()                  # the buckets' progress flags: allocated before any capture
         try:
             g_fwd = torch.cuda.CUDAGraph()
             # thread_local: the process group's watchdog thread may query events while this thread records
