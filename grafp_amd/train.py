@@ -23,13 +23,16 @@ def build_model(cfg, k=3, device=None):
 
 class Trainer:
     def __init__(self, cfg, model, device, amp_dtype=None, group=None, lr=None, n_buckets=4, ir_dir=None,
-                 noise_dir=None, aug_seed=None, data_parallel_graphs=None):
+                 noise_dir=None, aug_seed=None, data_parallel_graphs=None, overlap_graph_allreduce=False):
         self.cfg, self.model, self.device, self.group = cfg, model, device, group
         self.amp_dtype = amp_dtype
         self.world = gdist.world_size(group)
         # step_graph's data-parallel form (three graphs, eager collectives): by default whenever there is more than one
         # rank; True forces it for a one-rank process group too (the tests run RCCL that way on a one-GPU box)
         self._dp_graphs = self.world > 1 if data_parallel_graphs is None else bool(data_parallel_graphs)
+        # step_graph on an RCCL backend: True = each bucket's all-reduce starts behind its progress flag while the backward
+        # graph is still running (GradSync.reduce_buckets_after); False (default) = all buckets after the graph
+        self._overlap_graph_allreduce = bool(overlap_graph_allreduce)
         self._comm = None
         # ir_dir / noise_dir: recordings for the batched device-side augmentation of the second view (train.py:150-151)
         self.augment = GPUTransformNeuralfp(dict(cfg, aug_seed=aug_seed), ir_dir, noise_dir, train=True).to(device)
@@ -192,6 +195,8 @@ class Trainer:
         if host_staged:
             torch.cuda.current_stream().synchronize()
             self.sync.reduce_all()
+        elif not self._overlap_graph_allreduce:
+            self.sync.reduce_all()                    # stream-ordered behind the graph
         else:
             if self._comm is None:
                 self._comm = torch.cuda.Stream()

@@ -28,7 +28,8 @@ def graph_mode(out, B, rccl_one_rank=False):
     cfg["bsz_train"] = B
     torch.manual_seed(1234)
     model = build_model(cfg, device=device)
-    tr = Trainer(cfg, model, device, amp_dtype=torch.bfloat16, data_parallel_graphs=True if rccl_one_rank else None)
+    tr = Trainer(cfg, model, device, amp_dtype=torch.bfloat16, data_parallel_graphs=True if rccl_one_rank else None,
+                 overlap_graph_allreduce=os.environ.get("TEST_OVERLAP", "0") == "1")
     assert tr._dp_graphs
     per = B // world
     sl = slice(rank * per, (rank + 1) * per)
