@@ -48,9 +48,14 @@ template <typename T>
 __global__ __launch_bounds__(256) void knn_normalize_split_kernel(const T *__restrict__ x, int64_t sb, int64_t sc,
                                                                   float *__restrict__ den_out, float *__restrict__ sq,
                                                                   unsigned short *__restrict__ xh,
-                                                                  unsigned short *__restrict__ xl, int C, int N) {
+                                                                  unsigned short *__restrict__ xl, int C, int N,
+                                                                  int *__restrict__ counters) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     const int b = blockIdx.y;
+    // the two counters of this call (all uncertified / light queries) start at zero: done here, in front of pass 2 in
+    // stream order, rather than by a hipMemsetAsync -- a memset NODE inside a captured graph faulted on replay once
+    // other work had run in between (HIP 7.0)
+    if (blockIdx.x == 0 && b == 0 && threadIdx.x < 2) counters[threadIdx.x] = 0;
     if (n >= N) return;
     const T *xb = x + (size_t)b * sb + n;
     const size_t o = (size_t)b * C * N + n;
@@ -355,8 +360,11 @@ template <int K, typename I, typename T>
 __global__ __launch_bounds__(256) void knn_exact_clip_kernel(const T *__restrict__ x, int64_t sb, int64_t sc,
                                                              const float *__restrict__ den, const float *__restrict__ sq,
                                                              const unsigned char *__restrict__ unc_flag,
-                                                             I *__restrict__ idx, int C, int N, int chc) {
+                                                             I *__restrict__ idx, int C, int N, int chc,
+                                                             const int *__restrict__ counters,
+                                                             int *__restrict__ n_uncertified) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm_x[];
+    if (n_uncertified && blockIdx.x == 0 && threadIdx.x == 0) *n_uncertified = counters[0];   // diagnostics (last pass)
     T *sX = reinterpret_cast<T *>(sm_x);                                       // [2][chc][W] feature chunks (W columns)
     float *sQ = reinterpret_cast<float *>(sm_x + 2 * KX_CHUNK);                 // [KX_QG][C]
     int *s_list = reinterpret_cast<int *>(sQ + KX_QG * C);                      // [N]
@@ -516,7 +524,7 @@ struct KsArgs {
     int64_t sb, sc;
     const unsigned short *xh, *xl;
     const float *sq, *den;
-    int *count, *extra, *light;
+    int *count, *extra, *light, *n_unc;
     unsigned char *flag;
     void *idx;
     int B, C, N;
@@ -534,7 +542,7 @@ template <int K, typename I, typename T> static void ks_launch_exact(const KsArg
     (void)hipFuncSetAttribute((const void *)knn_exact_clip_kernel<K, I, T>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds_x);
     hipLaunchKernelGGL((knn_exact_clip_kernel<K, I, T>), dim3(a.B), dim3(256), lds_x, s, (const T *)a.x, a.sb, a.sc, a.den,
-                       a.sq, a.flag, (I *)a.idx, a.C, a.N, chc);
+                       a.sq, a.flag, (I *)a.idx, a.C, a.N, chc, a.count, a.n_unc);
 }
 template <int K, typename I> static void ks_launch(const KsArgs &a, hipStream_t s) {
     const int tiles = a.N / KS_TQ, nblocks = a.B * tiles;
@@ -599,30 +607,21 @@ extern "C" int grafp_knn_graph_split(const void *x, int dtype, int64_t stride_b,
     GRAFP_REQUIRE((((uintptr_t)xh | (uintptr_t)xl | (uintptr_t)x) & 15) == 0 && (stride_b * (dtype == GRAFP_F32 ? 4 : 2)) % 16 == 0 &&
                       (stride_c * (dtype == GRAFP_F32 ? 4 : 2)) % 16 == 0,
                   "knn_graph_split: input rows and workspace must be 16-byte aligned");
-    if (hipMemsetAsync(count, 0, 2 * sizeof(int), s) != hipSuccess) {       // [0] all uncertified, [1] the light ones
-        set_error("knn_graph_split: hipMemsetAsync failed");
-        return GRAFP_ERR_LAUNCH;
-    }
     const dim3 gn((N + 255) / 256, B);
     if (dtype == GRAFP_F32)
         hipLaunchKernelGGL(knn_normalize_split_kernel<float>, gn, dim3(256), 0, s, (const float *)x, stride_b, stride_c,
-                           den, sq, xh, xl, C, N);
+                           den, sq, xh, xl, C, N, count);
     else
         hipLaunchKernelGGL(knn_normalize_split_kernel<unsigned short>, gn, dim3(256), 0, s, (const unsigned short *)x,
-                           stride_b, stride_c, den, sq, xh, xl, C, N);
+                           stride_b, stride_c, den, sq, xh, xl, C, N, count);
     GRAFP_CHECK_LAUNCH("knn_normalize_split_kernel");
     KsArgs a;
     a.x = x; a.f32 = dtype == GRAFP_F32; a.sb = stride_b; a.sc = stride_c; a.xh = xh; a.xl = xl; a.sq = sq; a.den = den;
-    a.count = count; a.flag = flag; a.extra = extra; a.light = light; a.idx = idx; a.B = B; a.C = C; a.N = N;
+    a.count = count; a.n_unc = (int *)n_uncertified; a.flag = flag; a.extra = extra; a.light = light; a.idx = idx; a.B = B; a.C = C; a.N = N;
     a.margin2 = 2.0f * ks_margin(C);
     a.key_mask = ~((1u << ks_index_bits(N)) - 1u);
     if (idx_is_i32) ks_launch_k<int32_t>(k, a, s);
     else ks_launch_k<int64_t>(k, a, s);
     GRAFP_CHECK_LAUNCH("knn_topk_split_kernel");
-    if (n_uncertified &&
-        hipMemcpyAsync(n_uncertified, count, sizeof(int), hipMemcpyDeviceToDevice, s) != hipSuccess) {
-        set_error("knn_graph_split: hipMemcpyAsync failed");
-        return GRAFP_ERR_LAUNCH;
-    }
     return GRAFP_OK;
 }
