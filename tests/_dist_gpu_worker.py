@@ -13,11 +13,12 @@ from grafp_amd.train import Trainer, build_model, synthetic_batch      # noqa: E
 from grafp_amd.util import load_config                                 # noqa: E402
 
 
-def graph_mode(out, B, rccl_one_rank=False):
+def graph_mode(out, B, rccl_one_rank=False, overlap=False):
     """Trainer.step_graph under data parallelism (three graphs, eager collectives between) against Trainer.step from
     the same weights and optimizer state, on this rank's shard: losses and parameter updates.
     rccl_one_rank: a ONE-rank process group on the `nccl` (= RCCL) backend with the data-parallel graph form forced --
-    the only way to run RCCL's kernels, the external bucket events and the communication stream on a one-GPU box."""
+    the only way to run RCCL's kernels, the bucket progress flags and the communication stream on a one-GPU box;
+    overlap: the opt-in form that starts each bucket's all-reduce behind its flag (Trainer(overlap_graph_allreduce=True))."""
     if rccl_one_rank:
         rank, world, device = 0, 1, torch.device("cuda", 0)
         torch.cuda.set_device(0)
@@ -29,7 +30,7 @@ def graph_mode(out, B, rccl_one_rank=False):
     torch.manual_seed(1234)
     model = build_model(cfg, device=device)
     tr = Trainer(cfg, model, device, amp_dtype=torch.bfloat16, data_parallel_graphs=True if rccl_one_rank else None,
-                 overlap_graph_allreduce=os.environ.get("TEST_OVERLAP", "0") == "1")
+                 overlap_graph_allreduce=overlap)
     assert tr._dp_graphs
     per = B // world
     sl = slice(rank * per, (rank + 1) * per)
@@ -70,8 +71,8 @@ def graph_mode(out, B, rccl_one_rank=False):
 
 def main():
     out, B = sys.argv[1], int(sys.argv[2])
-    if len(sys.argv) > 3 and sys.argv[3] in ("graph", "graph_rccl1"):
-        return graph_mode(out, B, rccl_one_rank=sys.argv[3] == "graph_rccl1")
+    if len(sys.argv) > 3 and sys.argv[3] in ("graph", "graph_rccl1", "graph_rccl1_overlap"):
+        return graph_mode(out, B, rccl_one_rank=sys.argv[3] != "graph", overlap=sys.argv[3] == "graph_rccl1_overlap")
     rank, world, device = gdist.init_from_env(backend="gloo", local_device=0)
     cfg = load_config()
     cfg["bsz_train"] = B

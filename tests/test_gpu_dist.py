@@ -155,12 +155,14 @@ def test_step_graph_data_parallel(tmp_path):
         assert a["p_sum"] == b["p_sum"]                 # replicas stay in step (same reduced gradients, same update)
 
 
-def test_step_graph_data_parallel_over_rccl_one_rank(tmp_path):
+@pytest.mark.parametrize("mode", ["graph_rccl1", "graph_rccl1_overlap"])
+def test_step_graph_data_parallel_over_rccl_one_rank(tmp_path, mode):
     """The same comparison on the RCCL backend (a one-rank process group: the most a one-GPU box can do): the all-gather
-    and the four bucket all-reduces are RCCL launches, and each all-reduce is enqueued on the communication stream behind
-    the progress flag its bucket bumps inside the replayed backward graph (GradSync.begin_capture)."""
+    and the four bucket all-reduces are RCCL launches, stream-ordered behind the replayed backward graph (the default) or,
+    with Trainer(overlap_graph_allreduce=True), each enqueued on the communication stream behind the progress flag its
+    bucket bumps inside that graph (GradSync.begin_capture)."""
     out = str(tmp_path / "g1")
-    _launch(1, out, 16, extra=("graph_rccl1",))
+    _launch(1, out, 16, extra=(mode,))
     for step in torch.load(f"{out}.0.pt", weights_only=False):
         assert abs(step["loss_g"] - step["loss_e"]) <= 2e-3 * max(1.0, abs(step["loss_e"])), step
         assert step["d_e"] > 0 and step["d_diff"] < 0.05 * step["d_e"], step
