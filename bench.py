@@ -101,6 +101,19 @@ def summarise_kernels(timed, esize=4):
             by = sum((4.0 * C * N + 4.0 * N + 4.0 * k * N) * B for _, _, (B, C, N, k) in ev)
             row.update(bound="mfma", achieved=round(fl / (tot * 1e-3) / 1e12, 3), unit="TFLOP/s",
                        peak=PEAK_F32_MATRIX_TFLOPS)
+        elif name == "knn_split":
+            # the certified path (knn_split.hip), all passes of a call: norms, scan, exact recomputation of the
+            # uncertified queries.  bf16 inputs: ONE bf16 MFMA per 16 channels of a 32 x 32 tile (2 N^2 C flops) beside
+            # 12 VALU instructions per (query, candidate) pair for the key and its sorted insert -- the scan is VALU-bound,
+            # so the matrix fraction is small by construction; valu_frac prices the pairs at 12 lane-operations against
+            # 256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz
+            fl = sum(knn_flops(m[:4]) * (1.0 if m[4] == 2 else 3.0) for _, _, m in ev)
+            by = sum((e * C * N * 2.0 + 4.0 * k * N) * B for _, _, (B, C, N, k, e) in ev)
+            pairs = sum(float(B) * N * N for _, _, (B, C, N, k, e) in ev)
+            row.update(bound="mfma", achieved=round(fl / (tot * 1e-3) / 1e12, 3), unit="TFLOP/s",
+                       peak=PEAK_BF16_MFMA_TFLOPS,
+                       valu_frac=round(pairs * 12.0 / (256 * 4 * 16 * 2.4e9) / (tot * 1e-3), 4),
+                       note="VALU-bound scan (integer-key top-k inserts); see valu_frac")
         elif name == "knn_normalize":
             by = sum((esize * C * N + 4.0 * C * N + 4.0 * N) * B for _, _, (B, C, N, k) in ev)
         elif name in ("mrconv_fwd", "mrconv_bwd"):
@@ -156,7 +169,7 @@ def summarise_kernels(timed, esize=4):
     return out
 
 
-KERNEL_NAMES = ("conv1x1_gemm", "conv1x1_wgrad", "bn_bwd", "bn_affine", "bn_fwd", "knn_topk", "knn_normalize",
+KERNEL_NAMES = ("conv1x1_gemm", "conv1x1_wgrad", "bn_bwd", "bn_affine", "bn_fwd", "knn_split", "knn_topk", "knn_normalize",
                 "mrconv_fwd", "mrconv_bwd", "ntxent", "logmel", "peak_extract_fwd", "peak_extract_bwd")
 
 

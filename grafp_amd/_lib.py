@@ -43,6 +43,8 @@ SIGNATURES = {
     "grafp_knn_split_supported": (_I, [_I, _I, _I]),
     "grafp_knn_split_preferred": (_I, [_I, _I, _I]),
     "grafp_knn_split_workspace": (_Z, [_I, _I, _I]),
+    "grafp_knn_split_preferred_for": (_I, [_I, _I, _I, _I]),
+    "grafp_knn_split_workspace_for": (_Z, [_I, _I, _I, _I]),
     "grafp_knn_graph_split": (_I, [_P, _I, _L, _L, _I, _I, _I, _I, _P, _I, _P, _Z, _P, _P]),
     "grafp_mrconv_fwd_f32": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
     "grafp_mrconv_bwd_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),

@@ -27,6 +27,7 @@
 
 #include "common.h"
 #include "dma_ring.h"
+#include "tuning.h"
 
 namespace grafp {
 
@@ -299,6 +300,269 @@ __global__ __launch_bounds__(256, 2) void knn_topk_split_kernel(const unsigned s
     }
 }
 
+// ---- bf16 inputs: the RAW form (round 3b) -------------------------------------------------------------------------
+// A bf16 feature is its own exact bf16 operand.  G = <x_q, x_j> on the RAW features needs ONE bf16 MFMA per 16 channels
+// (no hi / lo planes, nothing written by pass 1 but the norms), and the normalisation moves behind the product:
+//   g~ = G r_j / den_q   (r_j = fl(1 / den_j)),      d'' = den_q d~ = fma(G, -2 r_j, fma(sq_j, den_q, (sq_q + 2^-10) den_q)).
+// For a fixed query the positive factor den_q does not change the order, so the keys are built from d'' (two VALU
+// instructions per candidate, as before) and the gaps are compared against 2 m den_q.  Error budget, unit rows:
+//   MFMA accumulation         C additions, each <= 2^-23 of a partial sum <= |x_q||x_j| (the products are exact in f32)
+//   r_j, the division         2 roundings, <= 2^-23 together
+//   oracle: fl(x / den) twice + its c-ordered fmaf chain            <= 2 * 2^-24 + C 2^-24
+//   => |g~ - g_oracle| <= e_r(C) = 1.5 C 2^-23 + 3 * 2^-23 ;   m_r(C) = 2 e_r(C) + 2e-6   (C = 64: 2.5e-5, 3 x tighter
+//   than the split form; C = 512: 1.9e-4)
+// Ranges: den >= 1e-12 by construction; a clip with a node norm above 2^40 (G could overflow) sends all its queries to
+// the exact pass.  Same outputs and tiers as knn_topk_split_kernel.
+constexpr int KR_NS = 4;                    // ring stages of [candidates | queries] (16 KB each)
+constexpr int KR_STAGE = 2 * KS_PLANE;
+constexpr int KR_NT = 8;                    // per-block candidate tables (cj = -2 r_j, sq_j) in flight
+constexpr int KR_LDS = KR_NS * KR_STAGE + KR_NT * KS_TR * 8;
+constexpr float KR_TINY = 1.8189894e-12f;   // 2^-39: |cj| below it <=> den_j > 2^40
+
+// pass 1 (RAW): den, sq exactly as knn_normalize_kernel (same chains, same bits) + the candidate table; VE nodes per thread
+template <int VE>
+__global__ __launch_bounds__(256) void knn_norms_kernel(const unsigned short *__restrict__ x, int64_t sb, int64_t sc,
+                                                        float *__restrict__ den_out, float *__restrict__ sq,
+                                                        float2 *__restrict__ cs, int B, int C, int N,
+                                                        int *__restrict__ counters) {
+    const int per = N / VE;
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid < 2) counters[gid] = 0;                            // see knn_normalize_split_kernel
+    if (gid >= (int64_t)B * per) return;
+    const int b = (int)(gid / per), n0 = (int)(gid - (int64_t)b * per) * VE;
+    const unsigned short *xb = x + (size_t)b * sb + n0;
+    float ss[VE], den[VE], q[VE];
+#pragma unroll
+    for (int u = 0; u < VE; ++u) ss[u] = 0.0f;
+    // raw bf16 pairs of channel c (VE / 2 dwords); 8 channels of loads in flight per thread
+    auto load = [&](int c, unsigned (&w)[VE / 2]) {
+        if (VE == 8) {
+            const uint4 t = *reinterpret_cast<const uint4 *>(xb + (size_t)c * sc);
+            w[0] = t.x; w[1 % (VE / 2)] = t.y; w[2 % (VE / 2)] = t.z; w[3 % (VE / 2)] = t.w;
+        } else if (VE == 4) {
+            const uint2 t = *reinterpret_cast<const uint2 *>(xb + (size_t)c * sc);
+            w[0] = t.x; w[1 % (VE / 2)] = t.y;
+        } else {
+            w[0] = *reinterpret_cast<const unsigned *>(xb + (size_t)c * sc);
+        }
+    };
+    for (int c = 0; c < C; c += 8) {                            // C % 32 == 0
+        unsigned w[8][VE / 2];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) load(c + j, w[j]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int e = 0; e < VE / 2; ++e) {
+                const float lo = __uint_as_float(w[j][e] << 16), hi = __uint_as_float(w[j][e] & 0xffff0000u);
+                ss[2 * e] = __builtin_fmaf(lo, lo, ss[2 * e]);
+                ss[2 * e + 1] = __builtin_fmaf(hi, hi, ss[2 * e + 1]);
+            }
+    }
+#pragma unroll
+    for (int u = 0; u < VE; ++u) {
+        den[u] = fmaxf(sqrtf(ss[u]), 1e-12f);
+        q[u] = 0.0f;
+    }
+    for (int c = 0; c < C; c += 8) {
+        unsigned w[8][VE / 2];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) load(c + j, w[j]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int e = 0; e < VE / 2; ++e) {
+                const float lo = __fdiv_rn(__uint_as_float(w[j][e] << 16), den[2 * e]);
+                const float hi = __fdiv_rn(__uint_as_float(w[j][e] & 0xffff0000u), den[2 * e + 1]);
+                q[2 * e] = __builtin_fmaf(lo, lo, q[2 * e]);
+                q[2 * e + 1] = __builtin_fmaf(hi, hi, q[2 * e + 1]);
+            }
+    }
+    const size_t o = (size_t)b * N + n0;
+#pragma unroll
+    for (int u = 0; u < VE; ++u) {
+        sq[o + u] = q[u];
+        den_out[o + u] = den[u];
+        cs[o + u] = make_float2(-2.0f * __frcp_rn(den[u]), q[u]);
+    }
+}
+
+template <int K, typename I>
+__global__ __launch_bounds__(256, 2) void knn_topk_raw_kernel(const unsigned short *__restrict__ x, int64_t sb, int64_t sc,
+                                                              const float *__restrict__ sq, const float *__restrict__ den,
+                                                              const float2 *__restrict__ cs, I *__restrict__ idx,
+                                                              int *__restrict__ unc_count,
+                                                              unsigned char *__restrict__ unc_flag,
+                                                              int *__restrict__ extra, int *__restrict__ light_list,
+                                                              int C, int N, int tiles_per_clip, int nblocks,
+                                                              float margin2, unsigned key_mask) {
+    constexpr int D = KR_NS - 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const float2 *const sCS = reinterpret_cast<const float2 *>(smem + KR_NS * KR_STAGE);
+    const unsigned lds0 = (unsigned)(uintptr_t)(gm_lptr)smem;
+
+    const int bid = xcd_remap(blockIdx.x, nblocks);
+    const int b = bid / tiles_per_clip;
+    const int q0 = (bid % tiles_per_clip) * KS_TQ;
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int myq = q0 + wave * 32 + l31;
+    const float iq = den[(size_t)b * N + myq];
+    const float dqi = (sq[(size_t)b * N + myq] + KS_SHIFT) * iq;
+    const float2 *csb = cs + (size_t)b * N;
+
+    const int nch = C / KS_KC, nblk = N / KS_TR, T = nblk * nch;
+
+    // ---- DMA: waves 0, 1 move the candidate tile of every chunk (channel rows 0-15 / 16-31), waves 2, 3 the query tile;
+    // instruction i covers 4 channel rows (256 B each); LDS slot s' = lane & 15 of row lane >> 4 holds source segment
+    // (s' >> 2) ^ (row & 3), piece s' & 3
+    const int pl = wave >> 1, hw = wave & 1;
+    const int rowl = lane >> 4, sl = lane & 15;
+    const int scol = (((sl >> 2) ^ (rowl & 3)) * 4 + (sl & 3)) * 8;
+    const unsigned short *src0 = x + (size_t)b * sb + (size_t)(hw * 16 + rowl) * sc + scol + (pl ? q0 : 0);
+    auto dma_chunk = [&](int t) {
+        const int blk = t / nch, ch = t - blk * nch;
+        const unsigned short *s = src0 + (size_t)(ch * KS_KC) * sc + (pl ? 0 : blk * KS_TR);
+        const unsigned st = lds0 + (t % KR_NS) * KR_STAGE + pl * KS_PLANE + hw * 4096;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gm_dma16(s + (size_t)(4 * i) * sc, st + i * 1024);
+        // the block's candidate table: 128 x (cj, sq_j) = 1 KiB, by DMA as well (see knn_topk_split_kernel)
+        if (ch == 0 && wave == 0)
+            gm_dma16(csb + blk * KS_TR + lane * 2, lds0 + KR_NS * KR_STAGE + (blk % KR_NT) * (KS_TR * 8));
+    };
+
+    int foff[4];
+    {
+        const int i = lane & 15, grp = (lane >> 4) & 1;
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const int bytecol = (tt * 32 + 16 * grp + 4 * (i & 3)) * 2;
+            const int seg = (bytecol >> 6) ^ (i >> 2);
+            foff[tt] = (8 * half + (i >> 2)) * 256 + seg * 64 + (bytecol & 63);
+        }
+    }
+    int qoff;
+    {
+        const int i = lane & 15, grp = (lane >> 4) & 1;
+        const int bytecol = (wave * 32 + 16 * grp + 4 * (i & 3)) * 2;
+        const int seg = (bytecol >> 6) ^ (i >> 2);
+        qoff = (8 * half + (i >> 2)) * 256 + seg * 64 + (bytecol & 63);
+    }
+    auto frag = [&](const unsigned char *p, int off) -> gm_bf16x8 {
+        const gm_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((gm_s16x4 __attribute__((address_space(3))) *)(p + off));
+        const gm_s16x4 hi =
+            __builtin_amdgcn_ds_read_tr16_b64_v4i16((gm_s16x4 __attribute__((address_space(3))) *)(p + off + 4 * 256));
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+
+    f32x16 acc[4], prev[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[t][r] = 0.0f; prev[t][r] = 0.0f; }
+    KeyList<K + 1> best;
+    best.init();
+    bool bad = false;
+
+    auto insert = [&](const f32x16 (&a)[4], int e, int tb, unsigned lane_bits) {
+        const int loc_c = (e >> 4) * 32 + ((e & 15) & 3) + 8 * ((e & 15) >> 2);
+        const float2 t = sCS[tb + loc_c + 4 * half];
+        const float d = __builtin_fmaf(a[e >> 4][e & 15], t.x, __builtin_fmaf(t.y, iq, dqi));
+        best.push((__float_as_uint(d) & key_mask) | lane_bits | (unsigned)loc_c);
+    };
+
+#pragma unroll
+    for (int c = 0; c < D; ++c)
+        if (c < T) dma_chunk(c);
+    for (int blk = 0; blk < nblk; ++blk) {
+        const int tb_prev = ((blk + KR_NT - 1) % KR_NT) * KS_TR;
+        const unsigned bits_prev = (unsigned)((blk - 1) * KS_TR);       // wave-uniform: (bits | loc_c) stays in SGPRs
+        for (int ch = 0; ch < nch; ++ch) {
+            const int t = blk * nch + ch;
+            {   // chunk t landed (this wave's pieces; wave 0's table pieces only make its wait stricter), then everybody's
+                const int newer = T - 1 - t;
+                if (newer >= D - 1) gm_wait_vm<(D - 1) * 4>();
+                else if (newer == 1) gm_wait_vm<4>();
+                else gm_wait_vm<0>();
+                __builtin_amdgcn_s_barrier();
+            }
+            if (t + D < T) dma_chunk(t + D);
+            const unsigned char *st = smem + (t % KR_NS) * KR_STAGE;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const gm_bf16x8 qf = frag(st + KS_PLANE, qoff + ks * 16 * 256);
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) {
+                    const gm_bf16x8 af = frag(st, foff[tt] + ks * 16 * 256);
+                    acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, qf, acc[tt], 0, 0, 0);
+                }
+                if (ch == 0 && blk > 0) {
+                    // in batches of 8: hipcc otherwise hoists all 32 table reads (64 registers) over the inserts and spills
+#pragma unroll
+                    for (int e8 = 0; e8 < 32; e8 += 8) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) insert(prev, ks * 32 + e8 + e, tb_prev, bits_prev);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    bad = bad || fabsf(sCS[tb_prev + ks * 64 + lane].x) < KR_TINY;
+                }
+            }
+        }
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            prev[tt] = acc[tt];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tt][r] = 0.0f;
+        }
+    }
+    {
+        const int tb_last = ((nblk - 1) % KR_NT) * KS_TR;
+        const unsigned bits_last = (unsigned)((nblk - 1) * KS_TR);
+#pragma unroll
+        for (int e8 = 0; e8 < 64; e8 += 8) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) insert(prev, e8 + e, tb_last, bits_last);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        bad = bad || fabsf(sCS[tb_last + lane].x) < KR_TINY || fabsf(sCS[tb_last + 64 + lane].x) < KR_TINY;
+    }
+    const bool clip_bad = __any(bad ? 1 : 0) != 0;
+    // index bit 2 (which half-wave's rows) is the same for every candidate a lane saw: set once, here
+#pragma unroll
+    for (int t = 0; t <= K; ++t) best.k[t] |= (unsigned)(4 * half);
+    best.next |= (unsigned)(4 * half);
+    unsigned ok[K + 1], onext = (unsigned)__shfl_xor((int)best.next, 32);
+#pragma unroll
+    for (int t = 0; t <= K; ++t) ok[t] = (unsigned)__shfl_xor((int)best.k[t], 32);
+#pragma unroll
+    for (int t = 0; t <= K; ++t) best.push(ok[t]);
+    best.next = onext < best.next ? onext : best.next;
+    if (half == 0) {
+        const unsigned imask = ~key_mask;
+        const size_t row = (size_t)b * N + myq;
+        I *o = idx + row * K;
+        const float trunc = __uint_as_float(0x3f800000u + imask) - 1.0f;
+        const float band = margin2 * iq;                                       // the keys are den_q times the distances
+        bool certified = !clip_bad;
+#pragma unroll
+        for (int t = 0; t < K; ++t) {
+            const float lo = __uint_as_float(best.k[t] & key_mask), hi = __uint_as_float(best.k[t + 1] & key_mask);
+            certified = certified && (hi - lo * (1.0f + trunc) > band);
+            o[t] = (I)(best.k[t] & imask);
+        }
+        const bool light = !clip_bad && __uint_as_float(best.next & key_mask) -
+                                                __uint_as_float(best.k[K - 1] & key_mask) * (1.0f + trunc) > band;
+        unc_flag[row] = certified ? 0 : (light ? 1 : 2);
+        if (!certified) {
+            atomicAdd(unc_count, 1);
+            if (light) {
+                extra[row] = (int)(best.k[K] & imask);
+                light_list[atomicAdd(unc_count + 1, 1)] = (int)row;
+            }
+        }
+    }
+}
+
 // pass 3a: a LIGHT query -- exact distances to its k + 1 listed candidates only (c-ordered fmaf chains on x / den, the
 // oracle's arithmetic), ranked by (distance, index).  8 lanes per query (lane s < k + 1 takes candidate s).
 template <int K, typename I, typename T>
@@ -323,6 +587,8 @@ __global__ __launch_bounds__(256) void knn_exact_pairs_kernel(const T *__restric
             const T *xb = x + (size_t)b * sb;
             const float dq = den[row], dj = den[(size_t)b * N + j];
             float g = 0.0f;
+            // (32 channels of loads in flight instead of 8 change nothing: 55-100 us per call either way -- every load of a
+            //  lane is its own page, 4 MB apart in the (C, B, N) layout: the address translation, not the data, is waited for)
             for (int c = 0; c < C; c += 8) {                   // C % 32 == 0
                 float vq[8], vj[8];
 #pragma unroll
@@ -352,6 +618,7 @@ __global__ __launch_bounds__(256) void knn_exact_pairs_kernel(const T *__restric
 // takes candidates t, t + 256, ... (ascending, so the strict-< insert keeps the lower index on ties), re-derives the
 // candidate's normalised features as x / den (the division of pass 1), runs the c-ordered fmaf chains of the 16 queries
 // side by side, and the block then takes K rounds of a (distance, index) minimum per query.
+template <int V> struct KsInt { static constexpr int value = V; };
 constexpr int KX_QG = 16;        // uncertified queries per pass over the clip's features
 constexpr int KX_NU = 2;         // candidates per thread and pass (256 threads: column ranges of 512 nodes)
 constexpr int KX_CHUNK = 16384;  // bytes of one staged feature chunk (double buffered)
@@ -384,29 +651,33 @@ __global__ __launch_bounds__(256) void knn_exact_clip_kernel(const T *__restrict
     const int W = N < 256 * KX_NU ? N : 256 * KX_NU;          // columns per range (N % 128 == 0)
     constexpr int VE = 16 / (int)sizeof(T);                    // elements per 16-byte vector
     const int vrow = W / VE, nvec = chc * vrow;                // vectors per row / per chunk
-    for (int g0 = 0; g0 < n; g0 += KX_QG) {
-        const int ng = n - g0 < KX_QG ? n - g0 : KX_QG;
+    // a clip's heavy queries in groups of QG, each group one pass over the clip's features; most clips hold one to four
+    // of them, and the pass is VALU work of (one division + QG fma) per candidate and channel: the narrow group for those
+    auto passes = [&](auto qg) {
+    constexpr int QG = decltype(qg)::value;
+    for (int g0 = 0; g0 < n; g0 += QG) {
+        const int ng = n - g0 < QG ? n - g0 : QG;
         __syncthreads();
         for (int i = tid; i < ng * C; i += 256) {
             const int qi = i / C, c = i - qi * C, q = s_list[g0 + qi];
             sQ[qi * C + c] = __fdiv_rn(ks_ld(xb + (size_t)c * sc + q), denb[q]);
         }
-        float sqq[KX_QG], bd[KX_QG][K];
-        int bi[KX_QG][K];
+        float sqq[QG], bd[QG][K];
+        int bi[QG][K];
 #pragma unroll
-        for (int qi = 0; qi < KX_QG; ++qi) {
+        for (int qi = 0; qi < QG; ++qi) {
             sqq[qi] = qi < ng ? sqb[s_list[g0 + qi]] : 0.0f;
 #pragma unroll
             for (int t = 0; t < K; ++t) { bd[qi][t] = INFINITY; bi[qi][t] = 0x7fffffff; }
         }
         for (int j0 = 0; j0 < N; j0 += W) {                    // candidate column ranges, ascending
-            float g[KX_NU][KX_QG], dj[KX_NU];
+            float g[KX_NU][QG], dj[KX_NU];
 #pragma unroll
             for (int u = 0; u < KX_NU; ++u) {
                 const int j = j0 + tid + 256 * u;
                 dj[u] = (tid + 256 * u < W) ? denb[j] : 1.0f;
 #pragma unroll
-                for (int qi = 0; qi < KX_QG; ++qi) g[u][qi] = 0.0f;
+                for (int qi = 0; qi < QG; ++qi) g[u][qi] = 0.0f;
             }
             // chunks of chc channels x W columns through LDS by LDS-DMA (1 KiB per wave instruction, lane-linear: vector
             // v of the chunk lands at byte 16 v), the next chunk in flight while this one is consumed
@@ -430,15 +701,15 @@ __global__ __launch_bounds__(256) void knn_exact_clip_kernel(const T *__restrict
                 if (ck + 1 < nchunk) dma(ck + 1);
                 for (int cc = 0; cc < chc; ++cc) {
                     const int c = ck * chc + cc;
-                    float a[KX_QG];
+                    float a[QG];
 #pragma unroll
-                    for (int qi = 0; qi < KX_QG; ++qi) a[qi] = sQ[qi * C + c];
+                    for (int qi = 0; qi < QG; ++qi) a[qi] = sQ[qi * C + c];
 #pragma unroll
                     for (int u = 0; u < KX_NU; ++u) {
                         if (tid + 256 * u < W) {
                             const float v = __fdiv_rn(ks_ld(buf + (size_t)cc * W + tid + 256 * u), dj[u]);
 #pragma unroll
-                            for (int qi = 0; qi < KX_QG; ++qi) g[u][qi] = __builtin_fmaf(v, a[qi], g[u][qi]);
+                            for (int qi = 0; qi < QG; ++qi) g[u][qi] = __builtin_fmaf(v, a[qi], g[u][qi]);
                         }
                     }
                 }
@@ -451,7 +722,7 @@ __global__ __launch_bounds__(256) void knn_exact_clip_kernel(const T *__restrict
                 if (tid + 256 * u < W) {
                     const float sqj = sqb[j];
 #pragma unroll
-                    for (int qi = 0; qi < KX_QG; ++qi) {
+                    for (int qi = 0; qi < QG; ++qi) {
                         if (qi < ng) {
                             float v = __builtin_fmaf(-2.0f, g[u][qi], sqq[qi]) + sqj;      // (sq_i + (-2 g)) + sq_j
                             int vi = j;
@@ -472,7 +743,7 @@ __global__ __launch_bounds__(256) void knn_exact_clip_kernel(const T *__restrict
             }
         }
 #pragma unroll
-        for (int qi = 0; qi < KX_QG; ++qi) {
+        for (int qi = 0; qi < QG; ++qi) {
             if (qi < ng) {                                                     // block-uniform
                 I *o = idx + ((size_t)b * N + s_list[g0 + qi]) * K;
 #pragma unroll
@@ -501,6 +772,9 @@ __global__ __launch_bounds__(256) void knn_exact_clip_kernel(const T *__restrict
             }
         }
     }
+    };
+    if (n <= 4) passes(KsInt<4>{});
+    else passes(KsInt<KX_QG>{});
 }
 
 static int ks_index_bits(int N) {
@@ -512,6 +786,7 @@ static float ks_margin(int C) {
     const float e_g = 1.15e-5f + 3.6e-7f * (float)C;
     return 2.0f * e_g + 1.1920929e-7f * (float)C + 1e-6f;
 }
+static float ks_margin_raw(int C) { return 2.0f * (1.7881393e-7f * (float)C + 3.6e-7f) + 2e-6f; }
 static bool ks_supported(int C, int N, int k) {
     return C > 0 && C % KS_KC == 0 && N >= KS_TR && N % KS_TR == 0 && N <= 4096 && k >= 1 && k <= 4 && k <= N &&
            ks_margin(C) < 0.9f * KS_SHIFT;
@@ -520,7 +795,8 @@ static size_t ks_align(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct KsArgs {
     const void *x;
-    bool f32;
+    bool f32, raw;
+    const float2 *cs;
     int64_t sb, sc;
     const unsigned short *xh, *xl;
     const float *sq, *den;
@@ -546,9 +822,16 @@ template <int K, typename I, typename T> static void ks_launch_exact(const KsArg
 }
 template <int K, typename I> static void ks_launch(const KsArgs &a, hipStream_t s) {
     const int tiles = a.N / KS_TQ, nblocks = a.B * tiles;
-    (void)hipFuncSetAttribute((const void *)knn_topk_split_kernel<K, I>, hipFuncAttributeMaxDynamicSharedMemorySize, KS_LDS);
-    hipLaunchKernelGGL((knn_topk_split_kernel<K, I>), dim3(nblocks), dim3(256), KS_LDS, s, a.xh, a.xl, a.sq, (I *)a.idx,
-                       a.count, a.flag, a.extra, a.light, a.C, a.N, tiles, nblocks, a.margin2, a.key_mask);
+    if (a.raw) {
+        (void)hipFuncSetAttribute((const void *)knn_topk_raw_kernel<K, I>, hipFuncAttributeMaxDynamicSharedMemorySize, KR_LDS);
+        hipLaunchKernelGGL((knn_topk_raw_kernel<K, I>), dim3(nblocks), dim3(256), KR_LDS, s, (const unsigned short *)a.x,
+                           a.sb, a.sc, a.sq, a.den, a.cs, (I *)a.idx, a.count, a.flag, a.extra, a.light, a.C, a.N, tiles,
+                           nblocks, a.margin2, a.key_mask);
+    } else {
+        (void)hipFuncSetAttribute((const void *)knn_topk_split_kernel<K, I>, hipFuncAttributeMaxDynamicSharedMemorySize, KS_LDS);
+        hipLaunchKernelGGL((knn_topk_split_kernel<K, I>), dim3(nblocks), dim3(256), KS_LDS, s, a.xh, a.xl, a.sq, (I *)a.idx,
+                           a.count, a.flag, a.extra, a.light, a.C, a.N, tiles, nblocks, a.margin2, a.key_mask);
+    }
     if (a.f32) ks_launch_exact<K, I, float>(a, s);
     else ks_launch_exact<K, I, unsigned short>(a, s);
 }
@@ -571,13 +854,23 @@ extern "C" int grafp_knn_split_supported(int C, int N, int k) { return grafp::ks
 // passes, which cost more than the 128-candidate scan they replace).
 extern "C" int grafp_knn_split_preferred(int C, int N, int k) { return grafp::ks_supported(C, N, k) && C <= 128 ? 1 : 0; }
 
-extern "C" size_t grafp_knn_split_workspace(int B, int C, int N) {
+// ... for inputs of `dtype`: bf16 features take the RAW form (one MFMA per 16 channels, no planes; see knn_topk_raw_kernel),
+// measured at 2048 clip-views against the exact-f32 kernel incl. both normalisation passes (profiles/r03_knn_bench.txt)
+extern "C" int grafp_knn_split_preferred_for(int dtype, int C, int N, int k) {
+    if (dtype != GRAFP_BF16) return grafp_knn_split_preferred(C, N, k);
+    return grafp::ks_supported(C, N, k) && C <= GRAFP_TUNE_INT("GRAFP_KNN_RAW_MAXC", 256) ? 1 : 0;
+}
+
+static size_t ks_workspace(int dtype, int B, int C, int N) {
     using namespace grafp;
     if (B <= 0 || C <= 0 || N <= 0) return 0;
     const size_t e = (size_t)B * C * N;
-    return 2 * ks_align((size_t)B * N * 4) + 2 * ks_align(e * 2) + 256 + ks_align((size_t)B * N) +
-           2 * ks_align((size_t)B * N * 4);
+    // sq, den | planes (f32 inputs) or the candidate table (bf16 inputs) | counters | flags | extra, light
+    const size_t mid = dtype == GRAFP_BF16 ? ks_align((size_t)B * N * 8) : 2 * ks_align(e * 2);
+    return 2 * ks_align((size_t)B * N * 4) + mid + 256 + ks_align((size_t)B * N) + 2 * ks_align((size_t)B * N * 4);
 }
+extern "C" size_t grafp_knn_split_workspace(int B, int C, int N) { return ks_workspace(GRAFP_F32, B, C, N); }
+extern "C" size_t grafp_knn_split_workspace_for(int dtype, int B, int C, int N) { return ks_workspace(dtype, B, C, N); }
 
 extern "C" int grafp_knn_graph_split(const void *x, int dtype, int64_t stride_b, int64_t stride_c, int B, int C, int N,
                                      int k, void *idx, int idx_is_i32, void *ws, size_t ws_bytes, int32_t *n_uncertified,
@@ -588,37 +881,59 @@ extern "C" int grafp_knn_graph_split(const void *x, int dtype, int64_t stride_b,
                   "knn_graph_split: unsupported shape B=%d C=%d N=%d k=%d (C %% 32, N %% 128, N <= 4096, k <= 4)", B, C, N, k);
     GRAFP_REQUIRE(dtype == GRAFP_F32 || dtype == GRAFP_BF16, "knn_graph_split: dtype %d not in {f32, bf16}", dtype);
     GRAFP_REQUIRE((int64_t)B * N < (1ll << 31), "knn_graph_split: too many nodes");
-    const size_t need = grafp_knn_split_workspace(B, C, N);
+    const size_t need = ks_workspace(dtype, B, C, N);
     if (!ws || ws_bytes < need) {
         set_error("knn_graph_split: workspace %zu bytes < required %zu", ws_bytes, need);
         return GRAFP_ERR_WORKSPACE;
     }
     hipStream_t s = (hipStream_t)stream;
+    const bool raw = dtype == GRAFP_BF16;
     const size_t e = (size_t)B * C * N;
     char *p = (char *)ws;
     float *sq = (float *)p;                       p += ks_align((size_t)B * N * 4);
     float *den = (float *)p;                      p += ks_align((size_t)B * N * 4);
-    unsigned short *xh = (unsigned short *)p;     p += ks_align(e * 2);
-    unsigned short *xl = (unsigned short *)p;     p += ks_align(e * 2);
+    unsigned short *xh = nullptr, *xl = nullptr;
+    float2 *cs = nullptr;
+    if (raw) {
+        cs = (float2 *)p;                         p += ks_align((size_t)B * N * 8);
+    } else {
+        xh = (unsigned short *)p;                 p += ks_align(e * 2);
+        xl = (unsigned short *)p;                 p += ks_align(e * 2);
+    }
     int *count = (int *)p;                        p += 256;
     unsigned char *flag = (unsigned char *)p;     p += ks_align((size_t)B * N);
     int *extra = (int *)p;                        p += ks_align((size_t)B * N * 4);
     int *light = (int *)p;
-    GRAFP_REQUIRE((((uintptr_t)xh | (uintptr_t)xl | (uintptr_t)x) & 15) == 0 && (stride_b * (dtype == GRAFP_F32 ? 4 : 2)) % 16 == 0 &&
+    GRAFP_REQUIRE((((uintptr_t)ws | (uintptr_t)x) & 15) == 0 && (stride_b * (dtype == GRAFP_F32 ? 4 : 2)) % 16 == 0 &&
                       (stride_c * (dtype == GRAFP_F32 ? 4 : 2)) % 16 == 0,
                   "knn_graph_split: input rows and workspace must be 16-byte aligned");
-    const dim3 gn((N + 255) / 256, B);
-    if (dtype == GRAFP_F32)
+    if (raw) {
+        // nodes per thread: 16-byte loads while that leaves >= 2^18 threads, narrower ones for the short rows of the
+        // late stages (a thread walks its channels in order -- the oracle's chains -- so nodes are the only parallelism)
+        const int64_t nodes = (int64_t)B * N;
+        const int ve = nodes >= (1 << 21) ? 8 : nodes >= (1 << 20) ? 4 : 2;
+        const int64_t threads = nodes / ve;
+        const dim3 gn((unsigned)((threads + 255) / 256));
+        if (ve == 8)
+            hipLaunchKernelGGL(knn_norms_kernel<8>, gn, dim3(256), 0, s, (const unsigned short *)x, stride_b, stride_c, den,
+                               sq, cs, B, C, N, count);
+        else if (ve == 4)
+            hipLaunchKernelGGL(knn_norms_kernel<4>, gn, dim3(256), 0, s, (const unsigned short *)x, stride_b, stride_c, den,
+                               sq, cs, B, C, N, count);
+        else
+            hipLaunchKernelGGL(knn_norms_kernel<2>, gn, dim3(256), 0, s, (const unsigned short *)x, stride_b, stride_c, den,
+                               sq, cs, B, C, N, count);
+        GRAFP_CHECK_LAUNCH("knn_norms_kernel");
+    } else {
+        const dim3 gn((N + 255) / 256, B);
         hipLaunchKernelGGL(knn_normalize_split_kernel<float>, gn, dim3(256), 0, s, (const float *)x, stride_b, stride_c,
                            den, sq, xh, xl, C, N, count);
-    else
-        hipLaunchKernelGGL(knn_normalize_split_kernel<unsigned short>, gn, dim3(256), 0, s, (const unsigned short *)x,
-                           stride_b, stride_c, den, sq, xh, xl, C, N, count);
-    GRAFP_CHECK_LAUNCH("knn_normalize_split_kernel");
+        GRAFP_CHECK_LAUNCH("knn_normalize_split_kernel");
+    }
     KsArgs a;
-    a.x = x; a.f32 = dtype == GRAFP_F32; a.sb = stride_b; a.sc = stride_c; a.xh = xh; a.xl = xl; a.sq = sq; a.den = den;
+    a.x = x; a.f32 = dtype == GRAFP_F32; a.raw = raw; a.cs = cs; a.sb = stride_b; a.sc = stride_c; a.xh = xh; a.xl = xl; a.sq = sq; a.den = den;
     a.count = count; a.n_unc = (int *)n_uncertified; a.flag = flag; a.extra = extra; a.light = light; a.idx = idx; a.B = B; a.C = C; a.N = N;
-    a.margin2 = 2.0f * ks_margin(C);
+    a.margin2 = 2.0f * (raw ? ks_margin_raw(C) : ks_margin(C));
     a.key_mask = ~((1u << ks_index_bits(N)) - 1u);
     if (idx_is_i32) ks_launch_k<int32_t>(k, a, s);
     else ks_launch_k<int64_t>(k, a, s);

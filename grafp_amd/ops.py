@@ -305,9 +305,10 @@ def knn_graph(x, k, normalize=True, layout="bcn", index_dtype=torch.int64, prefi
     x, B, C, N, sb, sc = _act_view(x.detach(), layout)
     idx = torch.empty((B, N, k), dtype=index_dtype, device=x.device)
     if (prefilter is None and switches.knn_split and normalize and index_dtype in (torch.int32, torch.int64)
-            and lib.grafp_knn_split_preferred(C, N, k)):
+            and lib.grafp_knn_split_preferred_for(_DT[x.dtype], C, N, k)):
         # split-bf16 Gram matrix + certified order, exact recomputation of the near-ties (knn_split.hip): the same
-        # indices bit for bit, ~2x faster than the exact-f32 MFMA kernel below where the library prefers it (C <= 128)
+        # indices bit for bit, ~2x faster than the exact-f32 MFMA kernel below where the library prefers it (f32
+        # inputs: C <= 128; bf16 inputs, whose raw features are exact bf16 operands: every stage)
         knn_graph_split(x, k, layout="raw", index_dtype=index_dtype, _view=(x, B, C, N, sb, sc), _out=idx)
         return idx
     if prefilter is None:
@@ -349,10 +350,10 @@ def knn_graph_split(x, k, layout="bcn", index_dtype=torch.int64, return_uncertif
     if not lib.grafp_knn_split_supported(C, N, k):
         raise ValueError(f"knn_graph_split: unsupported shape C={C} N={N} k={k}")
     idx = _out if _out is not None else torch.empty((B, N, k), dtype=index_dtype, device=x.device)
-    nbytes = lib.grafp_knn_split_workspace(B, C, N)
+    nbytes = lib.grafp_knn_split_workspace_for(_DT[x.dtype], B, C, N)
     ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
     unc = torch.zeros((), dtype=torch.int32, device=x.device) if return_uncertified else None
-    with _timed("knn_topk", (B, C, N, k)):
+    with _timed("knn_split", (B, C, N, k, x.element_size())):
         check(lib.grafp_knn_graph_split(_p(x), _DT[x.dtype], sb, sc, B, C, N, k, _p(idx),
                                         int(idx.dtype == torch.int32), _p(ws), nbytes, _p(unc), _stream()),
               "knn_graph_split")

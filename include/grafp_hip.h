@@ -125,10 +125,16 @@ int grafp_knn_graph_pre(const void *x, int dtype, int64_t stride_b, int64_t stri
  * rigorous error bound of the approximation (near-ties, duplicates) is recomputed with the exact f32 arithmetic of
  * grafp_knn_topk_f32.  x: any (b, c)-strided view with N contiguous, f32 or bf16 (as grafp_knn_normalize_strided);
  * idx int64 or int32 (idx_is_i32); n_uncertified: NULL, or one device int that receives the number of queries that
- * took the exact path (diagnostics). */
+ * took the exact path (diagnostics).
+ * bf16 inputs take the RAW form: a bf16 feature is its own exact bf16 operand, so the Gram matrix of the UN-normalised
+ * features needs one product per 16 channels and no planes, and the normalisation is applied behind the product
+ * (g = G / (den_q den_j)); tighter bound, same certified tiers, same indices.  The _for entries take the input dtype
+ * (the plain ones answer for f32 inputs). */
 int grafp_knn_split_supported(int C, int N, int k);
 int grafp_knn_split_preferred(int C, int N, int k);   /* supported AND measured faster than grafp_knn_topk_f32 (C <= 128) */
+int grafp_knn_split_preferred_for(int dtype, int C, int N, int k);
 size_t grafp_knn_split_workspace(int B, int C, int N);
+size_t grafp_knn_split_workspace_for(int dtype, int B, int C, int N);
 int grafp_knn_graph_split(const void *x, int dtype, int64_t stride_b, int64_t stride_c, int B, int C, int N, int k,
                           void *idx, int idx_is_i32, void *ws, size_t ws_bytes, int32_t *n_uncertified,
                           grafp_stream_t stream);

@@ -137,6 +137,61 @@ def test_knn_graph_split_worst_cases(dev):
     assert np.array_equal(ops.knn_graph(t(z).to(dev), 3).cpu().numpy(), native.knn_graph(z, 3))
 
 
+@pytest.mark.parametrize("C,N,B", [(64, 1024, 3), (128, 512, 3), (256, 256, 4), (512, 128, 4)])
+def test_knn_graph_raw_bf16_equals_f32_path(dev, C, N, B):
+    """bf16 inputs (the training path's activations) take the RAW form of knn_split.hip: the Gram matrix of the
+    un-normalised bf16 features (exact operands: one MFMA per 16 channels, no planes), normalisation behind the product,
+    certified tiers as before.  Against knn_graph.hip on the same bf16 values and the C oracle on their f32 widening:
+    normal features, a tight cluster, exact duplicates, a zero node, k = 1 ... 4, both layouts, both index types."""
+    from grafp_amd import ops
+    from oracle import native
+    x = hash_normalish(f"gpu:knnraw.{C}.{N}", (B, C, N)).astype(np.float32)
+    x[0, :, 40:100] = x[0, :, 40:41] + 1e-2 * hash_normalish(f"gpu:knnraw.c.{C}.{N}", (C, 60))    # a tight cluster
+    x[1, :, 10:50] = x[1, :, 10:11]                                                               # exact duplicates
+    x[2, :, 7] = 0.0                                                                              # a zero node
+    xb = t(x).to(torch.bfloat16).to(dev)
+    xw = xb.float().cpu().numpy()                                      # what the oracle sees: the same bf16 values
+    # the default route takes it up to C = 256 (at C = 512 the exact-f32 kernel ties at 2048 clips and wins below)
+    assert ops.lib.grafp_knn_split_preferred_for(ops._DT[torch.bfloat16], C, N, 3) == (1 if C <= 256 else 0)
+    for k in (3, 1, 2, 4):
+        a = ops.knn_graph(xb, k, prefilter=False)                      # exact-f32 MFMA kernel
+        b, unc = ops.knn_graph_split(xb, k, return_uncertified=True)
+        assert torch.equal(a, b), (k, int((a != b).sum()))
+        assert torch.equal(ops.knn_graph(xb, k), a)                    # the default route
+        if k == 3:
+            assert np.array_equal(b.cpu().numpy(), native.knn_graph(xw, 3))
+            assert 40 <= int(unc) <= 100 + 0.05 * B * N, int(unc)
+    b32 = ops.knn_graph(xb, 3, index_dtype=torch.int32)
+    assert b32.dtype == torch.int32 and torch.equal(b32.to(torch.int64), ops.knn_graph(xb, 3, prefilter=False))
+    xc = xb.permute(1, 0, 2).contiguous()                              # (C, B, N): how the encoder hands them over
+    assert torch.equal(ops.knn_graph(xc, 3, layout="cbn"), ops.knn_graph(xb, 3, prefilter=False))
+    # plain random features: the bound is 3 x tighter than the split form's -- almost everything certifies
+    y = t(hash_normalish(f"gpu:knnraw.r.{C}.{N}", (B, C, N)).astype(np.float32)).to(torch.bfloat16).to(dev)
+    idx, unc = ops.knn_graph_split(y, 3, return_uncertified=True)
+    assert torch.equal(idx, ops.knn_graph(y, 3, prefilter=False))
+    assert np.array_equal(idx.cpu().numpy(), native.knn_graph(y.float().cpu().numpy(), 3))
+    assert int(unc) <= (0.02 if C < 512 else 0.05) * B * N, (int(unc), B * N)
+
+
+def test_knn_graph_raw_bf16_worst_cases(dev):
+    """bf16 inputs: all nodes identical, one-hot features, an all-zero clip, features spread over 50 decades (norms above
+    2^40 send the whole clip through the exact pass: the raw Gram entries could overflow) and 2^-100-sized features."""
+    from grafp_amd import ops
+    from oracle import native
+    B, C, N = 5, 64, 256
+    x = np.ones((B, C, N), dtype=np.float32)
+    x[1] = np.eye(C, dtype=np.float32)[:, np.arange(N) % C]
+    x[2] = 0.0
+    x[3] = hash_normalish("gpu:knnraw.scale", (C, N)).astype(np.float32) * np.logspace(-20, 30, N, dtype=np.float32)[None, :]
+    x[4] = hash_normalish("gpu:knnraw.tiny", (C, N)).astype(np.float32) * np.float32(2.0 ** -100)
+    xb = t(x).to(torch.bfloat16).to(dev)
+    xw = xb.float().cpu().numpy()
+    idx, unc = ops.knn_graph_split(xb, 3, return_uncertified=True)
+    assert np.array_equal(idx.cpu().numpy(), native.knn_graph(xw, 3))
+    assert int(unc) >= 4 * N                                            # clips 0-3 whole; the tiny clip may certify
+    assert torch.equal(ops.knn_graph(xb, 3), ops.knn_graph(xb, 3, prefilter=False))
+
+
 def test_knn_graph_full_batch_properties(dev):
     """BASELINE config-2 size (B=256, stage 0): size-independent properties + a sampled exact check."""
     from grafp_amd import ops

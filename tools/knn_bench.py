@@ -29,6 +29,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--clips", type=int, default=2048)
     ap.add_argument("--model", action="store_true", help="also on the features a random-init encoder feeds its graphs")
+    ap.add_argument("--dtype", default="bf16", choices=("bf16", "f32"),
+                    help="bf16: (C, B, N) bf16 rows as the training path hands them over (RAW form of the certified path); "
+                         "f32: (B, C, N) f32 (split hi/lo planes)")
     args = ap.parse_args()
     dev = "cuda:0"
     depth, tot = (2, 2, 6, 2), [0.0, 0.0]
@@ -54,11 +57,14 @@ def main():
             model(*aug(x_i, x_j))
         ops.knn_graph = orig
     for stage, (C, N) in enumerate(((64, 1024), (128, 512), (256, 256), (512, 128))):
-        x = torch.randn(args.clips, C, N, device=dev)
-        t_f32 = timeit(lambda: ops.knn_graph(x, 3, index_dtype=torch.int32, prefilter=False))
-        t_split = timeit(lambda: ops.knn_graph(x, 3, index_dtype=torch.int32))
-        a = ops.knn_graph(x, 3, index_dtype=torch.int32, prefilter=False)
-        b, unc = ops.knn_graph_split(x, 3, index_dtype=torch.int32, return_uncertified=True)
+        if args.dtype == "bf16":
+            x, lay = torch.randn(C, args.clips, N, device=dev).to(torch.bfloat16), "cbn"
+        else:
+            x, lay = torch.randn(args.clips, C, N, device=dev), "bcn"
+        t_f32 = timeit(lambda: ops.knn_graph(x, 3, layout=lay, index_dtype=torch.int32, prefilter=False))
+        t_split = timeit(lambda: ops.knn_graph_split(x, 3, layout=lay, index_dtype=torch.int32))
+        a = ops.knn_graph(x, 3, layout=lay, index_dtype=torch.int32, prefilter=False)
+        b, unc = ops.knn_graph_split(x, 3, layout=lay, index_dtype=torch.int32, return_uncertified=True)
         fl = 2.0 * N * N * C * args.clips
         tot[0] += t_f32 * depth[stage]
         tot[1] += t_split * depth[stage]
@@ -68,7 +74,7 @@ def main():
         if C in feats:
             xf, layout = feats[C]
             tm_f32 = timeit(lambda: ops.knn_graph(xf, 3, layout=layout, index_dtype=torch.int32, prefilter=False))
-            tm_split = timeit(lambda: ops.knn_graph(xf, 3, layout=layout, index_dtype=torch.int32))
+            tm_split = timeit(lambda: ops.knn_graph_split(xf, 3, layout=layout, index_dtype=torch.int32))
             a = ops.knn_graph(xf, 3, layout=layout, index_dtype=torch.int32, prefilter=False)
             b, unc = ops.knn_graph_split(xf, 3, layout=layout, index_dtype=torch.int32, return_uncertified=True)
             nq = a.shape[0] * a.shape[1]
