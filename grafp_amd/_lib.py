@@ -52,6 +52,9 @@ SIGNATURES = {
     "grafp_mrconv_bwd_strided": (_I, [_P, _I, _L, _L, _P, _P, _L, _L, _I, _I, _I, _I, _P, _P]),
     "grafp_mrconv_fwd_strided_i32": (_I, [_P, _I, _L, _L, _P, _I, _I, _I, _I, _P, _L, _L, _P]),
     "grafp_mrconv_bwd_strided_i32": (_I, [_P, _I, _L, _L, _P, _P, _L, _L, _I, _I, _I, _I, _P, _P]),
+    "grafp_mrconv_arg_supported": (_I, [_I, _L, _L, _L, _L, _I, _I]),
+    "grafp_mrconv_fwd_arg": (_I, [_P, _I, _L, _L, _P, _I, _I, _I, _I, _I, _P, _L, _L, _P, _P]),
+    "grafp_mrconv_bwd_arg": (_I, [_P, _I, _P, _I, _P, _L, _L, _I, _I, _I, _I, _P, _L, _L, _P]),
     "grafp_stride2_taps_fwd": (_I, [_P, _I, _L, _I, _P, _P]),
     "grafp_stride2_taps_bwd": (_I, [_P, _I, _L, _I, _P, _P]),
     "grafp_bn_workspace": (_Z, [_I, _L]),

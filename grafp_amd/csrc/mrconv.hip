@@ -44,9 +44,10 @@ __device__ __forceinline__ void mr_ld4(const unsigned short *p, float (&v)[4]) {
     v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
 }
 __device__ __forceinline__ unsigned mr_pack(float lo, float hi) {
-    unsigned short a, b;
-    mr_st(&a, lo); mr_st(&b, hi);
-    return (unsigned)a | ((unsigned)b << 16);
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    const f2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, b2));      // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
 }
 // (outputs are streamed with the non-temporal hint: +35-65 % on a plain copy of tensors this size, tools/microbench/copy_bench.hip)
 __device__ __forceinline__ void mr_st4(float *p, const float (&v)[4]) {
@@ -58,6 +59,38 @@ __device__ __forceinline__ void mr_st4(unsigned short *p, const float (&v)[4]) {
     typedef unsigned u2 __attribute__((ext_vector_type(2)));
     const u2 t = {mr_pack(v[0], v[1]), mr_pack(v[2], v[3])};
     __builtin_nontemporal_store(t, reinterpret_cast<u2 *>(p));
+}
+
+// The backward scatter accumulates in 64-bit FIXED POINT with integer LDS atomics (ds_add_f32 runs at 0.33 lane-ops per
+// clock per CU on gfx950, ds_add_u64 at 10: tools/microbench/lds_atomic_bench.hip; and the sum no longer depends on the
+// order of the atomics: the gradient is deterministic).  Per slab the scale is 2^(39 - e), m = max |addend| < 2^e: an
+// addend becomes the integer v = rint(g scale), |v| < 2^39, carried as TWO signed 32-bit fields of one 64-bit word,
+// v = hi 2^20 + lo (|lo| < 2^20, |hi| < 2^19): a node receives at most N <= 2048 addends, so neither field's sum leaves
+// its 31 bits, the 64-bit add keeps the borrows right, and building / reading the word costs 9 + 7 VALU instructions
+// instead of the ~35 of the f32 <-> i64 conversions (both kernels were VALU-bound on them: 60 VALU instructions per
+// element, 300 us per call where the bytes take 130).
+__device__ __forceinline__ unsigned long long mr_fix_encode(float g, float scale) {
+    const float v = __builtin_rintf(g * scale);
+    const float hf = __builtin_truncf(v * 9.5367431640625e-7f);                 // 2^-20
+    const float lf = __builtin_fmaf(hf, -1048576.0f, v);                        // exact
+    const int hi = (int)hf, lo = (int)lf;
+    return ((unsigned long long)(unsigned)(hi + (lo >> 31)) << 32) | (unsigned long long)(unsigned)lo;
+}
+__device__ __forceinline__ float mr_fix_decode(unsigned long long a) {
+    const int lo = (int)(unsigned)a;
+    const int hi = (int)(unsigned)(a >> 32) - (lo >> 31);
+    return (float)__builtin_fma((double)hi, 1048576.0, (double)lo);             // the sum exactly, rounded once
+}
+// scale of a slab from the largest |addend| bits (integer maximum of the sign-stripped patterns: NaN / inf sort last)
+__device__ __forceinline__ void mr_fix_scale(unsigned mbits, bool &poisoned, float &scale, float &inv_scale) {
+    poisoned = mbits >= 0x7f800000u;
+    const float m = __uint_as_float(mbits);
+    int ex = 0;
+    (void)frexpf(m, &ex);                                     // m < 2^ex
+    int sh = mbits ? 39 - ex : 0;
+    sh = sh > 100 ? 100 : sh;
+    scale = ldexpf(1.0f, sh);
+    inv_scale = ldexpf(1.0f, -sh);
 }
 
 // Activations are addressed as base + b*sb + c*sc + n (N contiguous): (B,C,N) has sb = C*N, sc = N; the
@@ -134,11 +167,13 @@ __global__ __launch_bounds__(MR_THREADS) void mrconv_fwd_kernel(const T *__restr
 constexpr int MRP_ITEMS = 4;                      // 4-element pieces per thread per slab: slab = 4096 elements
 constexpr int MRP_SLAB = MRP_ITEMS * MR_THREADS * 4;
 
-template <typename T, typename I>
+// WK: also write which neighbour won (first maximum, the rule of the backward pass) -- 2 bits per element, the four
+// elements of a piece in one byte of arg (B, C, N / 4); K <= 4.  The backward pass then needs neither x nor the gather.
+template <typename T, typename I, bool WK>
 __global__ __launch_bounds__(MR_THREADS) void mrconv_fwd_p_kernel(const T *__restrict__ x, int64_t x_sb, int64_t x_sc,
                                                                   const I *__restrict__ idx, T *__restrict__ out,
                                                                   int64_t o_sb, int64_t o_sc, int C, int N, int K,
-                                                                  int CC) {
+                                                                  int CC, unsigned char *__restrict__ arg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = blockIdx.y, tid = threadIdx.x;
     float *rows = reinterpret_cast<float *>(smem);                 // [CC*N] (<= MRP_SLAB floats)
@@ -157,47 +192,65 @@ __global__ __launch_bounds__(MR_THREADS) void mrconv_fwd_p_kernel(const T *__res
             MR_NEXT(4, N, c, n);
         }
     }
-    float pv[MRP_ITEMS][4];
-    auto fetch = [&](int slab) {
+    // TWO slabs in flight per workgroup (register sets 0 / 1): with one, 5 workgroups x 8 KB per CU = 10 MB on the whole
+    // chip, and bytes in flight / HBM latency (~3.5 us under load) is what the kernel ran at (3.5 TB/s)
+    float pv[2][MRP_ITEMS][4];
+    auto fetch = [&](int par, int slab) {
         const int c0 = slab * CC, cc = min(CC, C - c0);
 #pragma unroll
         for (int it = 0; it < MRP_ITEMS; ++it)
-            if (pc[it] < cc) mr_ld4(xb + (size_t)(c0 + pc[it]) * x_sc + pn[it], pv[it]);
+            if (pc[it] < cc) mr_ld4(xb + (size_t)(c0 + pc[it]) * x_sc + pn[it], pv[par][it]);
     };
     int slab = blockIdx.x;
-    if (slab < nslab) fetch(slab);
+    const int G = gridDim.x;
+    if (slab < nslab) fetch(0, slab);
+    if (slab + G < nslab) fetch(1, slab + G);
     stage_idx<I>(sidx, idx + (size_t)b * N * K, N, K, tid);
-    for (; slab < nslab; slab += gridDim.x) {
-        const int c0 = slab * CC, cc = min(CC, C - c0);
-        __syncthreads();                       // previous slab fully consumed (and sidx staged, first time round)
+    while (slab < nslab) {
 #pragma unroll
-        for (int it = 0; it < MRP_ITEMS; ++it)
-            if (pc[it] < cc) {
+        for (int par = 0; par < 2; ++par) {
+            if (slab < nslab) {                    // workgroup-uniform
+                const int c0 = slab * CC, cc = min(CC, C - c0);
+                __syncthreads();                   // previous slab fully consumed (and sidx staged, first time round)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) rows[pc[it] * N + pn[it] + e] = pv[it][e];
-            }
-        __syncthreads();
-        float xi[MRP_ITEMS][4];
+                for (int it = 0; it < MRP_ITEMS; ++it)
+                    if (pc[it] < cc)                   // one 16-byte LDS write per piece (N % 4 == 0: aligned)
+                        *reinterpret_cast<float4 *>(rows + pc[it] * N + pn[it]) =
+                            make_float4(pv[par][it][0], pv[par][it][1], pv[par][it][2], pv[par][it][3]);
+                __syncthreads();
+                float xi[MRP_ITEMS][4];
 #pragma unroll
-        for (int it = 0; it < MRP_ITEMS; ++it)
+                for (int it = 0; it < MRP_ITEMS; ++it)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) xi[it][e] = pv[it][e];
-        if (slab + gridDim.x < nslab) fetch(slab + gridDim.x);      // next slab in flight during the gather
+                    for (int e = 0; e < 4; ++e) xi[it][e] = pv[par][it][e];
+                if (slab + 2 * G < nslab) fetch(par, slab + 2 * G);
 #pragma unroll
-        for (int it = 0; it < MRP_ITEMS; ++it) {
-            if (pc[it] < cc) {
-                const float *row = rows + pc[it] * N;
-                float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-                for (int k = 0; k < K; ++k) {
-                    const int4 j4 = *reinterpret_cast<const int4 *>(sidx + k * N + pn[it]);
-                    m[0] = fmaxf(m[0], row[j4.x] - xi[it][0]);
-                    m[1] = fmaxf(m[1], row[j4.y] - xi[it][1]);
-                    m[2] = fmaxf(m[2], row[j4.z] - xi[it][2]);
-                    m[3] = fmaxf(m[3], row[j4.w] - xi[it][3]);
+                for (int it = 0; it < MRP_ITEMS; ++it) {
+                    if (pc[it] < cc) {
+                        const float *row = rows + pc[it] * N;
+                        float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                        float best[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                        unsigned bk = 0;
+                        for (int k = 0; k < K; ++k) {
+                            const int4 j4 = *reinterpret_cast<const int4 *>(sidx + k * N + pn[it]);
+                            const float v[4] = {row[j4.x] - xi[it][0], row[j4.y] - xi[it][1], row[j4.z] - xi[it][2],
+                                                row[j4.w] - xi[it][3]};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                m[e] = fmaxf(m[e], v[e]);
+                                if (WK && (k == 0 || v[e] > best[e])) {  // mrconv_bwd's routing rule, comparison for comparison
+                                    best[e] = v[e];
+                                    bk = (bk & ~(3u << (2 * e))) | ((unsigned)k << (2 * e));
+                                }
+                            }
+                        }
+                        if (WK) arg[((size_t)b * C + c0 + pc[it]) * (N / 4) + pn[it] / 4] = (unsigned char)bk;
+                        T *o = ob + (size_t)(2 * (c0 + pc[it])) * o_sc + pn[it];
+                        mr_st4(o, xi[it]);
+                        mr_st4(o + o_sc, m);
+                    }
                 }
-                T *o = ob + (size_t)(2 * (c0 + pc[it])) * o_sc + pn[it];
-                mr_st4(o, xi[it]);
-                mr_st4(o + o_sc, m);
+                slab += G;
             }
         }
     }
@@ -214,7 +267,7 @@ __global__ __launch_bounds__(MR_THREADS) void mrconv_bwd_kernel(const T *__restr
                                                                 const T *__restrict__ gout, int64_t g_sb, int64_t g_sc,
                                                                 T *__restrict__ dx, int C, int N, int K, int CC) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ float s_max[MR_THREADS / 64];
+    __shared__ unsigned s_max[MR_THREADS / 64];
     const int b = blockIdx.y, c0 = blockIdx.x * CC, tid = threadIdx.x;
     const int cc = min(CC, C - c0);
     // 64-bit fixed-point scatter accumulator + integer LDS atomics (see mrconv_bwd_p_kernel): deterministic, and
@@ -227,7 +280,7 @@ __global__ __launch_bounds__(MR_THREADS) void mrconv_bwd_kernel(const T *__restr
     const T *xb = x + (size_t)b * x_sb + (size_t)c0 * x_sc;
     const T *gb = gout + (size_t)b * g_sb + (size_t)(2 * c0) * g_sc;
     float godd[BWD_ITEMS][4];
-    float m = 0.0f;
+    unsigned m = 0;
     {   // stage x; base <- g_even - g_odd
         MR_WALK(V, tid, N, c, n);
 #pragma unroll
@@ -248,25 +301,21 @@ __global__ __launch_bounds__(MR_THREADS) void mrconv_bwd_kernel(const T *__restr
                     rows[c * N + n + e] = v[e];
                     acc[c * N + n + e] = 0;
                     base[c * N + n + e] = ge[e] - godd[it][e];
-                    m = fmaxf(m, fabsf(godd[it][e]));
-                    if (!(fabsf(godd[it][e]) <= 3.0e38f)) m = INFINITY;
+                    m = max(m, __float_as_uint(godd[it][e]) & 0x7fffffffu);
                 }
             }
             MR_NEXT(V, N, c, n);
         }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
     if ((tid & 63) == 0) s_max[tid >> 6] = m;
     stage_idx<I>(sidx, idx + (size_t)b * N * K, N, K, tid);
     __syncthreads();
-    m = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
-    const bool poisoned = !(m <= 3.0e38f);
-    int ex = 0;
-    (void)frexpf(m, &ex);
-    int sh = m > 0.0f ? 40 - ex : 0;
-    sh = sh > 100 ? 100 : sh;
-    const float scale = ldexpf(1.0f, sh), inv_scale = ldexpf(1.0f, -sh);
+    m = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+    bool poisoned;
+    float scale, inv_scale;
+    mr_fix_scale(m, poisoned, scale, inv_scale);
     if (!poisoned) {   // route g_odd[c][m] to the arg-max neighbour of m (first maximum)
         MR_WALK(V, tid, N, c, n);
 #pragma unroll
@@ -283,8 +332,7 @@ __global__ __launch_bounds__(MR_THREADS) void mrconv_bwd_kernel(const T *__restr
                         const float v = row[j] - xi;
                         if (v > best) { best = v; bj = j; }
                     }
-                    atomicAdd(reinterpret_cast<unsigned long long *>(&acc[c * N + bj]),
-                              (unsigned long long)__float2ll_rn(godd[it][e] * scale));
+                    atomicAdd(reinterpret_cast<unsigned long long *>(&acc[c * N + bj]), mr_fix_encode(godd[it][e], scale));
                 }
             }
             MR_NEXT(V, N, c, n);
@@ -298,10 +346,11 @@ __global__ __launch_bounds__(MR_THREADS) void mrconv_bwd_kernel(const T *__restr
             float v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                v[e] = poisoned ? NAN : base[c * N + n + e] + __ll2float_rn(acc[c * N + n + e]) * inv_scale;
+                v[e] = poisoned ? NAN : base[c * N + n + e] + mr_fix_decode((unsigned long long)acc[c * N + n + e]) * inv_scale;
             mr_st4(db + (size_t)c * x_sc + n, v);
         } else {
-            mr_st(db + (size_t)c * x_sc + n, poisoned ? NAN : base[c * N + n] + __ll2float_rn(acc[c * N + n]) * inv_scale);
+            mr_st(db + (size_t)c * x_sc + n,
+                  poisoned ? NAN : base[c * N + n] + mr_fix_decode((unsigned long long)acc[c * N + n]) * inv_scale);
         }
         MR_NEXT(V, N, c, n);
     }
@@ -319,14 +368,8 @@ __global__ __launch_bounds__(MR_THREADS) void mrconv_bwd_p_kernel(const T *__res
                                                                   int64_t g_sc, T *__restrict__ dx, int C, int N, int K,
                                                                   int CC) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ float s_max[MR_THREADS / 64];
+    __shared__ unsigned s_max[MR_THREADS / 64];
     const int b = blockIdx.y, tid = threadIdx.x;
-    // The scatter accumulates in 64-bit FIXED POINT with integer LDS atomics: ds_add_f32 runs at 0.33 lane-ops per
-    // clock per CU on gfx950, ds_add_u64 at 10 (measured, tools/microbench/lds_atomic_bench.hip) -- the float atomics were
-    // ~160 us of this kernel's 215.  Per slab the scale is 2^(40 - e), e = exponent of the slab's largest |g_odd|:
-    // every addend is exact to 2^-40 of that maximum (bf16 and all but denormal-range f32 addends are exact), a node
-    // receives at most N <= 2048 addends (< 2^52), and the sum no longer depends on the order of the atomics: the
-    // gradient is deterministic.
     long long *acc = reinterpret_cast<long long *>(smem);          // [CC*N] fixed-point scatter accumulator
     float *rows = reinterpret_cast<float *>(acc + MRB_SLAB);       // [CC*N] x
     int *sidx = reinterpret_cast<int *>(rows + MRB_SLAB);          // [K][N]
@@ -363,7 +406,7 @@ __global__ __launch_bounds__(MR_THREADS) void mrconv_bwd_p_kernel(const T *__res
         const int c0 = slab * CC, cc = min(CC, C - c0);
         __syncthreads();                       // previous slab written out (and sidx staged, first time round)
         float xi[MRB_ITEMS][4], godd[MRB_ITEMS][4], base[MRB_ITEMS][4];
-        float m = 0.0f;
+        unsigned m = 0;
 #pragma unroll
         for (int it = 0; it < MRB_ITEMS; ++it)
             if (pc[it] < cc) {
@@ -374,22 +417,18 @@ __global__ __launch_bounds__(MR_THREADS) void mrconv_bwd_p_kernel(const T *__res
                     base[it][e] = pe[it][e] - po[it][e];       // identity branch minus the centre terms
                     xi[it][e] = pv[it][e];
                     godd[it][e] = po[it][e];
-                    m = fmaxf(m, fabsf(po[it][e]));            // (fmaxf drops NaNs: they are caught below)
-                    if (!(fabsf(po[it][e]) <= 3.0e38f)) m = INFINITY;
+                    m = max(m, __float_as_uint(po[it][e]) & 0x7fffffffu);
                 }
             }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
         if ((tid & 63) == 0) s_max[tid >> 6] = m;
         __syncthreads();
         if (slab + gridDim.x < nslab) fetch(slab + gridDim.x);
-        m = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
-        const bool poisoned = !(m <= 3.0e38f);                  // a non-finite gradient: the slab's output is NaN
-        int ex = 0;
-        (void)frexpf(m, &ex);                                   // m < 2^ex
-        int sh = m > 0.0f ? 40 - ex : 0;
-        sh = sh > 100 ? 100 : sh;
-        const float scale = ldexpf(1.0f, sh), inv_scale = ldexpf(1.0f, -sh);
+        m = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+        bool poisoned;                                          // a non-finite gradient: the slab's output is NaN
+        float scale, inv_scale;
+        mr_fix_scale(m, poisoned, scale, inv_scale);
         // route g_odd[c][m] to the arg-max neighbour of m (first maximum)
 #pragma unroll
         for (int it = 0; it < MRB_ITEMS; ++it) {
@@ -410,7 +449,7 @@ __global__ __launch_bounds__(MR_THREADS) void mrconv_bwd_p_kernel(const T *__res
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         atomicAdd(reinterpret_cast<unsigned long long *>(&acc[pc[it] * N + bj[e]]),
-                                  (unsigned long long)__float2ll_rn(godd[it][e] * scale));
+                                  mr_fix_encode(godd[it][e], scale));
                 }
             }
         }
@@ -421,9 +460,142 @@ __global__ __launch_bounds__(MR_THREADS) void mrconv_bwd_p_kernel(const T *__res
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    v[e] = poisoned ? NAN : base[it][e] + __ll2float_rn(acc[pc[it] * N + pn[it] + e]) * inv_scale;
+                    v[e] = poisoned ? NAN : base[it][e] + mr_fix_decode((unsigned long long)acc[pc[it] * N + pn[it] + e]) * inv_scale;
                 mr_st4(db + (size_t)(c0 + pc[it]) * x_sc + pn[it], v);
             }
+    }
+}
+
+// Backward from the recorded arg-max (mrconv_fwd_p_kernel<WK>): no x, no gather.  Per element: one byte-quarter, one
+// fixed-point LDS atomic.  LDS: i64 accumulator slab | edges [K][N].  A thread owns 4 CONSECUTIVE elements, so every
+// per-element LDS access of a wave strides 16 or 32 bytes per lane (PMC, first version: 70 % of the LDS-active cycles
+// were bank conflicts, the LDS busy 60 % of the kernel): the accumulator is zeroed and read back as 16-byte vectors and
+// the K edges of the thread's four nodes come as K 16-byte reads, selected in registers.
+template <typename T, typename I>
+__global__ __launch_bounds__(MR_THREADS) void mrconv_bwd_a_kernel(const unsigned char *__restrict__ arg,
+                                                                  const I *__restrict__ idx,
+                                                                  const T *__restrict__ gout, int64_t g_sb,
+                                                                  int64_t g_sc, T *__restrict__ dx, int64_t d_sb,
+                                                                  int64_t d_sc, int C, int N, int K, int CC) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ unsigned s_max[MR_THREADS / 64];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    unsigned long long *acc = reinterpret_cast<unsigned long long *>(smem);     // [CC*N] fixed-point scatter accumulator
+    int *sidx = reinterpret_cast<int *>(acc + MRB_SLAB);                         // [K][N]
+    const int nslab = (C + CC - 1) / CC;
+    // this thread's pieces inside a slab: element offset pc * N + pn, node pn
+    int off[MRB_ITEMS], pn[MRB_ITEMS], pc[MRB_ITEMS];
+    {
+        MR_WALK(4, tid, N, c, n);
+#pragma unroll
+        for (int it = 0; it < MRB_ITEMS; ++it) {
+            pc[it] = c;
+            pn[it] = n;
+            off[it] = c * N + n;
+            MR_NEXT(4, N, c, n);
+        }
+    }
+    // running pointers of the pieces: slab s -> s + gridDim.x moves them by a constant
+    const T *ge_p[MRB_ITEMS];
+    T *dx_p[MRB_ITEMS];
+    const unsigned char *ar_p[MRB_ITEMS];
+    const int64_t cstep = (int64_t)gridDim.x * CC;
+#pragma unroll
+    for (int it = 0; it < MRB_ITEMS; ++it) {
+        const int64_t c = (int64_t)blockIdx.x * CC + pc[it];
+        ge_p[it] = gout + (size_t)b * g_sb + (size_t)(2 * c) * g_sc + pn[it];
+        dx_p[it] = dx + (size_t)b * d_sb + (size_t)c * d_sc + pn[it];
+        ar_p[it] = arg + ((size_t)b * C + c) * (N / 4) + pn[it] / 4;
+    }
+    const int64_t ge_step = 2 * cstep * g_sc, dx_step = cstep * d_sc, ar_step = cstep * (N / 4);
+    float pe[2][MRB_ITEMS][4], po[2][MRB_ITEMS][4];                // g_even, g_odd of the TWO slabs in flight
+    unsigned pa[2][MRB_ITEMS];
+    auto fetch = [&](int par, int slab) {                          // slabs are fetched in order, each G after the last
+        const int cc = min(CC, C - slab * CC);
+#pragma unroll
+        for (int it = 0; it < MRB_ITEMS; ++it) {
+            if (pc[it] < cc) {
+                mr_ld4(ge_p[it], pe[par][it]);
+                mr_ld4(ge_p[it] + g_sc, po[par][it]);
+                pa[par][it] = *ar_p[it];
+            }
+            ge_p[it] += ge_step;
+            ar_p[it] += ar_step;
+        }
+    };
+    int slab = blockIdx.x;
+    const int G = gridDim.x;
+    if (slab < nslab) fetch(0, slab);
+    if (slab + G < nslab) fetch(1, slab + G);
+    stage_idx<I>(sidx, idx + (size_t)b * N * K, N, K, tid);
+    while (slab < nslab) {
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {
+            if (slab < nslab) {                    // workgroup-uniform
+                const int cc = min(CC, C - slab * CC);
+                __syncthreads();                   // previous slab written out (and the edges staged, first time round)
+                float godd[MRB_ITEMS][4], base[MRB_ITEMS][4];
+                unsigned ak[MRB_ITEMS];
+                unsigned m = 0;
+#pragma unroll
+                for (int it = 0; it < MRB_ITEMS; ++it)
+                    if (pc[it] < cc) {
+                        ak[it] = pa[par][it];
+                        *reinterpret_cast<uint4 *>(acc + off[it]) = make_uint4(0, 0, 0, 0);
+                        *reinterpret_cast<uint4 *>(acc + off[it] + 2) = make_uint4(0, 0, 0, 0);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            base[it][e] = pe[par][it][e] - po[par][it][e];   // identity branch minus the centre terms
+                            godd[it][e] = po[par][it][e];
+                            m = max(m, __float_as_uint(po[par][it][e]) & 0x7fffffffu);
+                        }
+                    }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+                if ((tid & 63) == 0) s_max[tid >> 6] = m;
+                __syncthreads();
+                if (slab + 2 * G < nslab) fetch(par, slab + 2 * G);
+                m = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+                bool poisoned;
+                float scale, inv_scale;
+                mr_fix_scale(m, poisoned, scale, inv_scale);
+                if (!poisoned) {
+#pragma unroll
+                    for (int it = 0; it < MRB_ITEMS; ++it)
+                        if (pc[it] < cc) {
+                            unsigned long long *arow = acc + (off[it] - pn[it]);
+                            // the winner's edge of each of the 4 nodes: K vector reads, selected in registers
+                            int bj[4] = {0, 0, 0, 0};
+                            for (int k = 0; k < K; ++k) {
+                                const int4 j4 = *reinterpret_cast<const int4 *>(sidx + k * N + pn[it]);
+                                const int jj[4] = {j4.x, j4.y, j4.z, j4.w};
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) bj[e] = ((ak[it] >> (2 * e)) & 3u) == (unsigned)k ? jj[e] : bj[e];
+                            }
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) atomicAdd(arow + bj[e], mr_fix_encode(godd[it][e], scale));
+                        }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int it = 0; it < MRB_ITEMS; ++it) {
+                    if (pc[it] < cc) {
+                        float v[4];
+                        const uint4 a01 = *reinterpret_cast<const uint4 *>(acc + off[it]);
+                        const uint4 a23 = *reinterpret_cast<const uint4 *>(acc + off[it] + 2);
+                        const unsigned long long a[4] = {((unsigned long long)a01.y << 32) | a01.x,
+                                                         ((unsigned long long)a01.w << 32) | a01.z,
+                                                         ((unsigned long long)a23.y << 32) | a23.x,
+                                                         ((unsigned long long)a23.w << 32) | a23.z};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = poisoned ? NAN : base[it][e] + mr_fix_decode(a[e]) * inv_scale;
+                        mr_st4(dx_p[it], v);
+                    }
+                    dx_p[it] += dx_step;
+                }
+                slab += G;
+            }
+        }
     }
 }
 
@@ -436,8 +608,17 @@ static int pick_cc(int C, int N, int target_elems) {
 
 }  // namespace grafp
 
+// the shapes whose forward can record the arg-max and whose backward can run from it (pointer alignment aside)
+static bool mrconv_arg_shape_ok(int dtype, int64_t x_sb, int64_t x_sc, int64_t o_sb, int64_t o_sc, int N, int K) {
+    using namespace grafp;
+    return (dtype == GRAFP_F32 || dtype == GRAFP_BF16) && N > 0 && K >= 1 && K <= 4 && N % 4 == 0 && x_sb % 4 == 0 &&
+           x_sc % 4 == 0 && o_sb % 4 == 0 && o_sc % 4 == 0 && N <= MRB_SLAB && N <= MRP_SLAB &&
+           ((size_t)MRP_SLAB + (size_t)K * N) * 4 <= 160 * 1024;
+}
+
 static int mrconv_fwd_impl(const void *x, int dtype, int64_t x_sb, int64_t x_sc, const void *idx, int idx32, int B,
-                           int C, int N, int K, void *out, int64_t o_sb, int64_t o_sc, grafp_stream_t stream) {
+                           int C, int N, int K, void *out, int64_t o_sb, int64_t o_sc, grafp_stream_t stream,
+                           unsigned char *arg = nullptr) {
     using namespace grafp;
     GRAFP_REQUIRE(x && idx && out, "mrconv_fwd: null pointer");
     GRAFP_REQUIRE(B > 0 && C > 0 && N > 0 && K > 0, "mrconv_fwd: bad shape B=%d C=%d N=%d K=%d", B, C, N, K);
@@ -461,18 +642,22 @@ static int mrconv_fwd_impl(const void *x, int dtype, int64_t x_sb, int64_t x_sc,
         const size_t ldsp = ((size_t)MRP_SLAB + (size_t)K * N) * 4;
         if (ldsp <= 160 * 1024) {
             const dim3 gridp(per_clip, B);
-#define MR_FWDP(T, I)                                                                                                  \
-    (void)hipFuncSetAttribute((const void *)mrconv_fwd_p_kernel<T, I>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
+#define MR_FWDP_W(T, I, WK)                                                                                            \
+    (void)hipFuncSetAttribute((const void *)mrconv_fwd_p_kernel<T, I, WK>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                               (int)ldsp);                                                                              \
-    hipLaunchKernelGGL((mrconv_fwd_p_kernel<T, I>), gridp, dim3(MR_THREADS), ldsp, (hipStream_t)stream, (const T *)x,  \
-                       x_sb, x_sc, (const I *)idx, (T *)out, o_sb, o_sc, C, N, K, ccp)
+    hipLaunchKernelGGL((mrconv_fwd_p_kernel<T, I, WK>), gridp, dim3(MR_THREADS), ldsp, (hipStream_t)stream,            \
+                       (const T *)x, x_sb, x_sc, (const I *)idx, (T *)out, o_sb, o_sc, C, N, K, ccp, arg)
+#define MR_FWDP(T, I)                                                                                                  \
+    if (arg) { MR_FWDP_W(T, I, true); } else { MR_FWDP_W(T, I, false); }
             if (dtype == GRAFP_F32) { if (idx32) { MR_FWDP(float, int32_t); } else { MR_FWDP(float, int64_t); } }
             else { if (idx32) { MR_FWDP(unsigned short, int32_t); } else { MR_FWDP(unsigned short, int64_t); } }
 #undef MR_FWDP
+#undef MR_FWDP_W
             GRAFP_CHECK_LAUNCH("mrconv_fwd_p_kernel");
             return GRAFP_OK;
         }
     }
+    GRAFP_REQUIRE(!arg, "mrconv_fwd_arg: shape / alignment outside grafp_mrconv_arg_supported");
 #define MR_FWD_I(T, V, I)                                                                                              \
     (void)hipFuncSetAttribute((const void *)mrconv_fwd_kernel<T, V, I>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
                               (int)lds);                                                                               \
@@ -569,6 +754,45 @@ extern "C" int grafp_mrconv_bwd_strided_i32(const void *x, int dtype, int64_t x_
                                             const void *grad_out, int64_t g_sb, int64_t g_sc, int B, int C, int N,
                                             int K, void *dx, grafp_stream_t stream) {
     return mrconv_bwd_impl(x, dtype, x_sb, x_sc, idx, 1, grad_out, g_sb, g_sc, B, C, N, K, dx, stream);
+}
+
+extern "C" int grafp_mrconv_arg_supported(int dtype, int64_t x_sb, int64_t x_sc, int64_t o_sb, int64_t o_sc, int N, int K) {
+    return mrconv_arg_shape_ok(dtype, x_sb, x_sc, o_sb, o_sc, N, K) ? 1 : 0;
+}
+extern "C" int grafp_mrconv_fwd_arg(const void *x, int dtype, int64_t x_sb, int64_t x_sc, const void *idx, int idx_is_i32,
+                                    int B, int C, int N, int K, void *out, int64_t o_sb, int64_t o_sc, uint8_t *arg,
+                                    grafp_stream_t stream) {
+    GRAFP_REQUIRE(arg, "mrconv_fwd_arg: null pointer");
+    GRAFP_REQUIRE(mrconv_arg_shape_ok(dtype, x_sb, x_sc, o_sb, o_sc, N, K),
+                  "mrconv_fwd_arg: shape outside grafp_mrconv_arg_supported (N=%d K=%d)", N, K);
+    return mrconv_fwd_impl(x, dtype, x_sb, x_sc, idx, idx_is_i32, B, C, N, K, out, o_sb, o_sc, stream, arg);
+}
+extern "C" int grafp_mrconv_bwd_arg(const uint8_t *arg, int dtype, const void *idx, int idx_is_i32, const void *grad_out,
+                                    int64_t g_sb, int64_t g_sc, int B, int C, int N, int K, void *dx, int64_t d_sb,
+                                    int64_t d_sc, grafp_stream_t stream) {
+    using namespace grafp;
+    GRAFP_REQUIRE(arg && idx && grad_out && dx, "mrconv_bwd_arg: null pointer");
+    GRAFP_REQUIRE(B > 0 && C > 0, "mrconv_bwd_arg: bad shape B=%d C=%d", B, C);
+    const size_t es = dtype == GRAFP_F32 ? 4 : 2;
+    GRAFP_REQUIRE(mrconv_arg_shape_ok(dtype, d_sb, d_sc, g_sb, g_sc, N, K) && (uintptr_t)grad_out % (4 * es) == 0 &&
+                      (uintptr_t)dx % (4 * es) == 0,
+                  "mrconv_bwd_arg: shape / alignment outside grafp_mrconv_arg_supported (N=%d K=%d)", N, K);
+    const int ccp = MRB_SLAB / N < C ? MRB_SLAB / N : C;
+    const int nslab = (C + ccp - 1) / ccp;
+    int per_clip = nslab < 4 ? nslab : 4;
+    while ((int64_t)per_clip * B < 1024 && per_clip < nslab) ++per_clip;
+    const size_t ldsp = (size_t)8 * MRB_SLAB + (size_t)4 * K * N;             // i64 accumulator + edges [K][N]
+    const dim3 gridp(per_clip, B);
+#define MR_BWDA(T, I)                                                                                                  \
+    (void)hipFuncSetAttribute((const void *)mrconv_bwd_a_kernel<T, I>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                              (int)ldsp);                                                                              \
+    hipLaunchKernelGGL((mrconv_bwd_a_kernel<T, I>), gridp, dim3(MR_THREADS), ldsp, (hipStream_t)stream, arg,           \
+                       (const I *)idx, (const T *)grad_out, g_sb, g_sc, (T *)dx, d_sb, d_sc, C, N, K, ccp)
+    if (dtype == GRAFP_F32) { if (idx_is_i32) { MR_BWDA(float, int32_t); } else { MR_BWDA(float, int64_t); } }
+    else { if (idx_is_i32) { MR_BWDA(unsigned short, int32_t); } else { MR_BWDA(unsigned short, int64_t); } }
+#undef MR_BWDA
+    GRAFP_CHECK_LAUNCH("mrconv_bwd_a_kernel");
+    return GRAFP_OK;
 }
 
 extern "C" int grafp_mrconv_fwd_f32(const float *x, const int64_t *idx, int B, int C, int N, int K, float *out,

@@ -49,6 +49,7 @@ class _Switches:
     bn_spin_limit = -1            # polls of the single-pass BatchNorm rendezvous (-1: the library default; 0: never wait)
     knn_split = True              # False: every k-NN graph by the exact-f32 MFMA kernel (knn_graph.hip) -- same indices
     fused_eval_affine = True      # False: eval-mode conv+BN+act as GEMM + normalise pass (same bits) instead of one kernel
+    mrconv_arg = True             # False: max-relative backward recomputes the arg-max from x instead of reading the record
 
 
 switches = _Switches()
@@ -372,23 +373,40 @@ class _MaxRelative(torch.autograd.Function):
         K = idx.shape[-1]
         if tuple(idx.shape) != (B, N, K):
             raise ValueError(f"idx shape {tuple(idx.shape)} does not match activations B={B} N={N}")
-        fwd = lib.grafp_mrconv_fwd_strided_i32 if idx.dtype == torch.int32 else lib.grafp_mrconv_fwd_strided
         out = torch.empty((B, 2 * C, N) if layout == "bcn" else (2 * C, B, N), dtype=x.dtype, device=x.device)
         o_sb, o_sc = (2 * C * N, N) if layout == "bcn" else (N, B * N)
+        ctx.layout, ctx.dims = layout, (B, C, N, tuple(x.shape), x.dtype)
+        ctx.from_arg = bool(switches.mrconv_arg and ctx.needs_input_grad[0]
+                            and lib.grafp_mrconv_arg_supported(_DT[x.dtype], sb, sc, o_sb, o_sc, N, K))
+        if ctx.from_arg:
+            # training: record which neighbour won (2 bits per element) -- backward then needs neither x nor the gather
+            arg = torch.empty((B, C, N // 4), dtype=torch.uint8, device=x.device)
+            with _timed("mrconv_fwd", (B, C, N, K)):
+                check(lib.grafp_mrconv_fwd_arg(_p(x), _DT[x.dtype], sb, sc, _p(idx), int(idx.dtype == torch.int32), B, C,
+                                               N, K, _p(out), o_sb, o_sc, _p(arg), _stream()), "mrconv_fwd_arg")
+            ctx.save_for_backward(arg, idx)
+            return out
+        fwd = lib.grafp_mrconv_fwd_strided_i32 if idx.dtype == torch.int32 else lib.grafp_mrconv_fwd_strided
         with _timed("mrconv_fwd", (B, C, N, K)):
             check(fwd(_p(x), _DT[x.dtype], sb, sc, _p(idx), B, C, N, K, _p(out), o_sb, o_sc, _stream()), "mrconv_fwd")
         ctx.save_for_backward(x, idx)
-        ctx.layout = layout
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         x, idx = ctx.saved_tensors
         layout = ctx.layout
-        _, B, C, N, sb, sc = _act_view(x, layout)
+        B, C, N, shape, dtype = ctx.dims
         K = idx.shape[-1]
-        g = grad_out.detach().to(x.dtype).contiguous()
+        g = grad_out.detach().to(dtype).contiguous()
         g_sb, g_sc = (2 * C * N, N) if layout == "bcn" else (N, B * N)
+        sb, sc = (C * N, N) if layout == "bcn" else (N, B * N)
+        if ctx.from_arg:
+            dx = torch.empty(shape, dtype=dtype, device=g.device)
+            with _timed("mrconv_bwd", (B, C, N, K)):
+                check(lib.grafp_mrconv_bwd_arg(_p(x), _DT[dtype], _p(idx), int(idx.dtype == torch.int32), _p(g), g_sb,
+                                               g_sc, B, C, N, K, _p(dx), sb, sc, _stream()), "mrconv_bwd_arg")
+            return dx, None, None
         dx = torch.empty_like(x)
         with _timed("mrconv_bwd", (B, C, N, K)):
             bwd = lib.grafp_mrconv_bwd_strided_i32 if idx.dtype == torch.int32 else lib.grafp_mrconv_bwd_strided

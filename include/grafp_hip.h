@@ -163,6 +163,17 @@ int grafp_mrconv_fwd_strided_i32(const void *x, int dtype, int64_t x_sb, int64_t
 int grafp_mrconv_bwd_strided_i32(const void *x, int dtype, int64_t x_sb, int64_t x_sc, const int32_t *idx,
                                  const void *grad_out, int64_t g_sb, int64_t g_sc, int B, int C, int N, int K,
                                  void *dx, grafp_stream_t stream);
+/* Training form: the forward pass also records WHICH neighbour won (the first maximum: the routing rule of the backward
+ * pass above, comparison for comparison) as 2 bits per element -- arg (B, C, N / 4) bytes, element n in bits 2 (n % 4)
+ * of byte n / 4 -- and the backward pass runs from that record: no x, no neighbour gather, the same dx bit for bit.
+ * For the shapes grafp_mrconv_arg_supported accepts (K <= 4, N % 4 == 0, N <= 2048, strides multiples of 4 elements;
+ * pointers 4-element aligned).  idx int64 or int32 (idx_is_i32); dx with its own strides (d_sb, d_sc). */
+int grafp_mrconv_arg_supported(int dtype, int64_t x_sb, int64_t x_sc, int64_t o_sb, int64_t o_sc, int N, int K);
+int grafp_mrconv_fwd_arg(const void *x, int dtype, int64_t x_sb, int64_t x_sc, const void *idx, int idx_is_i32, int B,
+                         int C, int N, int K, void *out, int64_t o_sb, int64_t o_sc, uint8_t *arg, grafp_stream_t stream);
+int grafp_mrconv_bwd_arg(const uint8_t *arg, int dtype, const void *idx, int idx_is_i32, const void *grad_out,
+                         int64_t g_sb, int64_t g_sc, int B, int C, int N, int K, void *dx, int64_t d_sb, int64_t d_sc,
+                         grafp_stream_t stream);
 
 /* ---- K8/K9 glue: fused [conv bias] + BatchNorm + activation + residual on the (C, M = B*N) layout ----
  * Replaces the `+ bias` -> BatchNorm2d -> ReLU/LeakyReLU -> `+ shortcut` chains around every 1x1 convolution

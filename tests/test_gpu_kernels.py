@@ -235,6 +235,37 @@ def test_max_relative_forward_backward(dev, B, C, N, K):
     np.testing.assert_allclose(xg.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("B,C,N,K", [(3, 64, 1024, 3), (2, 128, 512, 3), (2, 256, 256, 4), (2, 512, 128, 2), (2, 12, 2048, 1)])
+def test_max_relative_backward_from_record_equals_recompute(dev, monkeypatch, B, C, N, K):
+    """Training form: the forward pass records which neighbour won (2 bits per element) and the backward pass routes the
+    gradients from that record.  Same outputs and the same dx, bit for bit, as the form that recomputes the arg-max from
+    x -- f32 and bf16, both layouts, int32 / int64 edges, with exact ties (first maximum wins) and a NaN feature."""
+    from grafp_amd import ops
+    x = hash_normalish(f"gpu:mra.x.{C}.{N}", (B, C, N)).astype(np.float32)
+    x = np.round(x * 4.0) / 4.0                                      # a coarse grid: many exact ties among the neighbours
+    x[0, 1, 5] = np.nan
+    idx = hash_ints(f"gpu:mra.idx.{C}.{N}", (B, N, K), 0, N - 1).astype(np.int64)
+    idx[:, :, 0] = np.arange(N)[None, :]
+    g = hash_normalish(f"gpu:mra.g.{C}.{N}", (B, 2 * C, N)).astype(np.float32)
+    assert ops.lib.grafp_mrconv_arg_supported(0, C * N, N, 2 * C * N, N, N, K) == 1
+    for dt in (torch.float32, torch.bfloat16):
+        for layout in ("bcn", "cbn"):
+            xt = t(x).to(dt).to(dev)
+            gt = t(g).to(dt).to(dev)
+            if layout == "cbn":
+                xt, gt = xt.permute(1, 0, 2).contiguous(), gt.permute(1, 0, 2).contiguous()
+            for it in (torch.int64, torch.int32):
+                res = []
+                for rec in (True, False):
+                    monkeypatch.setattr(ops.switches, "mrconv_arg", rec)
+                    xg = xt.clone().requires_grad_(True)
+                    out = ops.max_relative(xg, t(idx).to(it).to(dev), layout=layout)
+                    out.backward(gt)
+                    res.append((out.detach(), xg.grad))
+                assert torch.equal(res[0][0].nan_to_num(7.0), res[1][0].nan_to_num(7.0)), (dt, layout, it)
+                assert torch.equal(res[0][1].nan_to_num(7.0), res[1][1].nan_to_num(7.0)), (dt, layout, it)
+
+
 def test_max_relative_golden(dev):
     from grafp_amd import ops
     g = golden("mrconv.npz")
