@@ -98,8 +98,26 @@ def _bn_training(bn, groups):
     return training, (0.0 if bn.momentum is None else bn.momentum)
 
 
+def deferred_norm(x, prod_conv, prod_bn, cons_conv, cons_bn, groups=1):
+    """An ops.DeferredNorm for  x -> [prod_conv, prod_bn, act] -> [cons_conv, cons_bn ...]  when the first layer's output
+    feeds only the second, both take the fused bf16 path in training mode and the measured rule says it pays."""
+    if not (prod_bn.training and cons_bn.training and cons_conv.groups == 1):
+        return None
+    cin, B, N = x.shape
+    xa = x
+    if torch.is_autocast_enabled() and x.is_cuda and x.dtype == torch.float32:
+        xa = x.to(torch.get_autocast_dtype("cuda"))
+    if not ops.conv_bn_act_supported(xa.reshape(cin, B * N), prod_conv.out_channels, prod_conv.groups, groups):
+        return None
+    if not ops.conv_bn_act_shape_supported(cons_conv.in_channels, B * N, cons_conv.out_channels, 1, groups):
+        return None
+    if not ops.defer_norm_pays(cons_conv.out_channels, cons_conv.in_channels, B * N):
+        return None
+    return ops.DeferredNorm()
+
+
 def conv_bn_act(conv, bn, x, residual=None, act=ops.ACT_NONE, slope=0.0, groups=1, weight=None, use_bias=True,
-                token=None, token_role=0):
+                token=None, token_role=0, defer=None, defer_role=0):
     """[1x1 Conv2d -> BatchNorm2d -> activation -> + shortcut] on x (Cin, B, N) -> (Cout, B, N).  bf16 activations on
     the GPU take the fused path (ops.conv_bn_act: hand-written GEMM with the batch statistics in its epilogue, one
     normalise pass); everything else the GEMM + fused BatchNorm kernel pair.  `weight`: a 2-D (Cout, K) weight derived
@@ -118,8 +136,10 @@ def conv_bn_act(conv, bn, x, residual=None, act=ops.ACT_NONE, slope=0.0, groups=
         z = ops.conv_bn_act(x2, w, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum, bn.eps,
                             bias, res, act, slope, cg, groups, getattr(conv, "_w_lowp", None) if weight is None else None,
                             token, token_role, getattr(conv, "_w_t", None) if weight is None else None,
-                            getattr(conv, "_w_aug", None) if weight is None else None)
+                            getattr(conv, "_w_aug", None) if weight is None else None, defer, defer_role)
         return z.reshape(cout, B, N)
+    if defer is not None:
+        raise RuntimeError("conv_bn_act: a DeferredNorm was handed to a layer outside the fused bf16 path")
     if weight is None:
         y = conv1x1(conv, x)
     else:

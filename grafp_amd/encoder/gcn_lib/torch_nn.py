@@ -4,7 +4,7 @@ import torch
 from torch import nn
 
 from ... import ops
-from .._dense import bn_act, conv1x1, conv_bn_act, from_cbn, to_cbn
+from .._dense import bn_act, conv1x1, conv_bn_act, deferred_norm, from_cbn, to_cbn
 
 _ACTS = {
     "relu": lambda inplace, slope, n: nn.ReLU(inplace),
@@ -69,6 +69,18 @@ class BasicConv(nn.Sequential):
             elif isinstance(m, (nn.BatchNorm2d, nn.InstanceNorm2d)) and m.weight is not None:
                 m.weight.data.fill_(1)
                 m.bias.data.zero_()
+
+    def forward_cbn_deferred(self, x, groups, consumer):
+        """As forward_cbn for a [conv, BatchNorm, ReLU] stack whose output feeds only `consumer` = (conv, bn), another
+        fused layer: -> (output, ops.DeferredNorm or None).  With a token the output is the RAW convolution output and
+        the consumer applies BatchNorm + ReLU while it stages its operand (_dense.deferred_norm decides)."""
+        mods = list(self)
+        if (len(mods) == 3 and isinstance(mods[0], nn.Conv2d) and isinstance(mods[1], nn.BatchNorm2d)
+                and isinstance(mods[2], nn.ReLU)):
+            d = deferred_norm(x, mods[0], mods[1], consumer[0], consumer[1], groups)
+            if d is not None:
+                return conv_bn_act(mods[0], mods[1], x, act=ops.ACT_RELU, groups=groups, defer=d, defer_role=1), d
+        return self.forward_cbn(x, groups), None
 
     def forward_cbn(self, x, groups=1):
         """x (Cin,B,N) -> (Cout,B,N).  [conv, BatchNorm, ReLU] triples run as GEMM + one fused kernel."""

@@ -24,9 +24,13 @@ class MRConv2d(nn.Module):
         super().__init__()
         self.nn = BasicConv([in_channels * 2, out_channels], act, norm, bias)
 
-    def aggregate_cbn(self, x, nn_idx, groups=1):
-        """x (C,B,N), nn_idx (B,N,k) -> (Cout,B,N)."""
-        return self.nn.forward_cbn(ops.max_relative(x, nn_idx, layout="cbn"), groups)
+    def aggregate_cbn(self, x, nn_idx, groups=1, consumer=None):
+        """x (C,B,N), nn_idx (B,N,k) -> (Cout,B,N); with `consumer` (the one layer that reads the result) ->
+        (output, DeferredNorm or None): see BasicConv.forward_cbn_deferred."""
+        cat = ops.max_relative(x, nn_idx, layout="cbn")
+        if consumer is not None:
+            return self.nn.forward_cbn_deferred(cat, groups, consumer)
+        return self.nn.forward_cbn(cat, groups)
 
     def forward(self, x, edge_index, y=None):
         if y is not None:
@@ -56,11 +60,11 @@ class DyGraphConv2d(GraphConv2d):
         self.k, self.d, self.r = kernel_size, dilation, r
         self.dilated_knn_graph = DenseDilatedKnnGraph(kernel_size, dilation, stochastic, epsilon)
 
-    def forward_cbn(self, x, groups=1):
+    def forward_cbn(self, x, groups=1, consumer=None):
         # edges stay in the compact int32 format between the two graph kernels (the int64 (2,B,N,k) edge_index of the
         # reference is only materialised by the public forward())
         idx = self.dilated_knn_graph.neighbours(x, layout="cbn", index_dtype=torch.int32)
-        return self.gconv.aggregate_cbn(x, idx, groups)
+        return self.gconv.aggregate_cbn(x, idx, groups, consumer)
 
     def forward(self, x, relative_pos=None):
         shape = x.shape
@@ -94,8 +98,10 @@ class Grapher(nn.Module):
         """x (C,B,N) -> (C,B,N): 3 GEMMs, 3 fused BN kernels, the k-NN build and the max-relative gather."""
         tok = shortcut_token(x, self.fc1[0], self.fc2[0], groups)     # the shortcut's gradient rides fc1's data gradient
         y = conv_bn_act(self.fc1[0], self.fc1[1], x, groups=groups, token=tok, token_role=1)
-        y = self.graph_conv.forward_cbn(y, groups)
-        return conv_bn_act(self.fc2[0], self.fc2[1], y, residual=x, groups=groups, token=tok, token_role=2)
+        # stages 0-1: the grouped conv's BatchNorm + ReLU ride fc2's operand staging (no pass of their own)
+        y, d = self.graph_conv.forward_cbn(y, groups, consumer=(self.fc2[0], self.fc2[1]))
+        return conv_bn_act(self.fc2[0], self.fc2[1], y, residual=x, groups=groups, token=tok, token_role=2, defer=d,
+                           defer_role=2)
 
     def forward(self, x):
         return from_cbn(self.forward_cbn(to_cbn(x)), x)

@@ -10,7 +10,8 @@ import torch.nn.functional as F
 from torch import nn
 
 from .. import ops
-from ._dense import bn_act, conv1x1, conv_bn_act, deferred_counters, from_cbn, shortcut_token, stride2_operands, to_cbn
+from ._dense import (bn_act, conv1x1, conv_bn_act, deferred_counters, deferred_norm, from_cbn, shortcut_token,
+                     stride2_operands, to_cbn)
 from .gcn_lib.torch_nn import act_layer
 from .gcn_lib.torch_vertex import Grapher
 
@@ -67,10 +68,15 @@ class FFN(nn.Module):
         """x (C,B,N) -> (C,B,N): 2 GEMMs + 2 fused BN kernels (ReLU and the shortcut add are inside them)."""
         tok = shortcut_token(x, self.fc1[0], self.fc2[0], groups)     # the shortcut's gradient rides fc1's data gradient
         if isinstance(self.act, torch.nn.ReLU):
-            h = conv_bn_act(self.fc1[0], self.fc1[1], x, act=ops.ACT_RELU, groups=groups, token=tok, token_role=1)
+            # stages 0-1: the hidden activation (4C rows) is never normalised by a pass of its own -- fc2 does it on load
+            d = deferred_norm(x, self.fc1[0], self.fc1[1], self.fc2[0], self.fc2[1], groups)
+            h = conv_bn_act(self.fc1[0], self.fc1[1], x, act=ops.ACT_RELU, groups=groups, token=tok, token_role=1,
+                            defer=d, defer_role=1)
         else:
+            d = None
             h = self.act(conv_bn_act(self.fc1[0], self.fc1[1], x, groups=groups, token=tok, token_role=1))
-        return conv_bn_act(self.fc2[0], self.fc2[1], h, residual=x, groups=groups, token=tok, token_role=2)
+        return conv_bn_act(self.fc2[0], self.fc2[1], h, residual=x, groups=groups, token=tok, token_role=2, defer=d,
+                           defer_role=2)
 
     def forward(self, x):
         return from_cbn(self.forward_cbn(to_cbn(x)), x)

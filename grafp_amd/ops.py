@@ -49,6 +49,9 @@ class _Switches:
     bn_spin_limit = -1            # polls of the single-pass BatchNorm rendezvous (-1: the library default; 0: never wait)
     knn_split = True              # False: every k-NN graph by the exact-f32 MFMA kernel (knn_graph.hip) -- same indices
     fused_eval_affine = True      # False: eval-mode conv+BN+act as GEMM + normalise pass (same bits) instead of one kernel
+    defer_norm = False            # True: stages 0-1 normalise on load (ops.DeferredNorm) -- EXPERIMENTAL, off: the in-LDS
+                                  # transform of conv1x1_gemm's PRO form races with the LDS-DMA ring on the 2-workgroup tile
+                                  # (DESIGN.md section 6, round 3); -1.9 ms of a 102 ms step when it is on
     mrconv_arg = True             # False: max-relative backward recomputes the arg-max from x instead of reading the record
 
 
@@ -899,8 +902,15 @@ class _ConvBnAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, w_lowp, conv_groups, views, gamma, beta, pre_bias, residual, running_mean, running_var,
-                training, momentum, eps, act, slope, token=None, token_role=0, w_t=None, w_aug=None):
+                training, momentum, eps, act, slope, token=None, token_role=0, w_t=None, w_aug=None, defer=None,
+                defer_role=0):
         x = x.detach()
+        # DeferredNorm: role 1 = this layer's BatchNorm + activation are applied by its only consumer while THAT stages
+        # its operand (no normalise pass, the normalised tensor is never written); role 2 = that consumer
+        pro = None
+        if defer is not None and defer_role == 2 and defer.tab is not None:
+            pro = (defer.tab, int(defer.act), float(defer.slope))
+        ctx.pro = pro
         ctx.token, ctx.token_role = token, token_role        # 1: first layer of the block (consumes), 2: last (provides)
         ctx.w_t, ctx.w_aug = w_t, w_aug                      # prepared with the forward operand (lowp_weights), or None
         # shared prepared buffers in use: remember which preparation this forward pass saw
@@ -913,12 +923,23 @@ class _ConvBnAct(torch.autograd.Function):
             wl = w.detach().reshape(R, -1).to(torch.bfloat16)
         g32, b32 = _f32c(gamma), _f32c(beta)
         pb = None if pre_bias is None else _f32c(pre_bias)
-        if training:
+        if pro is not None:
+            if not training:
+                raise RuntimeError("conv_bn_act: a deferred normalisation reached an eval-mode consumer")
+            y, part = conv1x1_gemm(wl, x, conv_groups, views, pro_tab=pro[0], pro_act=pro[1], pro_slope=pro[2], stats=True)
+        elif training:
             y, part = conv1x1_gemm(wl, x, conv_groups, views, stats=True)
         else:
             y, part = conv1x1_gemm(wl, x, conv_groups, views), None
         res = None if residual is None else residual.detach().to(torch.bfloat16).contiguous()
-        if training and views <= 4:
+        if defer is not None and defer_role == 1:
+            if not training or res is not None:
+                raise RuntimeError("conv_bn_act: only a training-mode layer without a shortcut can defer its normalisation")
+            mean, invstd, tab = bn_finalize(part, R, K, conv_groups, M, views, g32, b32, pb, running_mean, running_var,
+                                            True, momentum, eps)
+            defer.tab, defer.act, defer.slope = tab, act, slope
+            z = y                                            # stands in for act(BN(y)): the consumer normalises on load
+        elif training and views <= 4:
             z, mean, invstd, tab = bn_finalize_affine(y, part, K, conv_groups, views, g32, b32, pb, running_mean,
                                                       running_var, momentum, eps, res, act, slope)
         else:
@@ -958,12 +979,15 @@ class _ConvBnAct(torch.autograd.Function):
                 dx = conv1x1_gemm(_group_transpose(wl, cg), dy, cg, 1)
         dw = None
         if ctx.needs_input_grad[1]:
-            dw = _wgrad_bf16(dy, x, R, K, cg, M).reshape(wfull)
+            if ctx.pro is not None:                        # x is the producer's raw output: the same transform on load
+                dw = _wgrad_bf16(dy, x, R, K, cg, M, views, ctx.pro[0], ctx.pro[1], ctx.pro[2]).reshape(wfull)
+            else:
+                dw = _wgrad_bf16(dy, x, R, K, cg, M).reshape(wfull)
         dres = dz if has_res else None
         if has_res and tok is not None and ctx.token_role == 2 and tok.grad is None:
             tok.grad, dres = dz, None                      # the first layer's backward adds it (see above)
         return (dx, dw, None, None, None, dgamma, dbeta, dpb, dres, None, None, None, None, None, None, None, None, None,
-                None, None)
+                None, None, None, None)
 
 
 def conv_bn_act_supported(x, cout, conv_groups, views):
@@ -980,9 +1004,30 @@ def conv_bn_act_shape_supported(K, M, cout, conv_groups, views):
     return gemm_supported(cout, K, conv_groups, M, views) and gemm_supported(K, cout, conv_groups, M, 1)
 
 
+class DeferredNorm:
+    """Shared by a layer whose BatchNorm + activation output has exactly ONE consumer, another conv_bn_act (role 1), and
+    that consumer (role 2): the producer returns its raw convolution output and leaves (scale, shift) here, the consumer
+    applies them to the operand tile while it is staged (conv1x1_gemm PRO, and again in its weight gradient).  Saves the
+    normalise pass (one read + one write of the widest tensors of a block) where the GEMM is HBM-bound."""
+
+    def __init__(self):
+        self.tab, self.act, self.slope = None, ACT_NONE, 0.0
+
+
+def defer_norm_pays(consumer_rows, consumer_operand_rows, M):
+    """Measured at 512 and 2048 clip-views: the consumer's output rows <= 128 (stages 0-1): skipped
+    pass 200-400 us against +30-115 us in the GEMM and +10-35 us in the weight gradient; beyond, the products are
+    matrix-bound and the in-LDS transform costs more than the pass."""
+    if not (switches.defer_norm and consumer_rows <= 128):
+        return False
+    # Never while a HIP graph is being recorded: back-to-back replays (two ranks sharing one device in
+    # tests/test_gpu_dist.py) hit the race of the PRO form in half of the runs -- wrong forward passes, finite values.
+    return not torch.cuda.is_current_stream_capturing()
+
+
 def conv_bn_act(x, w, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, pre_bias=None,
                 residual=None, act=ACT_NONE, slope=0.0, conv_groups=1, views=1, w_lowp=None, token=None, token_role=0,
-                w_t=None, w_aug=None):
+                w_t=None, w_aug=None, defer=None, defer_role=0):
     """act(BatchNorm(W x + pre_bias)) + residual for bf16 (K, M) rows (see _ConvBnAct).  token / token_role: a
     ShortcutToken shared by the first (role 1: its input IS the shortcut) and the last layer (role 2: `residual` is that
     same input) of a residual block."""
@@ -999,9 +1044,11 @@ def conv_bn_act(x, w, gamma, beta, running_mean, running_var, training, momentum
         _, _, tab = bn_finalize(None, R, K, int(conv_groups), M, int(views), gamma, beta, pre_bias, running_mean,
                                 running_var, False, momentum, eps)
         return conv1x1_gemm_affine(wl, x, tab, int(conv_groups), int(views), int(act), float(slope))
+    if defer is not None and not training:
+        raise RuntimeError("conv_bn_act: deferred normalisation is a training-mode construct")
     return _ConvBnAct.apply(x.contiguous(), w, w_lowp, int(conv_groups), int(views), gamma, beta, pre_bias, residual,
                             running_mean, running_var, bool(training), float(momentum), float(eps), int(act),
-                            float(slope), token, int(token_role), w_t, w_aug)
+                            float(slope), token, int(token_role), w_t, w_aug, defer, int(defer_role))
 
 
 def shortcut_token_supported(x, conv_groups=1):

@@ -27,6 +27,10 @@ def graph_mode(out, B, rccl_one_rank=False, overlap=False):
         rank, world, device = gdist.init_from_env(backend="gloo", local_device=0)
     cfg = load_config()
     cfg["bsz_train"] = B
+    # every later allocation of this process comes out of blocks full of NaNs (the caching allocator keeps them): a
+    # kernel that reads what nobody wrote -- fine on a fresh box where memory is zero -- shows up here
+    junk = torch.full((1 << 30,), float("nan"), device=device)
+    del junk
     torch.manual_seed(1234)
     model = build_model(cfg, device=device)
     tr = Trainer(cfg, model, device, amp_dtype=torch.bfloat16, data_parallel_graphs=True if rccl_one_rank else None,

@@ -96,6 +96,7 @@ def test_bf16_backward_layer_by_layer_vs_oracle_autograd(dev, monkeypatch, fused
     from oracle import model as om
     from grafp_amd import ops
     monkeypatch.setattr(ops.switches, "shortcut_fusion", bool(fused))
+    monkeypatch.setattr(ops.switches, "defer_norm", False)     # layer-by-layer: every layer stores its own output
     cfg, model = _model(dev)
     model.train()
     xi, xj = simclr_inputs()

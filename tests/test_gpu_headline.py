@@ -42,9 +42,12 @@ def _slabs(M, views, seed):
     return cols
 
 
-def _check_product(y, wf, xf, groups):
+def _check_product(y, wf, xf, groups, operand_rebuilt=False):
     """y (R, n) bf16 vs the f32 product of the same operands: one bf16 rounding step of slack plus the f32
-    accumulation-order error, bounded by 2^-18 of sum |w||x| (K <= 4096 terms of 2^-24 each, generously)."""
+    accumulation-order error, bounded by 2^-18 of sum |w||x| (K <= 4096 terms of 2^-24 each, generously).
+    operand_rebuilt: xf is this test's own rebuild of an operand the kernel derives in LDS (normalise-on-load): the kernel's
+    fma against torch's mul + add can move single operand elements across a bf16 rounding boundary, so (as in
+    tests/test_gpu_gemm.py::test_gemm_normalise_on_load) the bars are a relative L2 error and an outlier fraction."""
     R, Kg = wf.shape
     Rg = R // groups
     ref = torch.cat([wf[g * Rg:(g + 1) * Rg] @ xf[g * Kg:(g + 1) * Kg] for g in range(groups)], dim=0)
@@ -52,6 +55,10 @@ def _check_product(y, wf, xf, groups):
     refq = ref.to(torch.bfloat16).float()
     err = (y.float() - refq).abs()
     tol = refq.abs() * 2.0 ** -7 + mag * 2.0 ** -18 + 1e-30
+    if operand_rebuilt:
+        assert float((y.float() - refq).norm() / refq.norm()) < 2e-3, tuple(y.shape)
+        assert float((err > tol).float().mean()) < 1e-3, (float((err > tol).float().mean()), tuple(y.shape))
+        return
     assert bool((err <= tol).all()), (float((err / tol).max()), tuple(y.shape))
     assert float((y.float() != refq).float().mean()) < 2e-2
 
@@ -60,6 +67,16 @@ class _Checks:
     def __init__(self):
         self.seen = {"gemm": set(), "cat": set(), "affine": set(), "bn_bwd": set(), "wgrad": set()}
         self.graphs = []
+
+
+def _pro(xs, tab, act, slope, view_of):
+    """act(x * scale + shift) per operand row and view, rounded to bf16: what conv1x1_gemm / the weight gradient build from
+    the raw operand when the producer deferred its BatchNorm (ops.DeferredNorm)."""
+    t = tab.reshape(xs.shape[0], -1, 2).float()
+    v = view_of.long()
+    z = torch.addcmul(t[:, v, 1], xs, t[:, v, 0])
+    z = torch.relu(z) if act == 1 else (torch.where(z > 0, z, z * slope) if act == 2 else z)
+    return z.to(torch.bfloat16).float()
 
 
 def test_headline_step_kernels_vs_references(dev):
@@ -81,12 +98,15 @@ def test_headline_step_kernels_vs_references(dev):
 
     def gemm(w, x, groups=1, views=1, pro_tab=None, pro_act=0, pro_slope=0.0, stats=False):
         out = orig["conv1x1_gemm"](w, x, groups, views, pro_tab, pro_act, pro_slope, stats)
-        key = (w.shape[0], x.shape[0], groups, x.shape[1], views, stats)
-        if key not in ck.seen["gemm"] and pro_tab is None:
+        key = (w.shape[0], x.shape[0], groups, x.shape[1], views, stats, pro_tab is not None)
+        if key not in ck.seen["gemm"]:
             ck.seen["gemm"].add(key)
             y = out[0] if stats else out
             cols = _slabs(x.shape[1], views, len(ck.seen["gemm"])).to(x.device)
-            _check_product(y[:, cols], w.float(), x[:, cols].float(), groups)
+            xs = x[:, cols].float()
+            if pro_tab is not None:        # normalise-on-load (stages 0-1): the operand the kernel builds in LDS
+                xs = _pro(xs, pro_tab, pro_act, pro_slope, cols // (x.shape[1] // views))
+            _check_product(y[:, cols], w.float(), xs, groups, operand_rebuilt=pro_tab is not None)
         return out
 
     def gemm_cat(w, x1, x2):
@@ -166,14 +186,17 @@ def test_headline_step_kernels_vs_references(dev):
 
     def wgrad(g, x, cout, cin, groups, M, views=1, pro_tab=None, pro_act=0, pro_slope=0.0):
         dw = orig["_wgrad_bf16"](g, x, cout, cin, groups, M, views, pro_tab, pro_act, pro_slope)
-        key = (cout, cin, groups, M, views)
-        if key not in ck.seen["wgrad"] and pro_tab is None:
+        key = (cout, cin, groups, M, views, pro_tab is not None)
+        if key not in ck.seen["wgrad"]:
             ck.seen["wgrad"].add(key)
             og, cg = cout // groups, cin // groups
             want = torch.zeros((cout, cg), dtype=torch.float64, device=g.device)
             step = max(128, (1 << 27) // max(cout, cin))                 # <= 1 GiB of float64 per operand chunk
             for m0 in range(0, M, step):
                 gd, xd = g[:, m0:m0 + step].double(), x[:, m0:m0 + step].double()
+                if pro_tab is not None:
+                    view_of = torch.arange(m0, min(M, m0 + step), device=g.device) // (M // views)
+                    xd = _pro(x[:, m0:m0 + step].float(), pro_tab, pro_act, pro_slope, view_of).double()
                 for i in range(groups):
                     want[i * og:(i + 1) * og] += gd[i * og:(i + 1) * og] @ xd[i * cg:(i + 1) * cg].t()
             assert float((dw.double() - want).abs().max()) <= 2e-3 * float(want.abs().max()), key
@@ -199,6 +222,8 @@ def test_headline_step_kernels_vs_references(dev):
     M0 = 2 * PAIRS * 1024
     assert len(ck.seen["gemm"]) >= 30 and len(ck.seen["cat"]) == 8, {k: len(v) for k, v in ck.seen.items()}
     assert len(ck.seen["affine"]) >= 20 and len(ck.seen["bn_bwd"]) >= 16 and len(ck.seen["wgrad"]) >= 20
+    # the normalise-on-load form is off by default (ops.switches.defer_norm): no product went through _pro
+    assert sum(k[-1] for k in ck.seen["gemm"]) == 0 and sum(k[-1] for k in ck.seen["wgrad"]) == 0
     assert any(k[3] == M0 for k in ck.seen["gemm"]) and any(k[3] == M0 for k in ck.seen["wgrad"])
     assert len(ck.graphs) == 12
     for feats, idx in ck.graphs:
@@ -210,13 +235,13 @@ def test_headline_step_kernels_vs_references(dev):
     import ctypes
     info = (ctypes.c_int * 8)()
     tiles, four_rounds = set(), 0
-    for (R, K, groups, M, views, stats) in ck.seen["gemm"]:
+    for (R, K, groups, M, views, stats, _pro_on) in ck.seen["gemm"]:
         assert lib.grafp_conv1x1_gemm_plan(R, K, groups, M, views, info) == 0
         tiles.add(int(info[0]))
         four_rounds += int(info[4] >= 1024)
     assert tiles >= {0, 1, 3, 4} and four_rounds >= 1, (tiles, four_rounds)         # S, L, N64, N128 all ran
     cfgs = set()
-    for (cout, cin, groups, M, views) in ck.seen["wgrad"]:
+    for (cout, cin, groups, M, views, _pro_on) in ck.seen["wgrad"]:
         assert lib.grafp_conv1x1_wgrad_plan(cout, cin, groups, M, views, info) == 0
         cfgs.add(int(info[0]))
     assert {6, 7} <= cfgs, cfgs                      # SG and LG: the register-staged tiles of >= 750 MB / wide layers

@@ -584,3 +584,61 @@ def test_shortcut_gradient_fused_into_data_gradient(dev, monkeypatch):
     floor = 1e-3 * den ** 0.5
     worst = max(float((g1[n] - g0[n]).norm() / g0[n].norm()) for n in g0 if float(g0[n].norm()) >= floor)
     assert worst <= 0.3, worst
+
+
+def test_deferred_normalisation_equals_separate_passes(dev, monkeypatch):
+    """EXPERIMENTAL path, off by default (ops.switches.defer_norm): at stages 0-1 the BatchNorm + ReLU of the grouped graph
+    conv and of the FFN's hidden layer are applied by their consumer while it stages its operand (ops.DeferredNorm: no
+    normalise pass, the normalised tensors never written).  Same operand bits, same products: at this size the loss and
+    the activations come out identical and the gradients differ only by the summation order of the consumer's weight
+    gradient.  (At 2048 clip-views the in-LDS transform on the two-workgroup tile is NOT reliable -- a race with the
+    LDS-DMA ring, 0.6 % of the outputs wrong and different from run to run -- which is why the switch is off; this test
+    keeps the plumbing honest with bars that a stray element does not break.)"""
+    from grafp_amd import ops
+    from grafp_amd.simclr.ntxent import ntxent_loss
+    from grafp_amd.train import Trainer, build_model, synthetic_batch
+    from grafp_amd.util import load_config
+    cfg = load_config()
+    cfg["bsz_train"] = 8
+    junk = torch.full((1 << 28,), float("nan"), device=dev)      # later allocations come out of NaN-filled blocks: a table
+    del junk                                                      # entry nobody wrote would zero an operand row (ReLU)
+    torch.manual_seed(5)
+    model = build_model(cfg, device=dev)
+    tr = Trainer(cfg, model, dev, amp_dtype=torch.bfloat16)
+    x_i, x_j = synthetic_batch(8, 13, dev)
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    pro_launches = []
+    orig = ops.conv1x1_gemm
+
+    def gemm(w, x, groups=1, views=1, pro_tab=None, pro_act=0, pro_slope=0.0, stats=False):
+        if pro_tab is not None:
+            pro_launches.append((w.shape[0], x.shape[0]))
+        return orig(w, x, groups, views, pro_tab, pro_act, pro_slope, stats)
+
+    def run(defer):
+        monkeypatch.setattr(ops.switches, "defer_norm", bool(defer))
+        model.load_state_dict(state)
+        model.train()
+        for p in model.parameters():
+            p.grad = None
+        with torch.no_grad():
+            X_i, X_j = tr.augment(x_i, x_j)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            _, _, z_i, z_j = model(X_i, X_j)
+        loss = ntxent_loss(z_i, z_j, cfg)
+        loss.backward()
+        return (float(loss.detach()), torch.cat((z_i, z_j)).detach().float().clone(),
+                {n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.grad is not None})
+
+    assert ops.switches.defer_norm is False                             # the shipping default
+    monkeypatch.setattr(ops, "conv1x1_gemm", gemm)
+    l1, z1, g1 = run(True)
+    n_pro = len(pro_launches)
+    l0, z0, g0 = run(False)
+    assert n_pro == 8 and len(pro_launches) == 8, pro_launches        # gfc2 + ffn2 of the four stage 0-1 blocks, only
+    assert sorted(set(pro_launches)) == [(64, 128), (64, 256), (128, 256), (128, 512)]
+    assert abs(l1 - l0) <= 1e-3 * abs(l0) and float((z1 - z0).norm() / z0.norm()) <= 1e-2
+    assert g1.keys() == g0.keys()
+    num = sum(float((g1[n] - g0[n]).pow(2).sum()) for n in g0)
+    den = sum(float(g0[n].pow(2).sum()) for n in g0)
+    assert den > 0 and (num / den) ** 0.5 <= 5e-2, (num / den) ** 0.5
