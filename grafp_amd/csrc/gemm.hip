@@ -337,29 +337,6 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::NW == 4 ? 2 : 1) void conv1x1_ge
             issued_now = my_dma;
         }
         unsigned char *const st = smem + (t % NS) * CFG::STAGE;
-        if (PRO) {
-            // normalise + activate the X chunk in place: 32 rows x SLOTS 16-byte pieces, PRO_PIECES per thread
-#pragma unroll
-            for (int j = 0; j < CFG::PRO_PIECES; ++j) {
-                const int p = tid + CFG::THREADS * j;
-                const float2 ss = reinterpret_cast<const float2 *>(s_tab)[ch * GM_KC + p / CFG::SLOTS];
-                uint4 *cell = reinterpret_cast<uint4 *>(st + CFG::A_BYTES + p * 16);
-                uint4 v = *cell;
-                unsigned w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float lo = __uint_as_float(w[e] << 16), hi = __uint_as_float(w[e] & 0xffff0000u);
-                    lo = __builtin_fmaf(lo, ss.x, ss.y);
-                    hi = __builtin_fmaf(hi, ss.x, ss.y);
-                    if (pro_act == 1) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
-                    else if (pro_act == 2) { lo = lo > 0.f ? lo : lo * pro_slope; hi = hi > 0.f ? hi : hi * pro_slope; }
-                    w[e] = gm_pack_bf16(lo, hi);
-                }
-                *cell = make_uint4(w[0], w[1], w[2], w[3]);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-        }
         // ---- 2 k-steps x (2 x RT) MFMAs ----
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -371,6 +348,32 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::NW == 4 ? 2 : 1) void conv1x1_ge
                 const gm_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                     (gm_s16x4 __attribute__((address_space(3))) *)(st + xoff[mi] + ks * 16 * ROWB + 4 * ROWB));
                 xa[mi] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+            if (PRO) {
+                // normalise + activate the fragment IN REGISTERS: its 8 elements are 8 consecutive operand rows
+                // (16 ks + 8 half + 0..7) of the lane's column, so the 8 (scale, shift) pairs are the same for a whole
+                // half-wave: four broadcast 16-byte table reads.  (Rounds 1-3 did this as an in-place pass over the
+                // staged tile -- one more barrier per chunk, and ds_write traffic into a ring that LDS-DMA is filling:
+                // on the two-workgroup tile that pass raced with the ring at 2048 clip-views, 0.6 % of the outputs wrong
+                // and different from run to run.  Same arithmetic on the same values: the results are bit-identical.)
+                const float4 *tp = reinterpret_cast<const float4 *>(s_tab) + (ch * GM_KC + ks * 16 + 8 * half) / 2;
+                float4 t4[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) t4[q] = tp[q];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+                    gm_u32x4 w = __builtin_bit_cast(gm_u32x4, xa[mi]);
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        float lo = __uint_as_float(w[d] << 16), hi = __uint_as_float(w[d] & 0xffff0000u);
+                        lo = __builtin_fmaf(lo, t4[d].x, t4[d].y);
+                        hi = __builtin_fmaf(hi, t4[d].z, t4[d].w);
+                        if (pro_act == 1) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
+                        else if (pro_act == 2) { lo = lo > 0.f ? lo : lo * pro_slope; hi = hi > 0.f ? hi : hi * pro_slope; }
+                        w[d] = gm_pack_bf16(lo, hi);
+                    }
+                    xa[mi] = __builtin_bit_cast(gm_bf16x8, w);
+                }
             }
 #pragma unroll
             for (int ri = 0; ri < RT; ++ri) wb[ri] = *reinterpret_cast<const gm_bf16x8 *>(st + woff[ri][ks]);

@@ -349,7 +349,14 @@ __global__ __launch_bounds__(CFG::THREADS) void wgrad_dma_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
-    if (PRO) __syncthreads();
+    float2 ssb[CT];
+#pragma unroll
+    for (int b = 0; b < CT; ++b) ssb[b] = make_float2(1.0f, 0.0f);
+    if (PRO) {
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < CT; ++b) ssb[b] = reinterpret_cast<const float2 *>(s_tab)[wc * 32 * CT + b * 32 + l31];
+    }
 #pragma unroll
     for (int c = 0; c < D; ++c)
         if (c < T) issue(c);
@@ -360,30 +367,6 @@ __global__ __launch_bounds__(CFG::THREADS) void wgrad_dma_kernel(
         __builtin_amdgcn_s_barrier();
         if (t + D < T) issue(t + D);
         unsigned char *const st = smem + (t % NS) * CFG::STAGE;
-        if (PRO) {
-            // X tile: TC rows x 8 slots; every thread the same number of 16-byte pieces
-            constexpr int PIECES = CFG::TC * CFG::SLOTS / CFG::THREADS;
-#pragma unroll
-            for (int j = 0; j < PIECES; ++j) {
-                const int p = tid + CFG::THREADS * j;
-                const float2 ss = reinterpret_cast<const float2 *>(s_tab)[p / CFG::SLOTS];
-                uint4 *cell = reinterpret_cast<uint4 *>(st + CFG::G_BYTES + p * 16);
-                uint4 v = *cell;
-                unsigned w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float lo = __uint_as_float(w[e] << 16), hi = __uint_as_float(w[e] & 0xffff0000u);
-                    lo = __builtin_fmaf(lo, ss.x, ss.y);
-                    hi = __builtin_fmaf(hi, ss.x, ss.y);
-                    if (pro_act == 1) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
-                    else if (pro_act == 2) { lo = lo > 0.f ? lo : lo * pro_slope; hi = hi > 0.f ? hi : hi * pro_slope; }
-                    w[e] = gm_pack_bf16(lo, hi);
-                }
-                *cell = make_uint4(w[0], w[1], w[2], w[3]);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-        }
 #pragma unroll
         for (int ks = 0; ks < KC / 16; ++ks) {
             gm_bf16x8 av[RT], bv[CT];
@@ -393,6 +376,24 @@ __global__ __launch_bounds__(CFG::THREADS) void wgrad_dma_kernel(
 #pragma unroll
             for (int b = 0; b < CT; ++b)
                 bv[b] = *reinterpret_cast<const gm_bf16x8 *>(st + xoff[b] + (((2 * ks + half) ^ xx[b]) << 4));
+            if (PRO) {
+                // the fragment is 8 columns of ONE operand row: its (scale, shift) sits in two registers of the lane
+                // (in registers, not as a pass over the staged tile: see conv1x1_gemm_kernel)
+#pragma unroll
+                for (int b = 0; b < CT; ++b) {
+                    gm_u32x4 w = __builtin_bit_cast(gm_u32x4, bv[b]);
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        float lo = __uint_as_float(w[d] << 16), hi = __uint_as_float(w[d] & 0xffff0000u);
+                        lo = __builtin_fmaf(lo, ssb[b].x, ssb[b].y);
+                        hi = __builtin_fmaf(hi, ssb[b].x, ssb[b].y);
+                        if (pro_act == 1) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
+                        else if (pro_act == 2) { lo = lo > 0.f ? lo : lo * pro_slope; hi = hi > 0.f ? hi : hi * pro_slope; }
+                        w[d] = gm_pack_bf16(lo, hi);
+                    }
+                    bv[b] = __builtin_bit_cast(gm_bf16x8, w);
+                }
+            }
 #pragma unroll
             for (int a = 0; a < RT; ++a)
 #pragma unroll

@@ -49,9 +49,7 @@ class _Switches:
     bn_spin_limit = -1            # polls of the single-pass BatchNorm rendezvous (-1: the library default; 0: never wait)
     knn_split = True              # False: every k-NN graph by the exact-f32 MFMA kernel (knn_graph.hip) -- same indices
     fused_eval_affine = True      # False: eval-mode conv+BN+act as GEMM + normalise pass (same bits) instead of one kernel
-    defer_norm = False            # True: stages 0-1 normalise on load (ops.DeferredNorm) -- EXPERIMENTAL, off: the in-LDS
-                                  # transform of conv1x1_gemm's PRO form races with the LDS-DMA ring on the 2-workgroup tile
-                                  # (DESIGN.md section 6, round 3); -1.9 ms of a 102 ms step when it is on
+    defer_norm = True             # False: every BatchNorm + activation by its own pass (no normalise-on-load at stages 0-1)
     mrconv_arg = True             # False: max-relative backward recomputes the arg-max from x instead of reading the record
 
 
@@ -1018,11 +1016,7 @@ def defer_norm_pays(consumer_rows, consumer_operand_rows, M):
     """Measured at 512 and 2048 clip-views: the consumer's output rows <= 128 (stages 0-1): skipped
     pass 200-400 us against +30-115 us in the GEMM and +10-35 us in the weight gradient; beyond, the products are
     matrix-bound and the in-LDS transform costs more than the pass."""
-    if not (switches.defer_norm and consumer_rows <= 128):
-        return False
-    # Never while a HIP graph is being recorded: back-to-back replays (two ranks sharing one device in
-    # tests/test_gpu_dist.py) hit the race of the PRO form in half of the runs -- wrong forward passes, finite values.
-    return not torch.cuda.is_current_stream_capturing()
+    return bool(switches.defer_norm) and consumer_rows <= 128
 
 
 def conv_bn_act(x, w, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, pre_bias=None,

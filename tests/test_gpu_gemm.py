@@ -123,6 +123,38 @@ def test_gemm_normalise_on_load(R, K, groups, M, views, act):
     assert float(((y - ref).abs() > ref.abs() * 2.0 ** -6 + ref.abs().max() * 2.0 ** -12).float().mean()) < 1e-3
 
 
+@pytest.mark.parametrize("R,K,M,views", [(64, 128, 1 << 21, 2), (64, 256, 1 << 21, 2), (128, 256, 1 << 20, 2),
+                                         (128, 512, 1 << 20, 2), (64, 128, 1 << 14, 2)])
+def test_normalise_on_load_is_bitwise_the_separate_pass_at_training_sizes(R, K, M, views):
+    """The stage 0-1 consumers of a 1024-pair step (2048 clip-views) and a small one: the product with the operand
+    normalised in the fragment registers equals bn_affine + plain product BIT FOR BIT, run after run, and the weight
+    gradient with the same transform equals the plain one on the materialised operand up to its summation order.
+    (The round 1-3 form -- an in-place pass over the staged LDS tile -- raced with the LDS-DMA ring on the two-workgroup
+    tile at exactly these sizes: 0.6 % of the outputs wrong, different from run to run; the small shapes never showed it.)"""
+    from grafp_amd import ops
+    g = torch.Generator().manual_seed(R + K)
+    x = torch.randn(K, M, generator=g).to(torch.bfloat16).to(DEV)
+    go = torch.randn(R, M, generator=g).to(torch.bfloat16).to(DEV)
+    w = (torch.randn(R, K, generator=g) / K ** 0.5).to(torch.bfloat16).to(DEV)
+    tab = torch.stack((torch.rand(K, views, generator=g) + 0.5, torch.randn(K, views, generator=g)), dim=-1).contiguous().to(DEV)
+    z = ops.bn_affine(x, tab, views, None, ops.ACT_RELU)
+    y0, p0 = ops.conv1x1_gemm(w, z, 1, views, stats=True)
+    d0 = ops._wgrad_bf16(go, z, R, K, 1, M)
+    for _ in range(3):
+        y1, p1 = ops.conv1x1_gemm(w, x, 1, views, pro_tab=tab, pro_act=ops.ACT_RELU, stats=True)
+        assert torch.equal(y1, y0)
+        # the statistics of identical outputs (compared with a bar, not bit for bit: the plain kernel's partial sums of
+        # ONE workgroup in ~2000 came out differently in one of two runs at this size -- same y, mean off by 1.5e-6;
+        # seen while writing this test, not understood yet, noted in DESIGN.md)
+        one = torch.ones(R, device=DEV)
+        m0 = ops.bn_finalize(p0, R, K, 1, M, views, one, 0 * one, None, None, None, True, 0.1, 1e-5)
+        m1 = ops.bn_finalize(p1, R, K, 1, M, views, one, 0 * one, None, None, None, True, 0.1, 1e-5)
+        for a_, b_ in zip(m0[:2], m1[:2]):
+            np.testing.assert_allclose(a_.cpu().numpy(), b_.cpu().numpy(), rtol=2e-5, atol=2e-5)
+        d1 = ops._wgrad_bf16(go, x, R, K, 1, M, views, tab, ops.ACT_RELU, 0.0)
+        assert float((d1 - d0).norm() / d0.norm()) <= 2e-6
+
+
 def test_gemm_rejects_unsupported_shapes():
     from grafp_amd import ops
     assert not ops.gemm_supported(64, 8, 1, 1024, 1)        # K = 8 (the stem): library GEMM
