@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void knn_normalize_split_kernel(const T *__res
                                                                   int *__restrict__ counters) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     const int b = blockIdx.y;
-    // the two counters of this call (all uncertified / light queries) start at zero: done here, in front of pass 2 in
+    // the counters of this call (all uncertified queries; diagnostics) start at zero: done here, in front of pass 2 in
     // stream order, rather than by a hipMemsetAsync -- a memset NODE inside a captured graph faulted on replay once
     // other work had run in between (HIP 7.0)
     if (blockIdx.x == 0 && b == 0 && threadIdx.x < 2) counters[threadIdx.x] = 0;
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256, 2) void knn_topk_split_kernel(const unsigned s
                                                                 const float *__restrict__ sq, I *__restrict__ idx,
                                                                 int *__restrict__ unc_count,
                                                                 unsigned char *__restrict__ unc_flag,
-                                                                int *__restrict__ extra, int *__restrict__ light_list,
+                                                                int *__restrict__ extra,
                                                                 int C, int N, int tiles_per_clip, int nblocks,
                                                                 float margin2, unsigned key_mask) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -292,10 +292,7 @@ __global__ __launch_bounds__(256, 2) void knn_topk_split_kernel(const unsigned s
         unc_flag[row] = certified ? 0 : (light ? 1 : 2);
         if (!certified) {
             atomicAdd(unc_count, 1);                                           // diagnostics: all uncertified queries
-            if (light) {
-                extra[row] = (int)(best.k[K] & imask);
-                light_list[atomicAdd(unc_count + 1, 1)] = (int)row;
-            }
+            if (light) extra[row] = (int)(best.k[K] & imask);          // the (k+1)-th listed candidate (pass 3a reads it)
         }
     }
 }
@@ -393,7 +390,7 @@ __global__ __launch_bounds__(256, 2) void knn_topk_raw_kernel(const unsigned sho
                                                               const float2 *__restrict__ cs, I *__restrict__ idx,
                                                               int *__restrict__ unc_count,
                                                               unsigned char *__restrict__ unc_flag,
-                                                              int *__restrict__ extra, int *__restrict__ light_list,
+                                                              int *__restrict__ extra,
                                                               int C, int N, int tiles_per_clip, int nblocks,
                                                               float margin2, unsigned key_mask) {
     constexpr int D = KR_NS - 1;
@@ -555,64 +552,12 @@ __global__ __launch_bounds__(256, 2) void knn_topk_raw_kernel(const unsigned sho
         unc_flag[row] = certified ? 0 : (light ? 1 : 2);
         if (!certified) {
             atomicAdd(unc_count, 1);
-            if (light) {
-                extra[row] = (int)(best.k[K] & imask);
-                light_list[atomicAdd(unc_count + 1, 1)] = (int)row;
-            }
+            if (light) extra[row] = (int)(best.k[K] & imask);          // the (k+1)-th listed candidate (pass 3a reads it)
         }
     }
 }
 
-// pass 3a: a LIGHT query -- exact distances to its k + 1 listed candidates only (c-ordered fmaf chains on x / den, the
-// oracle's arithmetic), ranked by (distance, index).  8 lanes per query (lane s < k + 1 takes candidate s).
-template <int K, typename I, typename T>
-__global__ __launch_bounds__(256) void knn_exact_pairs_kernel(const T *__restrict__ x, int64_t sb, int64_t sc,
-                                                              const float *__restrict__ den, const float *__restrict__ sq,
-                                                              const int *__restrict__ counts,
-                                                              const int *__restrict__ light_list,
-                                                              const int *__restrict__ extra, I *__restrict__ idx, int C,
-                                                              int N) {
-    const int lane = threadIdx.x & 63, sub = lane & 7;
-    const int slot = (blockIdx.x * 256 + threadIdx.x) >> 3, nslots = gridDim.x * 32;
-    const int count = counts[1];
-    for (int base = 0; base < count; base += nslots) {
-        const int e = base + slot;
-        const bool active = e < count && sub <= K;
-        unsigned long long key = ~0ull;
-        int row = 0, j = 0;
-        if (active) {
-            row = light_list[e];
-            const int b = row / N, q = row - b * N;
-            j = sub < K ? (int)idx[(size_t)row * K + sub] : extra[row];
-            const T *xb = x + (size_t)b * sb;
-            const float dq = den[row], dj = den[(size_t)b * N + j];
-            float g = 0.0f;
-            // (32 channels of loads in flight instead of 8 change nothing: 55-100 us per call either way -- every load of a
-            //  lane is its own page, 4 MB apart in the (C, B, N) layout: the address translation, not the data, is waited for)
-            for (int c = 0; c < C; c += 8) {                   // C % 32 == 0
-                float vq[8], vj[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    vq[u] = ks_ld(xb + (size_t)(c + u) * sc + q);
-                    vj[u] = ks_ld(xb + (size_t)(c + u) * sc + j);
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) g = __builtin_fmaf(__fdiv_rn(vj[u], dj), __fdiv_rn(vq[u], dq), g);
-            }
-            const float d = __builtin_fmaf(-2.0f, g, sq[row]) + sq[(size_t)b * N + j];   // (sq_i + (-2 g)) + sq_j
-            key = ks_key64(d, j);
-        }
-        // rank inside the 8-lane group (keys are distinct: the indices are)
-        int rank = 0;
-#pragma unroll
-        for (int t = 0; t <= K; ++t) {
-            const unsigned long long other = __shfl(key, (lane & ~7) + t);
-            rank += other < key ? 1 : 0;
-        }
-        if (active && rank < K) idx[(size_t)row * K + rank] = (I)j;
-    }
-}
-
+// pass 3a (LIGHT queries: exact distances to the k + 1 listed candidates only) lives at the head of knn_exact_clip_kernel.
 // pass 3b: the HEAVY queries with the oracle's exact arithmetic against every candidate.  One workgroup per CLIP (its feature slab is read
 // once per group of 16 uncertified queries instead of once per query): the queries' normalised vectors sit in LDS, thread t
 // takes candidates t, t + 256, ... (ascending, so the strict-< insert keeps the lower index on ties), re-derives the
@@ -629,7 +574,8 @@ __global__ __launch_bounds__(256) void knn_exact_clip_kernel(const T *__restrict
                                                              const unsigned char *__restrict__ unc_flag,
                                                              I *__restrict__ idx, int C, int N, int chc,
                                                              const int *__restrict__ counters,
-                                                             int *__restrict__ n_uncertified) {
+                                                             int *__restrict__ n_uncertified,
+                                                             const int *__restrict__ extra) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm_x[];
     if (n_uncertified && blockIdx.x == 0 && threadIdx.x == 0) *n_uncertified = counters[0];   // diagnostics (last pass)
     T *sX = reinterpret_cast<T *>(sm_x);                                       // [2][chc][W] feature chunks (W columns)
@@ -639,15 +585,58 @@ __global__ __launch_bounds__(256) void knn_exact_clip_kernel(const T *__restrict
     __shared__ unsigned long long s_red[4];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (tid == 0) s_n = 0;
+    __shared__ int s_nl;
+    if (tid == 0) { s_n = 0; s_nl = 0; }
     __syncthreads();
-    for (int q = tid; q < N; q += 256)
-        if (unc_flag[(size_t)b * N + q] == 2) s_list[atomicAdd(&s_n, 1)] = q;          // the HEAVY queries of this clip
+    // HEAVY queries from the front of s_list, LIGHT ones from its back (a query is one or the other)
+    for (int q = tid; q < N; q += 256) {
+        const unsigned char f = unc_flag[(size_t)b * N + q];
+        if (f == 2) s_list[atomicAdd(&s_n, 1)] = q;
+        else if (f == 1) s_list[N - 1 - atomicAdd(&s_nl, 1)] = q;
+    }
     __syncthreads();
-    const int n = s_n;
-    if (n == 0) return;
+    const int n = s_n, nl = s_nl;
+    if (n == 0 && nl == 0) return;
     const T *xb = x + (size_t)b * sb;
     const float *denb = den + (size_t)b * N, *sqb = sq + (size_t)b * N;
+    // ---- LIGHT queries of this clip (pass 3a, formerly a kernel of its own over a global list): exact distances to the
+    // k + 1 listed candidates only, c-ordered fmaf chains on x / den, ranked by (distance, index); 8 lanes per query (lane
+    // s < k + 1 takes candidate s).  Done here, clip by clip, instead of a kernel of its own over a global list of rows: one
+    // launch and the list's atomics less, the same 100 us per call for both exact passes (load-latency bound: two
+    // workgroups per CU by registers, a few queries each; neither deeper unrolling nor the per-clip grouping moved it).
+    for (int base = 0; base < nl; base += 32) {
+        const int e = base + (tid >> 3), sub = lane & 7;
+        const bool active = e < nl && sub <= K;
+        unsigned long long key = ~0ull;
+        int q = 0, j = 0;
+        if (active) {
+            q = s_list[N - 1 - e];
+            const size_t row = (size_t)b * N + q;
+            j = sub < K ? (int)idx[row * K + sub] : extra[row];
+            const float dq = denb[q], dj = denb[j];
+            float g = 0.0f;
+            for (int c = 0; c < C; c += 8) {                   // C % 32 == 0 (32 channels of loads in flight change nothing)
+                float vq[8], vj[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    vq[u] = ks_ld(xb + (size_t)(c + u) * sc + q);
+                    vj[u] = ks_ld(xb + (size_t)(c + u) * sc + j);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) g = __builtin_fmaf(__fdiv_rn(vj[u], dj), __fdiv_rn(vq[u], dq), g);
+            }
+            const float d = __builtin_fmaf(-2.0f, g, sqb[q]) + sqb[j];        // (sq_i + (-2 g)) + sq_j
+            key = ks_key64(d, j);
+        }
+        int rank = 0;                                          // inside the 8-lane group (keys are distinct: the indices are)
+#pragma unroll
+        for (int t = 0; t <= K; ++t) {
+            const unsigned long long other = __shfl(key, (lane & ~7) + t);
+            rank += other < key ? 1 : 0;
+        }
+        if (active && rank < K) idx[((size_t)b * N + q) * K + rank] = (I)j;
+    }
+    if (n == 0) return;
     const int W = N < 256 * KX_NU ? N : 256 * KX_NU;          // columns per range (N % 128 == 0)
     constexpr int VE = 16 / (int)sizeof(T);                    // elements per 16-byte vector
     const int vrow = W / VE, nvec = chc * vrow;                // vectors per row / per chunk
@@ -800,7 +789,7 @@ struct KsArgs {
     int64_t sb, sc;
     const unsigned short *xh, *xl;
     const float *sq, *den;
-    int *count, *extra, *light, *n_unc;
+    int *count, *extra, *n_unc;
     unsigned char *flag;
     void *idx;
     int B, C, N;
@@ -813,24 +802,22 @@ template <int K, typename I, typename T> static void ks_launch_exact(const KsArg
     int chc = 32;
     while (chc > 1 && (size_t)chc * wcols * sizeof(T) > KX_CHUNK) chc >>= 1;
     const size_t lds_x = (size_t)2 * KX_CHUNK + (size_t)KX_QG * a.C * 4 + (size_t)a.N * 4;
-    hipLaunchKernelGGL((knn_exact_pairs_kernel<K, I, T>), dim3(1024), dim3(256), 0, s, (const T *)a.x, a.sb, a.sc, a.den,
-                       a.sq, a.count, a.light, a.extra, (I *)a.idx, a.C, a.N);
     (void)hipFuncSetAttribute((const void *)knn_exact_clip_kernel<K, I, T>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds_x);
     hipLaunchKernelGGL((knn_exact_clip_kernel<K, I, T>), dim3(a.B), dim3(256), lds_x, s, (const T *)a.x, a.sb, a.sc, a.den,
-                       a.sq, a.flag, (I *)a.idx, a.C, a.N, chc, a.count, a.n_unc);
+                       a.sq, a.flag, (I *)a.idx, a.C, a.N, chc, a.count, a.n_unc, a.extra);
 }
 template <int K, typename I> static void ks_launch(const KsArgs &a, hipStream_t s) {
     const int tiles = a.N / KS_TQ, nblocks = a.B * tiles;
     if (a.raw) {
         (void)hipFuncSetAttribute((const void *)knn_topk_raw_kernel<K, I>, hipFuncAttributeMaxDynamicSharedMemorySize, KR_LDS);
         hipLaunchKernelGGL((knn_topk_raw_kernel<K, I>), dim3(nblocks), dim3(256), KR_LDS, s, (const unsigned short *)a.x,
-                           a.sb, a.sc, a.sq, a.den, a.cs, (I *)a.idx, a.count, a.flag, a.extra, a.light, a.C, a.N, tiles,
+                           a.sb, a.sc, a.sq, a.den, a.cs, (I *)a.idx, a.count, a.flag, a.extra, a.C, a.N, tiles,
                            nblocks, a.margin2, a.key_mask);
     } else {
         (void)hipFuncSetAttribute((const void *)knn_topk_split_kernel<K, I>, hipFuncAttributeMaxDynamicSharedMemorySize, KS_LDS);
         hipLaunchKernelGGL((knn_topk_split_kernel<K, I>), dim3(nblocks), dim3(256), KS_LDS, s, a.xh, a.xl, a.sq, (I *)a.idx,
-                           a.count, a.flag, a.extra, a.light, a.C, a.N, tiles, nblocks, a.margin2, a.key_mask);
+                           a.count, a.flag, a.extra, a.C, a.N, tiles, nblocks, a.margin2, a.key_mask);
     }
     if (a.f32) ks_launch_exact<K, I, float>(a, s);
     else ks_launch_exact<K, I, unsigned short>(a, s);
@@ -865,9 +852,9 @@ static size_t ks_workspace(int dtype, int B, int C, int N) {
     using namespace grafp;
     if (B <= 0 || C <= 0 || N <= 0) return 0;
     const size_t e = (size_t)B * C * N;
-    // sq, den | planes (f32 inputs) or the candidate table (bf16 inputs) | counters | flags | extra, light
+    // sq, den | planes (f32 inputs) or the candidate table (bf16 inputs) | counters | flags | extra
     const size_t mid = dtype == GRAFP_BF16 ? ks_align((size_t)B * N * 8) : 2 * ks_align(e * 2);
-    return 2 * ks_align((size_t)B * N * 4) + mid + 256 + ks_align((size_t)B * N) + 2 * ks_align((size_t)B * N * 4);
+    return 2 * ks_align((size_t)B * N * 4) + mid + 256 + ks_align((size_t)B * N) + ks_align((size_t)B * N * 4);
 }
 extern "C" size_t grafp_knn_split_workspace(int B, int C, int N) { return ks_workspace(GRAFP_F32, B, C, N); }
 extern "C" size_t grafp_knn_split_workspace_for(int dtype, int B, int C, int N) { return ks_workspace(dtype, B, C, N); }
@@ -903,7 +890,6 @@ extern "C" int grafp_knn_graph_split(const void *x, int dtype, int64_t stride_b,
     int *count = (int *)p;                        p += 256;
     unsigned char *flag = (unsigned char *)p;     p += ks_align((size_t)B * N);
     int *extra = (int *)p;                        p += ks_align((size_t)B * N * 4);
-    int *light = (int *)p;
     GRAFP_REQUIRE((((uintptr_t)ws | (uintptr_t)x) & 15) == 0 && (stride_b * (dtype == GRAFP_F32 ? 4 : 2)) % 16 == 0 &&
                       (stride_c * (dtype == GRAFP_F32 ? 4 : 2)) % 16 == 0,
                   "knn_graph_split: input rows and workspace must be 16-byte aligned");
@@ -932,7 +918,7 @@ extern "C" int grafp_knn_graph_split(const void *x, int dtype, int64_t stride_b,
     }
     KsArgs a;
     a.x = x; a.f32 = dtype == GRAFP_F32; a.raw = raw; a.cs = cs; a.sb = stride_b; a.sc = stride_c; a.xh = xh; a.xl = xl; a.sq = sq; a.den = den;
-    a.count = count; a.n_unc = (int *)n_uncertified; a.flag = flag; a.extra = extra; a.light = light; a.idx = idx; a.B = B; a.C = C; a.N = N;
+    a.count = count; a.n_unc = (int *)n_uncertified; a.flag = flag; a.extra = extra; a.idx = idx; a.B = B; a.C = C; a.N = N;
     a.margin2 = 2.0f * (raw ? ks_margin_raw(C) : ks_margin(C));
     a.key_mask = ~((1u << ks_index_bits(N)) - 1u);
     if (idx_is_i32) ks_launch_k<int32_t>(k, a, s);
