@@ -396,6 +396,14 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::NW == 4 ? 2 : 1) void conv1x1_ge
                         const unsigned pk = gm_pack_bf16(acc[0][ri][0], 0.f);
                         sShift[ri] = __shfl(__uint_as_float(pk << 16), l31);
                     }
+                    // the shift as a REAL register pair, made once per row tile.  Left to itself hipcc keeps the RT shifts in
+                    // adjacent registers and splats by operand selection (v_pk_add_f32 d, a, v[72:73] op_sel:[0,1] neg_lo
+                    // neg_hi for the odd one); with that form, at 2^20+ columns, ONE accumulate of lanes 48-63 of the odd row
+                    // tile took 0 instead of the shift in a few workgroups per launch -- identical y, (mean, M2) partials off
+                    // by 1e-6, different from run to run, whichever way the shift had been broadcast (ds_bpermute,
+                    // v_permlane32_swap, with or without wait states).  Repeated launches are bit-identical since.
+                    gm_f32x2 sh = {sShift[ri], sShift[ri]};
+                    if (STATS) asm volatile("" : "+v"(sh));
                     unsigned pk0[2][4], pk1[2][4];
 #pragma unroll
                     for (int mi = 0; mi < 2; ++mi)
@@ -419,15 +427,6 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::NW == 4 ? 2 : 1) void conv1x1_ge
                                 // two elements per VALU instruction (v_pk_add_f32 / v_pk_fma_f32): the statistics
                                 // are VALU work the MFMAs wait for -- 4 instructions per output element cost as
                                 // much as the products themselves at K = 128
-                                // the shift as a REAL register pair.  Left to itself hipcc keeps the RT shifts in adjacent
-                                // registers and splats by operand selection (v_pk_add_f32 d, a, v[72:73] op_sel:[0,1]
-                                // neg_lo neg_hi for the odd one); with that form, at 2^20+ columns, ONE accumulate of lanes
-                                // 48-63 of the odd row tile took 0 instead of the shift in a few workgroups per launch --
-                                // identical y, (mean, M2) partials off by 1e-6, different from run to run, whichever way the
-                                // shift had been broadcast (ds_bpermute, v_permlane32_swap, with or without wait states).
-                                // Two moves per row tile and element group; repeated launches are bit-identical since.
-                                gm_f32x2 sh = {sShift[ri], sShift[ri]};
-                                asm volatile("" : "+v"(sh));
                                 const gm_f32x2 da = gm_f32x2{__uint_as_float(p0 << 16), __uint_as_float(p0 & 0xffff0000u)} - sh;
                                 const gm_f32x2 db = gm_f32x2{__uint_as_float(p1 << 16), __uint_as_float(p1 & 0xffff0000u)} - sh;
                                 sS[ri] += da;
