@@ -21,6 +21,7 @@ def test_wgrad_staging_registers_are_left_alone_by_the_compiler():
                          stderr=subprocess.STDOUT, text=True)
     assert res.returncode == 0, res.stdout
     assert "contract holds for 2 instantiations" in res.stdout
+    assert "no high-register splat in a packed subtraction" in res.stdout
 
 
 _FAKE = """
@@ -50,3 +51,11 @@ def test_checker_flags_violations():
     _, errs = tool.check(_FAKE.format(extra="", agpr=16, vgpr=224))
     assert len(errs) == 2
     assert tool.check("nothing here")[1]
+
+
+def test_checker_flags_the_high_register_splat():
+    tool = _tool()
+    good = "_ZN5grafp19conv1x1_gemm_kernelIfoo: ; @x\n\tv_pk_add_f32 v[0:1], v[0:1], v[2:3] neg_lo:[0,1] neg_hi:[0,1]\n\ts_endpgm\n"
+    bad = good.replace("v[2:3] neg_lo", "v[2:3] op_sel:[0,1] neg_lo")
+    assert tool.check_gemm_splat(good) == (1, [])
+    assert len(tool.check_gemm_splat(bad)[1]) == 1

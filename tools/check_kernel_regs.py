@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""Build-time check of the register contract of wgrad_gr_kernel (grafp_amd/csrc/wgrad.hip).
+"""Build-time checks on the generated code: (1) the register contract of wgrad_gr_kernel (grafp_amd/csrc/wgrad.hip), (2) no
+high-register operand-selection splat in a packed-f32 subtraction of conv1x1_gemm_kernel (see check_gemm_splat).
+
+(1):
 
 That kernel keeps in-flight G-operand loads in the PHYSICAL registers v224-v255, named inside inline asm, and relies on
 `amdgpu_num_vgpr(224)` keeping the compiler out of them.  A compiler or flag change that breaks any of the following
@@ -63,6 +66,23 @@ def check(asm):
     return kernels, errors
 
 
+def check_gemm_splat(asm):
+    """conv1x1_gemm_kernel (gemm.hip): no packed-f32 subtraction may take its subtrahend by the HIGH-register splat of a
+    register pair (`v_pk_add_f32 d, a, v[n:n+1] op_sel:[0,1] neg_lo:[0,1] neg_hi:[0,1]`).  That is the form hipcc chose for
+    the statistics shift of the odd row tile when two shifts shared a pair; on gfx950 one accumulate of lanes 48-63 then
+    took 0 instead of the shift in a few workgroups per launch (round 3: run-to-run differences of the partial
+    statistics).  The kernel keeps the shift in a pair of its own; this check notices if a compiler change undoes that."""
+    errors, kernels = [], 0
+    for m in re.finditer(r"^(_ZN5grafp19conv1x1_gemm_kernel\w+):\s*;[^\n]*\n(.*?)^\s*s_endpgm", asm, flags=re.S | re.M):
+        kernels += 1
+        for ln in m.group(2).split("\n"):
+            if "v_pk_add_f32" in ln and "op_sel:[0,1]" in ln and "neg_lo:[0,1]" in ln:
+                errors.append(f"{m.group(1)[:60]}...: {ln.strip()}")
+    if kernels == 0:
+        errors.append("no conv1x1_gemm_kernel instantiation found in the assembly")
+    return kernels, errors
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--hipcc", default=os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"))
@@ -80,7 +100,19 @@ def main():
         print("REGISTER CONTRACT VIOLATED:", e)
     if not errors:
         print(f"wgrad_gr_kernel register contract holds for {kernels} instantiations")
-    return 1 if errors else 0
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "gemm.s")
+        res = subprocess.run([args.hipcc] + FLAGS + [os.path.join(CSRC, "gemm.hip"), "-o", out],
+                             stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if res.returncode != 0:
+            print(res.stdout)
+            return 2
+        gk, gerrors = check_gemm_splat(open(out).read())
+    for e in gerrors:
+        print("HIGH-REGISTER SPLAT IN A PACKED SUBTRACTION:", e)
+    if not gerrors:
+        print(f"conv1x1_gemm_kernel: no high-register splat in a packed subtraction ({gk} instantiations)")
+    return 1 if (errors or gerrors) else 0
 
 
 if __name__ == "__main__":
