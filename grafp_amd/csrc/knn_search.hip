@@ -27,6 +27,8 @@
 #include <math.h>
 
 #include "common.h"
+#include "dma_ring.h"
+#include "tuning.h"
 
 namespace grafp {
 
@@ -47,6 +49,18 @@ constexpr int SR_SUBCAP = SR_CAP / SR_NSUB;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            \
         __builtin_amdgcn_wave_barrier();                              \
     } while (0)
+
+// (database slice, query group) of this workgroup.  The grid is (slices, query groups); workgroups go to the 8 XCDs
+// round-robin in dispatch order (x fastest), so without a remap the query groups that stream the SAME slice sit on
+// different XCDs and every one of them pulls the slice through its own L2: at nq = 4096 the 256 MB bf16 copy was read 32
+// times from the memory side (5 TB/s, the bound of that launch).  With the remap an XCD owns whole slices: all query
+// groups of a slice run side by side on one L2 and the database crosses the fabric about once.
+__device__ __forceinline__ void search_block(int &split, int &qgroup) {
+    const int total = (int)(gridDim.x * gridDim.y);
+    const int v = xcd_remap((int)(blockIdx.x + gridDim.x * blockIdx.y), total);
+    split = v / (int)gridDim.y;
+    qgroup = v - split * (int)gridDim.y;
+}
 
 template <typename I>
 __device__ __forceinline__ bool lex_lt(float d1, I i1, float d2, I i2) {
@@ -245,9 +259,14 @@ __device__ __forceinline__ void stream_tiles(const float *__restrict__ db, const
 // query operand of the MFMA: B[k = 2s + half][j = l31]
 __device__ __forceinline__ void load_queries(const float *__restrict__ q, int qi, bool qvalid, int half,
                                              float (&bq)[64]) {
+    // row 0 stands in for a lane without a query: the loads are unconditional (64 in flight behind ONE wait -- written
+    // as `qvalid ? load : 0` every element became its own branch, load and vmcnt(0): 64 serial round trips, a fifth of a
+    // small-batch launch) and the value is dropped afterwards
     const float *qrow = q + (size_t)(qvalid ? qi : 0) * SR_D + half;
 #pragma unroll
-    for (int s = 0; s < 64; ++s) bq[s] = qvalid ? qrow[2 * s] : 0.0f;
+    for (int s = 0; s < 64; ++s) bq[s] = qrow[2 * s];
+#pragma unroll
+    for (int s = 0; s < 64; ++s) bq[s] = qvalid ? bq[s] : 0.0f;
 }
 
 // ---- launch 0: query norms, empty group minima, empty candidate lists ---------------------------------------------
@@ -279,8 +298,9 @@ __global__ __launch_bounds__(256, 2) void search_bound_kernel(const float *__res
     float *sDD = tile + TROWS * SR_LS;              // [TROWS]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int qw = wave % QW, rw = wave / QW;
-    const int split = blockIdx.x;
-    const int qi = (blockIdx.y * QW + qw) * 32 + l31;
+    int split, qgroup;
+    search_block(split, qgroup);
+    const int qi = (qgroup * QW + qw) * 32 + l31;
     const bool qvalid = qi < nq;
     const int64_t row_begin = (int64_t)split * rows_per_split;
     const int64_t row_end = (row_begin + rows_per_split < n_sample) ? row_begin + rows_per_split : n_sample;
@@ -332,8 +352,9 @@ __global__ __launch_bounds__(256, 2) void search_scan_kernel(const float *__rest
     float *sDD = tile + TROWS * SR_LS;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int qw = wave % QW, rw = wave / QW;
-    const int split = blockIdx.x;
-    const int qi = (blockIdx.y * QW + qw) * 32 + l31;
+    int split, qgroup;
+    search_block(split, qgroup);
+    const int qi = (qgroup * QW + qw) * 32 + l31;
     const bool qvalid = qi < nq;
     const int64_t row_begin = (int64_t)split * rows_per_split;
     const int64_t row_end = (row_begin + rows_per_split < n) ? row_begin + rows_per_split : n;
@@ -471,8 +492,10 @@ __global__ __launch_bounds__(256) void search_select_kernel(const float *__restr
 // Rearranged, the scan test per element is <q^,x^> >= A_q + H_row: one add and one compare.
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // native vector: stays in registers (uint4 went to scratch)
-constexpr int SB_TR = 128;           // rows per LDS tile
-constexpr int SB_LS = 272;           // bytes per LDS row (256 + 16: ds_read_b128 of 32 rows is conflict-free)
+constexpr int SB_TR = 64;            // rows per ring stage
+constexpr int SB_NS = 3;             // ring stages: two tiles in flight behind the one being multiplied
+constexpr int SB_STAGE = SB_TR * 256 + SB_TR * 4;   // rows (256 B, 16-byte pieces XOR-swizzled by row) + their norms
+constexpr int SB_PER = 5;            // LDS-DMA instructions per tile and wave: 4 x 1 KB of rows + 16 norms
 constexpr float SB_SLACK = 0.008f;
 
 __device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
@@ -490,176 +513,253 @@ __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float *__restric
 // query operand of the bf16 MFMA: lane (l31, half) holds dims 16 s + 8 half + 0..7 of query l31, s = 0..7
 __device__ __forceinline__ void load_queries_bf16(const float *__restrict__ q, int qi, bool qvalid, int half,
                                                   bf16x8 (&bq)[8]) {
-    const float *qrow = q + (size_t)(qvalid ? qi : 0) * SR_D + 8 * half;
+    typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));   // q is only promised 4-byte alignment
+    const f32x4_a4 *qrow = reinterpret_cast<const f32x4_a4 *>(q + (size_t)(qvalid ? qi : 0) * SR_D + 8 * half);
+    f32x4 raw[16];                           // unconditional loads, all in flight at once (see load_queries)
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        raw[2 * s] = qrow[4 * s];
+        raw[2 * s + 1] = qrow[4 * s + 1];
+    }
 #pragma unroll
     for (int s = 0; s < 8; ++s)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) bq[s][e] = qvalid ? (short)f32_to_bf16_rne(qrow[16 * s + e]) : (short)0;
+        for (int e = 0; e < 8; ++e)
+            bq[s][e] = qvalid ? (short)f32_to_bf16_rne(raw[2 * s + (e >> 2)][e & 3]) : (short)0;
 }
 
-// Tiles of SB_TR bf16 rows: HBM -> registers (one tile ahead) -> LDS; sH[row] = dd[row] * hscale (NaN past the end).
-// Wave (qw, rw) multiplies row blocks rw, rw + RW, ... of the tile with its 32 queries: on_block(t, rb, acc);
-// on_tile(t) runs once per tile on every thread at the quiescent point between the tile barriers.
-template <int QW, typename F, typename G>
+// Tiles of SB_TR bf16 rows through a ring of SB_NS LDS stages, filled by LDS-DMA (no registers, no LDS-write phase):
+// every wave issues its quarter of a tile two tiles ahead -- 4 x global_load_lds_dwordx4 (64 lanes x 16 B = 4 rows each)
+// and one dword DMA for 16 of the rows' norms -- and waits for it with a hand-counted vmcnt before the tile's barrier.
+// (A DMA instruction costs its wave 60-185 issue cycles: with two producer waves the other two stood at the barrier.)
+//   The register-prefetch form this replaces had ONE tile in flight and, through a conditional load the compiler
+//   drained on the spot, waited for it right after issuing it; its per-block code recycled one fragment register quad
+//   (read, wait, MFMA, eight times) and built 16 lane masks with 16 dependent scalar ORs: 12 000 cycles per 128-row
+//   tile at nq = 4096 against 3 000 of MFMA work.
+//   Measured and dropped: touching the lines of the tiles further ahead (one dword per 128-byte line) to pull them into
+//   L2 early -- nq = 4096 unchanged, nq = 41 scan 82 us against 60 (96 streams per XCD overflow its L2: every line is
+//   fetched twice).
+// LDS rows are 256 B unpadded; piece p of LDS row r holds piece p ^ (r & 15) of the database row (the DMA lane picks
+// its global address accordingly), so the 16-byte fragment reads of a lane group hit 16 different bank groups.
+// Wave (qw, rw) multiplies row blocks rw, rw + RW, ... of the tile with its NQS sets of 32 queries: on_block(t, rb, j, acc,
+// hv) per set j, hv = the norms of the lane's 16 accumulator rows (NaN past the end of the slice); on_tile(t) runs once
+// per tile on every thread at the quiescent point behind the tile barrier.
+template <int QW, int NQS, typename F, typename G>
 __device__ __forceinline__ void stream_tiles_bf16(const unsigned short *__restrict__ dbh, const float *__restrict__ dd,
-                                                  int64_t row_begin, int64_t row_end, unsigned char *tile, float *sH,
-                                                  float hscale, const bf16x8 (&bq)[8], F &&on_block, G &&on_tile) {
+                                                  int64_t row_begin, int64_t row_end, unsigned char *ring,
+                                                  const bf16x8 (&bq)[NQS][8], F &&on_block, G &&on_tile) {
     constexpr int RW = 4 / QW;
-    constexpr int NV = SB_TR * 16 / 256;   // uint4 per thread per tile
+    static_assert(SB_TR % (32 * RW) == 0 && SB_TR == 64, "one dword DMA covers the 64 norms of a tile");
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int rw = wave / QW;
     const int ntiles = row_end > row_begin ? (int)((row_end - row_begin + SB_TR - 1) / SB_TR) : 0;
+    if (ntiles == 0) return;
     const int nrows = (int)(row_end - row_begin);
-    const u32x4 *base4 = reinterpret_cast<const u32x4 *>(dbh) + row_begin * 16;
+    const unsigned lds0 = (unsigned)(uintptr_t)(gm_lptr)ring;
+    const unsigned char *rows = reinterpret_cast<const unsigned char *>(dbh) + row_begin * 256;
     const float *ddb = dd + row_begin;
-    u32x4 pf[NV];
-    float pdd = 0.0f;
-    auto prefetch = [&](int t) {
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);      // LDS-DMA bases travel in M0: scalar operands
+    const int sub = lane >> 4, pos = lane & 15;
+    auto issue = [&](int t, int stage) {              // this wave's quarter of tile t (clamped by the caller)
+        const unsigned st = __builtin_amdgcn_readfirstlane(lds0 + stage * SB_STAGE);
 #pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            const int item = tid + v * 256;
-            int lr = t * SB_TR + (item >> 4);
-            lr = lr < nrows ? lr : nrows - 1;          // rows past the end: any readable data, their sH is NaN
-            pf[v] = base4[(size_t)lr * 16 + (item & 15)];
+        for (int j = 0; j < 4; ++j) {
+            const int i = wave_u * 4 + j, r = 4 * i + sub;
+            int lr = t * SB_TR + r;
+            lr = lr < nrows ? lr : nrows - 1;          // rows past the end: any readable data, their norm becomes NaN
+            gm_dma16(rows + (size_t)lr * 256 + ((pos ^ (r & 15)) << 4), st + i * 1024);
         }
-        if (tid < SB_TR) {
-            const int lr = t * SB_TR + tid;
-            pdd = lr < nrows ? ddb[lr] * hscale : __builtin_nanf("");
-        }
+        int lr = t * SB_TR + wave_u * 16 + pos;        // norms of rows 16 w .. 16 w + 15: lanes 0-15 only
+        lr = lr < nrows ? lr : nrows - 1;
+        if (lane < 16) gm_dma4(ddb + lr, st + SB_TR * 256 + wave_u * 64);
     };
-    if (ntiles > 0) prefetch(0);
-    for (int t = 0; t < ntiles; ++t) {
-        __syncthreads();  // every wave is done reading the previous tile
-        on_tile(t);       // quiescent point: no wave is inside on_block, so workgroup state is uniform here
 #pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            const int item = tid + v * 256;
-            *reinterpret_cast<u32x4 *>(tile + (item >> 4) * SB_LS + (item & 15) * 16) = pf[v];
+    for (int t0 = 0; t0 < SB_NS - 1; ++t0) issue(t0 < ntiles ? t0 : ntiles - 1, t0);
+    int stage = 0;
+    for (int t = 0; t < ntiles; ++t) {
+        gm_wait_vm<(SB_NS - 2) * SB_PER>();                   // this wave's part of tile t has landed
+        __syncthreads();  // everybody's part has; every wave is done with tile t-1, whose stage is free again
+        on_tile(t);       // quiescent point: no wave is inside on_block, so workgroup state is uniform here
+        unsigned char *st = ring + stage * SB_STAGE;
+        float *sd = reinterpret_cast<float *>(st + SB_TR * 256);
+        if (t == ntiles - 1 && (nrows & (SB_TR - 1)) != 0) {   // uniform: the slice ends inside this tile
+            if (tid < SB_TR && t * SB_TR + tid >= nrows) sd[tid] = __builtin_nanf("");
+            __syncthreads();
         }
-        if (tid < SB_TR) sH[tid] = pdd;
-        __syncthreads();
-        if (t + 1 < ntiles) prefetch(t + 1);
+        const int free_stage = stage == 0 ? SB_NS - 1 : stage - 1;
+        issue(t + SB_NS - 1 < ntiles ? t + SB_NS - 1 : ntiles - 1, free_stage);
 #pragma unroll
         for (int rb = rw; rb < SB_TR / 32; rb += RW) {
-            const unsigned char *arow = tile + (rb * 32 + l31) * SB_LS + half * 16;
+            // all LDS reads of the block -- eight row fragments and the 16 norms of this lane's accumulator rows -- go
+            // out as one batch ahead of the MFMA chain (left alone, the compiler recycles ONE fragment register quad:
+            // read, wait, MFMA, eight times over, i.e. eight exposed LDS latencies per block)
+            const unsigned char *arow = st + (rb * 32 + l31) * 256;
             bf16x8 a[8];
 #pragma unroll
-            for (int s2 = 0; s2 < 8; ++s2) a[s2] = *reinterpret_cast<const bf16x8 *>(arow + s2 * 32);
-            f32x16 acc;
+            for (int s2 = 0; s2 < 8; ++s2)
+                a[s2] = *reinterpret_cast<const bf16x8 *>(arow + (((2 * s2 + half) ^ (l31 & 15)) << 4));
+            f32x4 hv4[4];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            for (int g = 0; g < 4; ++g) hv4[g] = *reinterpret_cast<const f32x4 *>(sd + rb * 32 + 8 * g + 4 * half);
+            __builtin_amdgcn_sched_barrier(0);
+            // NQS independent accumulator chains share every row fragment: with two query sets per wave a fragment
+            // read feeds two MFMAs and neither chain waits for the other's result
+            f32x16 acc[NQS];
 #pragma unroll
-            for (int s2 = 0; s2 < 8; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s2], bq[s2], acc, 0, 0, 0);
-            on_block(t, rb, acc);
+            for (int j = 0; j < NQS; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+#pragma unroll
+            for (int s2 = 0; s2 < 8; ++s2)
+#pragma unroll
+                for (int j = 0; j < NQS; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s2], bq[j][s2], acc[j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            float hv[16];                      // hv[r]: norm of row mfma_row(r, half) of the block (NaN past the end)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hv[r] = hv4[r >> 2][r & 3];
+#pragma unroll
+            for (int j = 0; j < NQS; ++j) on_block(t, rb, j, acc[j], hv);
         }
+        stage = stage + 1 == SB_NS ? 0 : stage + 1;
     }
+    gm_wait_vm<0>();      // nothing of this wave's is in flight when the caller reuses LDS or the wave ends
 }
 
-template <int QW>
-__global__ __launch_bounds__(256, 2) void search_bound_bf16_kernel(const unsigned short *__restrict__ dbh,
-                                                                   const float *__restrict__ dd, int64_t n_sample,
-                                                                   const float *__restrict__ q,
-                                                                   const float *__restrict__ qq, int nq,
-                                                                   int64_t rows_per_split, int *__restrict__ gmin) {
+template <int QW, int NQS>
+__global__ __launch_bounds__(256, NQS == 2 ? 2 : 3) void search_bound_bf16_kernel(
+    const unsigned short *__restrict__ dbh, const float *__restrict__ dd, int64_t n_sample, const float *__restrict__ q,
+    const float *__restrict__ qq, int nq, int64_t rows_per_split, int *__restrict__ gmin) {
     constexpr int RW = 4 / QW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    unsigned char *tile = reinterpret_cast<unsigned char *>(smem);
-    float *sH = reinterpret_cast<float *>(smem + SB_TR * SB_LS);
+    unsigned char *ring = reinterpret_cast<unsigned char *>(smem);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int qw = wave % QW, rw = wave / QW;
-    const int split = blockIdx.x;
-    const int qi = (blockIdx.y * QW + qw) * 32 + l31;
-    const bool qvalid = qi < nq;
+    int split, qgroup;
+    search_block(split, qgroup);
     const int64_t row_begin = (int64_t)split * rows_per_split;
     const int64_t row_end = (row_begin + rows_per_split < n_sample) ? row_begin + rows_per_split : n_sample;
-    bf16x8 bq[8];
-    load_queries_bf16(q, qi, qvalid, half, bq);
     const float kplus = 1.0f + SB_SLACK;
-    const float qk = qvalid ? qq[qi] * kplus : 0.0f;
-    float best = INFINITY;
-    stream_tiles_bf16<QW>(dbh, dd, row_begin, row_end, tile, sH, kplus, bq, [&](int, int rb, const f32x16 &acc) {
+    bf16x8 bq[NQS][8];
+    int qi[NQS];
+    float qk[NQS], bestm[NQS];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            // d~ + SLACK (qq + dd) >= d; rows past the end carry NaN and are ignored by fminf
-            const float up = __builtin_fmaf(-2.0f, acc[r], qk + sH[rb * 32 + mfma_row(r, half)]);
-            best = fminf(best, up);
-        }
+    for (int j = 0; j < NQS; ++j) {
+        qi[j] = ((qgroup * QW + qw) * NQS + j) * 32 + l31;
+        load_queries_bf16(q, qi[j], qi[j] < nq, half, bq[j]);
+        qk[j] = qi[j] < nq ? qq[qi[j]] * kplus : 0.0f;
+        bestm[j] = -INFINITY;
+    }
+    // d~ + SLACK (qq + dd) = qk - 2 (<q^,x^> - dd kplus / 2): the lane keeps the MAXIMUM of the bracket (one fma per
+    // element, maxima three at a time); rows past the end carry NaN and are ignored by fmaxf
+    const float nhk = -0.5f * kplus;
+    stream_tiles_bf16<QW, NQS>(dbh, dd, row_begin, row_end, ring, bq,
+                               [&](int, int, int j, const f32x16 &acc, const float (&hv)[16]) {
+        float e[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) e[r] = __builtin_fmaf(hv[r], nhk, acc[r]);
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) bestm[j] = fmaxf(fmaxf(bestm[j], e[r]), e[r + 1]);
     }, [](int) {});
-    best = best < 0.0f ? 0.0f : best;
-    if (qvalid && best < INFINITY) {
-        const int g = (((split * RW + rw) * 2) + half) & (SR_GROUPS - 1);
-        atomicMin(&gmin[(size_t)qi * SR_GROUPS + g], __float_as_int(best));
+#pragma unroll
+    for (int j = 0; j < NQS; ++j) {
+        float best = bestm[j] > -INFINITY ? __builtin_fmaf(-2.0f, bestm[j], qk[j]) : INFINITY;
+        best = best < 0.0f ? 0.0f : best;
+        if (qi[j] < nq && best < INFINITY) {
+            const int g = (((split * RW + rw) * 2) + half) & (SR_GROUPS - 1);
+            atomicMin(&gmin[(size_t)qi[j] * SR_GROUPS + g], __float_as_int(best));
+        }
     }
 }
 
 // Hits are rare (a few hundred per query over the whole database) but a returning global atomic costs microseconds,
 // so the MFMA loop only appends (query, row) to an LDS queue with an LDS atomic; the queue is drained to the
 // per-query candidate lists by all 256 threads at once -- at a tile boundary when it is half full, and at the end.
-constexpr int HB_CAP = 1024;      // 9 KB: with the 35 KB tile three workgroups still fit the 160 KB of a CU
+constexpr int HB_CAP = 384;       // 3.4 KB: with the 49 KB ring three workgroups still fit the 160 KB of a CU
 
-template <int QW>
-__global__ __launch_bounds__(256, 3) void search_scan_bf16_kernel(const unsigned short *__restrict__ dbh,
-                                                                  const float *__restrict__ dd, int64_t n,
-                                                                  const float *__restrict__ q,
-                                                                  const float *__restrict__ qq, int nq,
-                                                                  int64_t rows_per_split,
-                                                                  const float *__restrict__ thr,
-                                                                  int *__restrict__ cnt, int *__restrict__ cand_i,
-                                                                  float *__restrict__ cand_ip) {
+template <int QW, int NQS>
+__global__ __launch_bounds__(256, NQS == 2 ? 2 : 3) void search_scan_bf16_kernel(
+    const unsigned short *__restrict__ dbh, const float *__restrict__ dd, int64_t n, const float *__restrict__ q,
+    const float *__restrict__ qq, int nq, int64_t rows_per_split, const float *__restrict__ thr, int *__restrict__ cnt,
+    int *__restrict__ cand_i, float *__restrict__ cand_e) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    unsigned char *tile = reinterpret_cast<unsigned char *>(smem);
-    float *sH = reinterpret_cast<float *>(smem + SB_TR * SB_LS);
+    unsigned char *ring = reinterpret_cast<unsigned char *>(smem);
     __shared__ int hb_row[HB_CAP];
-    __shared__ float hb_ip[HB_CAP];
+    __shared__ float hb_e[HB_CAP];
     __shared__ unsigned char hb_q[HB_CAP];
     __shared__ int s_hits;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int qw = wave % QW;
-    const int split = blockIdx.x;
-    const int qbase = blockIdx.y * QW * 32;
-    const int qi = qbase + qw * 32 + l31;
-    const bool qvalid = qi < nq;
+    int split, qgroup;
+    search_block(split, qgroup);
+    const int qbase = qgroup * QW * NQS * 32;        // the workgroup's queries: qbase + [0, 32 QW NQS)
     const int64_t row_begin = (int64_t)split * rows_per_split;
     const int64_t row_end = (row_begin + rows_per_split < n) ? row_begin + rows_per_split : n;
     if (tid == 0) s_hits = 0;
-    bf16x8 bq[8];
-    load_queries_bf16(q, qi, qvalid, half, bq);
     // keep iff d~ - SLACK (qq + dd) <= bound  <=>  <q^,x^> >= A_q + H_row
     const float kminus = 1.0f - SB_SLACK;
-    const float a_q = qvalid ? 0.5f * (qq[qi] * kminus - thr[qi]) : INFINITY;
-    const int sub = blockIdx.x & (SR_NSUB - 1);
-    auto append = [&](int qg, int row, float ip) {            // to sub-list `sub` of the query's candidate list
+    bf16x8 bq[NQS][8];
+    float a_q[NQS];
+#pragma unroll
+    for (int j = 0; j < NQS; ++j) {
+        const int qi = qbase + (qw * NQS + j) * 32 + l31;
+        load_queries_bf16(q, qi, qi < nq, half, bq[j]);
+        a_q[j] = qi < nq ? 0.5f * (qq[qi] * kminus - thr[qi]) : INFINITY;
+    }
+    const int sub = split & (SR_NSUB - 1);
+    auto append = [&](int qg, int row, float ev) {            // to sub-list `sub` of the query's candidate list
         const int pos = atomicAdd(&cnt[qg * SR_NSUB + sub], 1);
         if (pos < SR_SUBCAP) {                                // beyond: the select kernel sees the count and rescans
             cand_i[(size_t)qg * SR_CAP + sub * SR_SUBCAP + pos] = row;
-            cand_ip[(size_t)qg * SR_CAP + sub * SR_SUBCAP + pos] = ip;   // <q^,x^>: bounds d from both sides later
+            cand_e[(size_t)qg * SR_CAP + sub * SR_SUBCAP + pos] = ev;   // E = <q^,x^> - dd kminus / 2: bounds d later
         }
     };
     auto drain = [&]() {                                      // all threads; callers provide the barriers around it
         const int nh = s_hits < HB_CAP ? s_hits : HB_CAP;
-        for (int e = tid; e < nh; e += 256) append(qbase + hb_q[e], hb_row[e], hb_ip[e]);
+        for (int e = tid; e < nh; e += 256) append(qbase + hb_q[e], hb_row[e], hb_e[e]);
     };
     __syncthreads();
-    stream_tiles_bf16<QW>(dbh, dd, row_begin, row_end, tile, sH, 0.5f * kminus, bq,
-                          [&](int t, int rb, const f32x16 &acc) {
-        unsigned long long any = 0;
+    const float hs = 0.5f * kminus;
+    // keep iff <q^,x^> - H_row >= A_q.  Common case: 16 fmas, their maximum three at a time (NaN past the end of the
+    // slice drops out of fmaxf), ONE compare and one branch per block -- no per-element lane masks, whose 16 dependent
+    // scalar ORs behind 16 VALU compares cost as much as the MFMA chain itself.
+    stream_tiles_bf16<QW, NQS>(dbh, dd, row_begin, row_end, ring, bq,
+                               [&](int t, int rb, int j, const f32x16 &acc, const float (&hv)[16]) {
+        float e[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r)                                 // NaN past the end: the compare fails
-            any |= __ballot(acc[r] >= a_q + sH[rb * 32 + mfma_row(r, half)]);
-        if (any != 0) {
-            const int slab0 = (int)(row_begin + (int64_t)t * SB_TR + rb * 32);
+        for (int r = 0; r < 16; ++r) e[r] = __builtin_fmaf(hv[r], -hs, acc[r]);
+        float m = fmaxf(e[0], e[1]);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if (acc[r] >= a_q + sH[rb * 32 + mfma_row(r, half)]) {
-                    const int row = slab0 + mfma_row(r, half);
+        for (int r = 2; r < 16; r += 2) m = fmaxf(fmaxf(m, e[r]), e[r + 1]);
+        if (__ballot(m >= a_q[j]) != 0) {
+            // A block holds a hit far more often than "rare" suggests -- 32 x 32 pairs against several hundred candidates
+            // per query in a million rows: every second block -- so this path must be cheap as well.  Only the lanes
+            // with a hit work: 16 compares into a bit mask (no branches), and in the usual case of ONE hit its value is
+            // the maximum already at hand.  (16 divergent `if`s, each with its own compare, exec save, branch and
+            // LDS atomic: 1 400 cycles per block with a hit, half of the kernel.)
+            if (m >= a_q[j]) {
+                unsigned bits = 0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) bits |= e[r] >= a_q[j] ? 1u << r : 0u;
+                const int slab0 = (int)(row_begin + (int64_t)t * SB_TR + rb * 32) + 4 * half;
+                const int ql = (qw * NQS + j) * 32 + l31;             // < 256: fits the queue's byte
+                auto push = [&](int r, float ev) {                    // row mfma_row(r, half) of the block
+                    const int row = slab0 + (r & 3) + 8 * (r >> 2);
                     const int slot = atomicAdd(&s_hits, 1);
                     if (slot < HB_CAP) {
                         hb_row[slot] = row;
-                        hb_ip[slot] = acc[r];
-                        hb_q[slot] = (unsigned char)(qw * 32 + l31);
+                        hb_e[slot] = ev;
+                        hb_q[slot] = (unsigned char)ql;
                     } else {
-                        append(qi, row, acc[r]);                      // queue full (tiny database, bound = +inf)
+                        append(qbase + ql, row, ev);                  // queue full (tiny database, bound = +inf)
                     }
+                };
+                if ((bits & (bits - 1)) == 0) {
+                    push(__builtin_ctz(bits), m);
+                } else {                                              // several hits in one lane's 16 rows: rare
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if ((bits >> r) & 1) push(r, e[r]);
                 }
             }
         }
@@ -676,8 +776,11 @@ __global__ __launch_bounds__(256, 3) void search_scan_bf16_kernel(const unsigned
 }
 
 // Per query: the k best of its candidates by (exact distance, id).
-// The scan left (row, <q^,x^>) pairs.  With t = qq + dd[row] the true distance lies in [lo, hi],
-//   lo = t (1 - SLACK) - 2 <q^,x^>,   hi = t (1 + SLACK) - 2 <q^,x^>,
+// The scan left (row, E) pairs, E = <q^,x^> - dd[row] (1 - SLACK) / 2 -- the very value its test compared.  With
+// t = qq + dd[row] the true distance lies in [lo, hi],
+//   lo = t (1 - SLACK) - 2 <q^,x^> = qq (1 - SLACK) - 2 E             (no dd[row]: phase B needs no gather for it),
+//   hi = t (1 + SLACK) - 2 <q^,x^> = qq (1 + SLACK) - 2 E + 2 SLACK dd[row]
+// (the roundings of these forms are a few 2^-24 (qq + dd), against the 1.7e-4 (qq + dd) SB_SLACK keeps in reserve),
 // so phase A takes the k-th smallest hi (at least k rows are truly that close: a bound ~10x tighter than the scan's)
 // and phase B evaluates the exact f32 distance -- the oracle's fmaf chain over the 512-byte row -- only for the rows
 // whose lo does not exceed it: a few dozen random row reads per query instead of several hundred.
@@ -719,7 +822,7 @@ __global__ __launch_bounds__(256) void search_select_exact_kernel(const float *_
                                                                   int64_t id_base, const float *__restrict__ thr,
                                                                   const int *__restrict__ cnt,
                                                                   const int *__restrict__ cand_i,
-                                                                  const float *__restrict__ cand_ip,
+                                                                  const float *__restrict__ cand_e,
                                                                   float *__restrict__ out_d,
                                                                   int64_t *__restrict__ out_i) {
     __shared__ float pend_d[4][WT_PEND];
@@ -753,6 +856,8 @@ __global__ __launch_bounds__(256) void search_select_exact_kernel(const float *_
         return s2 * SR_SUBCAP + (e - s_off[s2]);
     };
     float thr2 = thr[qi];
+    const float kminus = 1.0f - SB_SLACK, kplus = 1.0f + SB_SLACK;
+    const float qhi = myqq * kplus, dspan = kplus - kminus;     // (the difference of two floats this close is exact)
     WaveTop top;
     float td;
     int ti;
@@ -766,8 +871,7 @@ __global__ __launch_bounds__(256) void search_select_exact_kernel(const float *_
             if (valid) {
                 const int sl = slot_of(e);
                 row = cand_i[(size_t)qi * SR_CAP + sl];
-                const float t = myqq + dd[row];
-                hi = __builtin_fmaf(-2.0f, cand_ip[(size_t)qi * SR_CAP + sl], t * (1.0f + SB_SLACK));
+                hi = __builtin_fmaf(dspan, dd[row], __builtin_fmaf(-2.0f, cand_e[(size_t)qi * SR_CAP + sl], qhi));
                 hi = hi < 0.0f ? 0.0f : hi;
             }
             top.push(valid, hi, row, k, lane);
@@ -781,7 +885,6 @@ __global__ __launch_bounds__(256) void search_select_exact_kernel(const float *_
     __syncthreads();                                       // sq visible; the merge buffers are free again
     // phase B: exact distances of the rows that can still be among the k best
     top.init(pend_d[wave], pend_i[wave], thr2);
-    const float kminus = 1.0f - SB_SLACK;
     for (int64_t e0 = 0; e0 < total; e0 += 256) {
         const int64_t e = e0 + tid;
         bool need = e < total;
@@ -790,7 +893,7 @@ __global__ __launch_bounds__(256) void search_select_exact_kernel(const float *_
             if (listed) {
                 const int sl = slot_of((int)e);
                 row = cand_i[(size_t)qi * SR_CAP + sl];
-                const float lo = __builtin_fmaf(-2.0f, cand_ip[(size_t)qi * SR_CAP + sl], (myqq + dd[row]) * kminus);
+                const float lo = __builtin_fmaf(-2.0f, cand_e[(size_t)qi * SR_CAP + sl], myqq * kminus);   // no dd[row]
                 need = lo <= thr2;
             } else {
                 row = e;
@@ -1063,11 +1166,16 @@ extern "C" int grafp_knn_search_l2_pre(const float *db, const void *db_bf16, con
     hipStream_t s = (hipStream_t)stream;
     // measured crossovers (1M x 128): the 1x4 shape only pays for a handful of queries (nq=16: 136 vs 127 us, nq=32:
     // 168 vs 143 us for the 2x2 shape)
-    const int qw = nq <= 8 ? 1 : (nq <= 64 ? 2 : 4), rw = 4 / qw;
-    const int qgroups = (nq + 32 * qw - 1) / (32 * qw);
+    const int qw = nq <= 64 ? 2 : 4, rw = 4 / qw;      // (the 1x4 shape went with the 64-row ring stages)
+    // two query sets per wave (256 queries per workgroup, two workgroups per CU) once there are several query groups:
+    // every row fragment read from LDS feeds two independent MFMA chains and the database crosses L2 half as often
+    // (measured, 1M x 128, nq = 4096: 1.71 ms against 1.64 with one set -- the shipping plan is one set; the other stays
+    // reachable in the measurement build)
+    const int nqs = GRAFP_TUNE_INT("GRAFP_SEARCH_NQS", 1) == 2 && qw == 4 ? 2 : 1;
+    const int qgroups = (nq + 32 * qw * nqs - 1) / (32 * qw * nqs);
     int splits, b_splits;
     int64_t rps, b_rps;
-    int64_t want = 768 / qgroups;
+    int64_t want = (nqs == 2 ? 512 : 768) / qgroups;
     split_rows(n, SB_TR, want < 1 ? 1 : want, &splits, &rps);
     int64_t b_rows = n / 16 > 65536 ? n / 16 : 65536;
     if (b_rows > n) b_rows = n;
@@ -1081,25 +1189,25 @@ extern "C" int grafp_knn_search_l2_pre(const float *db, const void *db_bf16, con
     int *cnt = (int *)w;                    w += align256((size_t)nq * SR_NSUB * sizeof(int));
     int *gmin = (int *)w;                   w += align256((size_t)nq * SR_GROUPS * sizeof(int));
     int *cand_i = (int *)w;                 w += align256((size_t)nq * SR_CAP * sizeof(int));
-    float *cand_ip = (float *)w;
+    float *cand_e = (float *)w;
     const int64_t ng = (int64_t)nq * SR_GROUPS;
     hipLaunchKernelGGL(search_init_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, s, q, nq, qq, gmin, cnt);
-    const size_t lds = (size_t)SB_TR * SB_LS + SB_TR * sizeof(float);
+    const size_t lds = (size_t)SB_NS * SB_STAGE;
     const dim3 grid_b(b_splits, qgroups), grid(splits, qgroups);
     const unsigned short *dbh = (const unsigned short *)db_bf16;
-#define SB_LAUNCH(QW)                                                                                               \
-    hipLaunchKernelGGL(search_bound_bf16_kernel<QW>, grid_b, dim3(256), lds, s, dbh, db_sqnorm, b_rows, q,          \
-                       (const float *)qq, nq, b_rps, gmin);                                                         \
+#define SB_LAUNCH(QW, NQS)                                                                                          \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(search_bound_bf16_kernel<QW, NQS>), grid_b, dim3(256), lds, s, dbh,          \
+                       db_sqnorm, b_rows, q, (const float *)qq, nq, b_rps, gmin);                                   \
     hipLaunchKernelGGL(search_thr_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, (const int *)gmin, nq, k, thr);      \
-    hipLaunchKernelGGL(search_scan_bf16_kernel<QW>, grid, dim3(256), lds, s, dbh, db_sqnorm, n, q,                  \
-                       (const float *)qq, nq, rps, (const float *)thr, cnt, cand_i, cand_ip)
-    if (qw == 1) { SB_LAUNCH(1); }
-    else if (qw == 2) { SB_LAUNCH(2); }
-    else { SB_LAUNCH(4); }
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(search_scan_bf16_kernel<QW, NQS>), grid, dim3(256), lds, s, dbh, db_sqnorm,  \
+                       n, q, (const float *)qq, nq, rps, (const float *)thr, cnt, cand_i, cand_e)
+    if (qw == 2) { SB_LAUNCH(2, 1); }
+    else if (nqs == 1) { SB_LAUNCH(4, 1); }
+    else { SB_LAUNCH(4, 2); }
 #undef SB_LAUNCH
     GRAFP_CHECK_LAUNCH("search_bound_bf16_kernel / search_scan_bf16_kernel");
     hipLaunchKernelGGL(search_select_exact_kernel, dim3(nq), dim3(256), 0, s, db, db_sqnorm, n, q, (const float *)qq, nq,
-                       k, id_base, (const float *)thr, (const int *)cnt, (const int *)cand_i, (const float *)cand_ip,
+                       k, id_base, (const float *)thr, (const int *)cnt, (const int *)cand_i, (const float *)cand_e,
                        out_dist, out_ids);
     GRAFP_CHECK_LAUNCH("search_select_exact_kernel");
     return GRAFP_OK;
