@@ -538,7 +538,10 @@ __device__ __forceinline__ void load_queries_bf16(const float *__restrict__ q, i
 //   tile at nq = 4096 against 3 000 of MFMA work.
 //   Measured and dropped: touching the lines of the tiles further ahead (one dword per 128-byte line) to pull them into
 //   L2 early -- nq = 4096 unchanged, nq = 41 scan 82 us against 60 (96 streams per XCD overflow its L2: every line is
-//   fetched twice).
+//   fetched twice); the DMA instructions issued from inside the MFMA chain instead of in front of the blocks (neutral).
+//   Where a tile's ~4 000 cycles per wave go at nq = 4096 (s_memtime, three workgroups per CU): LDS fragment batches
+//   ~650, MFMA chains ~510, DMA issue ~380, barrier + DMA wait ~430, block tests ~130 each and ~650 for the every second
+//   block that holds a hit.
 // LDS rows are 256 B unpadded; piece p of LDS row r holds piece p ^ (r & 15) of the database row (the DMA lane picks
 // its global address accordingly), so the 16-byte fragment reads of a lane group hit 16 different bank groups.
 // Wave (qw, rw) multiplies row blocks rw, rw + RW, ... of the tile with its NQS sets of 32 queries: on_block(t, rb, j, acc,
@@ -831,6 +834,8 @@ __global__ __launch_bounds__(256) void search_select_exact_kernel(const float *_
     __shared__ int wtop_i[4][32];
     __shared__ float sq[SR_D];
     __shared__ float s_thr2;
+    __shared__ int need_rows[SR_CAP];                      // every listed candidate fits: no overflow case
+    __shared__ int s_nneed;
     const int qi = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     if (tid < SR_D) sq[tid] = q[(size_t)qi * SR_D + tid];
     __shared__ int s_off[SR_NSUB + 1];
@@ -848,7 +853,6 @@ __global__ __launch_bounds__(256) void search_select_exact_kernel(const float *_
     __syncthreads();
     const int c = s_off[SR_NSUB];
     const bool listed = c >= 0;                            // else: a sub-list overflowed -> exact rescan of every row
-    const int64_t total = listed ? (int64_t)c : n;
     auto slot_of = [&](int e) {                            // flat candidate index -> slot in the query's list
         int s2 = 0;
 #pragma unroll
@@ -863,18 +867,28 @@ __global__ __launch_bounds__(256) void search_select_exact_kernel(const float *_
     int ti;
     if (listed) {                                          // phase A: k-th smallest upper bound
         top.init(pend_d[wave], pend_i[wave], INFINITY);
-        for (int e0 = 0; e0 < c; e0 += 256) {
-            const int e = e0 + tid;
-            const bool valid = e < c;
-            float hi = INFINITY;
-            int row = 0;
-            if (valid) {
-                const int sl = slot_of(e);
-                row = cand_i[(size_t)qi * SR_CAP + sl];
-                hi = __builtin_fmaf(dspan, dd[row], __builtin_fmaf(-2.0f, cand_e[(size_t)qi * SR_CAP + sl], qhi));
-                hi = hi < 0.0f ? 0.0f : hi;
+        // four candidates per thread and round, every load of a kind in flight at once (indices clamped to the last
+        // candidate instead of branching around the loads): a list of 600 costs two dependent round trips, not six
+        for (int e0 = 0; e0 < c; e0 += 4 * 256) {
+            int row[4];
+            float ev[4], ddv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + u * 256 + tid;
+                const size_t sl = (size_t)qi * SR_CAP + slot_of(e < c ? e : c - 1);
+                row[u] = cand_i[sl];
+                ev[u] = cand_e[sl];
             }
-            top.push(valid, hi, row, k, lane);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ddv[u] = dd[row[u]];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (e0 + u * 256 < c) {                    // uniform: push is a wave-level call
+                    float hi = __builtin_fmaf(dspan, ddv[u], __builtin_fmaf(-2.0f, ev[u], qhi));
+                    hi = hi < 0.0f ? 0.0f : hi;
+                    top.push(e0 + u * 256 + tid < c, hi, row[u], k, lane);
+                }
+            }
         }
         if (top.pc > 0) top.fold(k, lane);
         block_merge_tops(top, wtop_d, wtop_i, wave, lane, td, ti);
@@ -885,40 +899,61 @@ __global__ __launch_bounds__(256) void search_select_exact_kernel(const float *_
     __syncthreads();                                       // sq visible; the merge buffers are free again
     // phase B: exact distances of the rows that can still be among the k best
     top.init(pend_d[wave], pend_i[wave], thr2);
-    for (int64_t e0 = 0; e0 < total; e0 += 256) {
-        const int64_t e = e0 + tid;
-        bool need = e < total;
-        int64_t row = 0;
-        if (need) {
-            if (listed) {
-                const int sl = slot_of((int)e);
-                row = cand_i[(size_t)qi * SR_CAP + sl];
-                const float lo = __builtin_fmaf(-2.0f, cand_e[(size_t)qi * SR_CAP + sl], myqq * kminus);   // no dd[row]
-                need = lo <= thr2;
-            } else {
-                row = e;
-            }
-        }
-        float d = INFINITY;
-        if (need) {
-            // the whole row is requested before the dependent fmaf chain starts (every lane reads a different row)
-            f32x4 xr[SR_D / 4];
-            const f32x4 *rp = reinterpret_cast<const f32x4 *>(db) + row * (SR_D / 4);
+    auto exact = [&](int64_t row) {                        // the oracle's chain over the 512-byte row
+        // the whole row is requested before the dependent fmaf chain starts (every lane reads a different row)
+        f32x4 xr[SR_D / 4];
+        const f32x4 *rp = reinterpret_cast<const f32x4 *>(db) + row * (SR_D / 4);
 #pragma unroll
-            for (int c4 = 0; c4 < SR_D / 4; ++c4) xr[c4] = rp[c4];
-            const float ddr = dd[row];
-            float ip = 0.0f;
+        for (int c4 = 0; c4 < SR_D / 4; ++c4) xr[c4] = rp[c4];
+        const float ddr = dd[row];
+        float ip = 0.0f;
 #pragma unroll
-            for (int c4 = 0; c4 < SR_D / 4; ++c4) {
-                ip = __builtin_fmaf(xr[c4][0], sq[4 * c4 + 0], ip);
-                ip = __builtin_fmaf(xr[c4][1], sq[4 * c4 + 1], ip);
-                ip = __builtin_fmaf(xr[c4][2], sq[4 * c4 + 2], ip);
-                ip = __builtin_fmaf(xr[c4][3], sq[4 * c4 + 3], ip);
-            }
-            d = (myqq + ddr) - 2.0f * ip;
-            d = d < 0.0f ? 0.0f : d;
+        for (int c4 = 0; c4 < SR_D / 4; ++c4) {
+            ip = __builtin_fmaf(xr[c4][0], sq[4 * c4 + 0], ip);
+            ip = __builtin_fmaf(xr[c4][1], sq[4 * c4 + 1], ip);
+            ip = __builtin_fmaf(xr[c4][2], sq[4 * c4 + 2], ip);
+            ip = __builtin_fmaf(xr[c4][3], sq[4 * c4 + 3], ip);
         }
-        top.push(need, d, (int)row, k, lane);
+        const float d = (myqq + ddr) - 2.0f * ip;
+        return d < 0.0f ? 0.0f : d;
+    };
+    if (listed) {
+        // the rows still in question (lo <= the bound of phase A: a few dozen of the several hundred) are compacted
+        // into an LDS list first, then fetched one per thread side by side -- picked out of the candidate rounds where
+        // they stand, every round paid a full row-fetch latency for its two or three scattered lanes
+        const float qlo = myqq * kminus;
+        if (tid == 0) s_nneed = 0;
+        __syncthreads();
+        for (int e0 = 0; e0 < c; e0 += 4 * 256) {
+            int row[4];
+            float ev[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + u * 256 + tid;
+                const size_t sl = (size_t)qi * SR_CAP + slot_of(e < c ? e : c - 1);
+                row[u] = cand_i[sl];
+                ev[u] = cand_e[sl];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (e0 + u * 256 + tid < c && __builtin_fmaf(-2.0f, ev[u], qlo) <= thr2)    // lo: no dd[row] needed
+                    need_rows[atomicAdd(&s_nneed, 1)] = row[u];
+        }
+        __syncthreads();
+        const int nneed = s_nneed;
+        for (int i0 = 0; i0 < nneed; i0 += 256) {
+            const bool need = i0 + tid < nneed;
+            const int row = need ? need_rows[i0 + tid] : 0;
+            const float d = need ? exact(row) : INFINITY;
+            top.push(need, d, row, k, lane);
+        }
+    } else {
+        for (int64_t e0 = 0; e0 < n; e0 += 256) {
+            const int64_t row = e0 + tid;
+            const bool need = row < n;
+            const float d = need ? exact(row) : INFINITY;
+            top.push(need, d, (int)row, k, lane);
+        }
     }
     if (top.pc > 0) top.fold(k, lane);
     block_merge_tops(top, wtop_d, wtop_i, wave, lane, td, ti);

@@ -416,7 +416,7 @@ def _planted(n, nq, seed, noise=0.05):
 
 
 @pytest.mark.parametrize("n,nq,k", [(1000, 1, 20), (1000, 5, 1), (5000, 41, 20), (5000, 70, 20), (20000, 300, 20),
-                                     (777, 33, 32), (129, 64, 7), (50000, 41, 20)])
+                                     (777, 33, 32), (129, 64, 7), (50000, 41, 20), (30000, 1100, 20)])
 def test_search_bit_exact_vs_c_oracle(dev, n, nq, k):
     from grafp_amd import ops
     from oracle import native
