@@ -250,13 +250,19 @@ template <int WR_, int WM_, int RT_, int CT_, int NS_, int KC_ = 64> struct WgCf
     static constexpr int RP256 = 256 / ROWB;                       // tile rows per 256 B = per pass over the 64 banks
     static constexpr int G_BYTES = TO * ROWB, X_BYTES = TC * ROWB, STAGE = G_BYTES + X_BYTES;
     static constexpr int G_DMA = TO / RPD / NW, X_DMA = TC / RPD / NW;   // DMA instructions per wave and chunk
-    static_assert(KC_ == 64 || KC_ == 32, "row pieces of 128 or 64 bytes");
+    static_assert(KC_ == 128 || KC_ == 64 || KC_ == 32, "row pieces of 256, 128 or 64 bytes");
     static_assert(TO % (RPD * NW) == 0 && TC % (RPD * NW) == 0, "whole DMA instructions per wave");
     // slot s of row r lives at slot s ^ swz(r): a 16-lane ds_read_b128 group (16 consecutive rows, one slot) then
     // covers every bank exactly once -- 128-byte rows: 2 rows x 8 slots, 64-byte rows: 4 rows x 4 slots per 256 B
     static __device__ __forceinline__ int swz(int row) { return (row / RP256) & (SLOTS - 1); }
 };
 typedef WgCfg<2, 2, 1, 1, 4> WgT;
+// 256-byte row pieces for the layers whose rows lie megabytes apart (stage 0-1 at 1024 pairs per GPU): at a 4 MB row
+// stride LDS-DMA pieces of 128 bytes stream at 4.1-4.7 TB/s, 256-byte pieces at 4.9-6.3 (rowpiece_read_bench) -- the
+// wave's time goes into ISSUING the DMA instructions against the back-pressure of the memory pipeline (s_memtime: 2 100
+// of 3 100 cycles per chunk), so ring depth does not matter there (3, 4, 5 stages, 8 x 64-byte: equal) and the piece does
+typedef WgCfg<2, 2, 1, 1, 2, 128> WgT128;                          // 64 x 64, 2 x 32 KB, 2 workgroups per CU
+typedef WgCfg<2, 2, 2, 2, 2, 128> WgS128;                          // 128 x 128, 2 x 64 KB, 1 workgroup per CU
 typedef WgCfg<2, 2, 2, 2, 2> WgS;
 typedef WgCfg<2, 4, 4, 2, 2> WgL;
 // 64-byte row pieces: the same LDS holds twice as many chunks, i.e. twice the loads in flight per workgroup -- what the
@@ -579,16 +585,17 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::NW == 4 ? 2 : 1) __attribute__((
 }
 
 struct WgDmaPlan {
-    int cfg;                      // 0 = T (64 x 64), 1 = S (128 x 128), 2 = L (256 x 256), 3 = S32, 4 = M32 (256 x 128), 5 = L32
+    int cfg;                      // 0 = T (64 x 64), 1 = S (128 x 128), 2 = L (256 x 256), 3 = S32, 4 = M32 (256 x 128), 5 = L32,
+                                  // 6 = SG, 7 = LG (G through registers), 8 = T128 (64 x 64, 256-byte row pieces), 10 = S128
     int to, tc, tiles_o, tiles_c, slices_view, nslices;
     int64_t cols;
 };
-// tile: -1 = the measured heuristic below; 0 ... 7 = that configuration (T, S, L, S32, M32, L32, SG, LG); 9 = the
+// tile: -1 = the measured heuristic below; 0 ... 8, 10 = that configuration (T, S, L, S32, M32, L32, SG, LG, T128; S128); 9 = the
 // register-staged split-K kernel of round 1 (wgrad_partial_kernel).  A per-call argument of the *_tile entry points
 // (tests force every configuration on small cases); GRAFP_WGRAD_TILE only in measurement builds (tuning.h).
 static int wg_tile(int tile) {
     if (tile < 0) tile = GRAFP_TUNE_INT("GRAFP_WGRAD_TILE", -1);
-    return ((tile >= 0 && tile <= 7) || tile == 9) ? tile : -1;
+    return (tile >= 0 && tile <= 10) ? tile : -1;
 }
 static bool wgrad_dma_ok(int cout_g, int cin_g, int64_t M, int views, int tile) {
     return wg_tile(tile) != 9 && cout_g % 32 == 0 && cin_g % 32 == 0 && views >= 1 && M % views == 0 &&
@@ -627,9 +634,26 @@ static WgDmaPlan wgrad_dma_plan(int cout_g, int cin_g, int groups, int64_t M, in
             p.cfg = opbytes >= 750e6 ? 6 : 5;
         }
     }
+    // 256-byte row pieces (T128) for the small outputs of stages 0-1 from 2^19 columns on (tools/gemm_bench.py --wgrad with
+    // the tile forced, 512 / 1024 / 2048 clip-views: 64-row layers -3 ... -25 %, 128 x 128 -5 ... -13 %, the grouped
+    // convolution of stage 0 -8 ... -15 %, that of stage 1 -30 % at 2048 clip-views but +24 % at 1024; equal at 256)
+    const bool p256 = GRAFP_TUNE_INT("GRAFP_WGRAD_NO_P256", 0) == 0;          // A/B: without the 256-byte-piece tiles
+    if (p256 && M >= (1 << 19)) {
+        if (groups == 1 && (lo <= 64 || outs <= 128 * 128)) p.cfg = 8;
+        if (groups > 1 && (cout_g <= 32 || (cout_g <= 64 && opbytes >= 750e6))) p.cfg = 8;
+    }
+    // ... and the 128 x 128 tile on 256-byte pieces (S128, one workgroup per CU) for the next size class, 128 x 256 ...
+    // 256 x 256 outputs from 250 MB of operands: -9 ... -28 % at 1024 / 2048 clip-views (stage 1 fc2 / FFN, stage 2 fc1);
+    // the grouped convolution of stage 2 only at 2048 clip-views (-20 %; +15 % at 1024).  Larger outputs lose 10-30 %.
+    if (p256 && !pro) {
+        if (groups == 1 && outs > 128 * 128 && outs <= 256 * 256 && opbytes >= 250e6) p.cfg = 10;
+        if (groups > 1 && cout_g == 128 && cin_g == 128 && opbytes >= 750e6) p.cfg = 10;
+    }
     const int forced = wg_tile(tile);
-    if (forced >= 0 && forced <= 7 && !(pro && forced >= 6)) p.cfg = forced;
-    static const int tile_o[8] = {64, 128, 256, 128, 256, 256, 128, 256}, tile_c[8] = {64, 128, 256, 128, 128, 256, 128, 256};
+    if (forced >= 0 && forced != 9 && !(pro && (forced == 6 || forced == 7))) p.cfg = forced;
+    if (p.cfg == 8 && (M / views) % 128 != 0) p.cfg = 0;          // T128 / S128 need whole 128-column chunks
+    if (p.cfg == 10 && (M / views) % 128 != 0) p.cfg = 1;
+    static const int tile_o[11] = {64, 128, 256, 128, 256, 256, 128, 256, 64, 0, 128}, tile_c[11] = {64, 128, 256, 128, 128, 256, 128, 256, 64, 0, 128};
     p.to = tile_o[p.cfg];
     p.tc = tile_c[p.cfg];
     p.tiles_o = (cout_g + p.to - 1) / p.to;
@@ -641,16 +665,17 @@ static WgDmaPlan wgrad_dma_plan(int cout_g, int cin_g, int groups, int64_t M, in
     // all layers at 256 clip-views, -5 % at 512 against two rounds; one workgroup per CU
     // for the 256 x 256 tiles -- a second round doubles their partial sums (128 slices x 1 MB written and read back
     // against 1.3 GB of operands) and was 5-30 % slower on every shape (LG at 2048 clip-views: 16.4 -> 15.0 ms per step)
-    static const int64_t targets[8] = {512, 512, 512, 1024, 512, 256, 512, 256};
+    static const int64_t targets[11] = {512, 512, 512, 1024, 512, 256, 512, 256, 512, 0, 256};
     int64_t target = targets[p.cfg];
-    if (p.cfg <= 1 && opbytes >= 750e6) target = 1024;        // the small tiles at 1024 pairs per GPU: two rounds (+2 %)
+    if ((p.cfg <= 1 || p.cfg == 8) && opbytes >= 750e6) target = 1024;        // the small tiles at 1024 pairs per GPU: two rounds (+2 %)
     if (GRAFP_TUNE_INT("GRAFP_WGRAD_TARGET", 0) > 0) target = GRAFP_TUNE_INT("GRAFP_WGRAD_TARGET", 0);
     int64_t sv = (target + tiles * views - 1) / (tiles * views);
     const int64_t max_sv = (Mv / 64 + 7) / 8;
     if (sv > max_sv) sv = max_sv;
     if (sv < 1) sv = 1;
     int64_t cols = (Mv + sv - 1) / sv;
-    cols = (cols + 63) / 64 * 64;
+    const int64_t kc = p.cfg == 8 || p.cfg == 10 ? 128 : 64;
+    cols = (cols + kc - 1) / kc * kc;
     p.cols = cols;
     p.slices_view = (int)((Mv + cols - 1) / cols);
     p.nslices = p.slices_view * views;
@@ -790,6 +815,8 @@ extern "C" int grafp_conv1x1_wgrad_tile_bf16(const void *grad_out, const void *x
         if (pro_tab) {
             switch (p.cfg) {
             case 0: WG_LAUNCH(WgT, true); break;
+            case 8: WG_LAUNCH(WgT128, true); break;
+            case 10: WG_LAUNCH(WgS128, true); break;
             case 1: WG_LAUNCH(WgS, true); break;
             case 2: WG_LAUNCH(WgL, true); break;
             case 3: WG_LAUNCH(WgS32, true); break;
@@ -801,6 +828,8 @@ extern "C" int grafp_conv1x1_wgrad_tile_bf16(const void *grad_out, const void *x
             case 6: WG_LAUNCH_GR(WgSG); break;
             case 7: WG_LAUNCH_GR(WgLG); break;
             case 0: WG_LAUNCH(WgT, false); break;
+            case 8: WG_LAUNCH(WgT128, false); break;
+            case 10: WG_LAUNCH(WgS128, false); break;
             case 1: WG_LAUNCH(WgS, false); break;
             case 2: WG_LAUNCH(WgL, false); break;
             case 3: WG_LAUNCH(WgS32, false); break;

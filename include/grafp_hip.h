@@ -331,7 +331,8 @@ int grafp_conv1x1_wgrad_bf16(const void *grad_out, const void *x, int Cout, int 
  * with their own table entries (a split-K slice never straddles two); pro_tab NULL = plain weight gradient. */
 size_t grafp_conv1x1_wgrad_pro_workspace(int Cout, int Cin, int groups, int64_t M, int views);
 /* The launch plan of the weight gradient for this shape (as grafp_conv1x1_gemm_plan): info (host, 8 ints) =
- * {tile configuration (0 T, 1 S, 2 L, 3 S32, 4 M32, 5 L32, 6 SG, 7 LG; -1 = the register-staged kernel of odd shapes),
+ * {tile configuration (0 T, 1 S, 2 L, 3 S32, 4 M32, 5 L32, 6 SG, 7 LG, 8 T128, 10 S128; -1 = the register-staged kernel
+ *  of odd shapes),
  *  tile output rows, tile operand rows, split-K slices, output tiles, 0, 0, 0}. */
 int grafp_conv1x1_wgrad_plan(int Cout, int Cin, int groups, int64_t M, int views, int *info);
 int grafp_conv1x1_wgrad_pro_bf16(const void *grad_out, const void *x, int Cout, int Cin, int groups, int64_t M,
@@ -339,7 +340,8 @@ int grafp_conv1x1_wgrad_pro_bf16(const void *grad_out, const void *x, int Cout, 
                                  void *ws, size_t ws_bytes, grafp_stream_t stream);
 /* The same with the tile configuration as an explicit per-call argument (tile = -1: the measured rule, what the
  * entries above use; 0 ... 7: T 64x64, S 128x128, L 256x256, S32, M32 256x128, L32 (64-byte row pieces), SG, LG (G
- * operand through registers); 9: the register-staged split-K kernel).  The rule picks the wide configurations only at
+ * operand through registers); 8, 10: T128, S128 = T and S on 256-byte row pieces, for operand rows that lie megabytes
+ * apart; 9: the register-staged split-K kernel).  The rule picks the wide configurations only at
  * sizes a test cannot afford for every shape, so the tests force each one on small cases through this entry. */
 size_t grafp_conv1x1_wgrad_tile_workspace(int Cout, int Cin, int groups, int64_t M, int views, int tile);
 int grafp_conv1x1_wgrad_tile_bf16(const void *grad_out, const void *x, int Cout, int Cin, int groups, int64_t M,

@@ -184,7 +184,11 @@ def test_gemm_rejects_unsupported_shapes():
 
 # (cout, cin, groups, M, views): the three tile configurations (64 / 128 / 256), grouped, ragged rows, short slices
 WG_SHAPES = [(64, 64, 1, 8192, 2), (256, 64, 1, 16384, 2), (128, 128, 4, 8192, 2), (128, 256, 1, 4096, 1),
-             (1024, 256, 1, 2048, 2), (512, 2048, 1, 1024, 2), (96, 160, 1, 1280, 1), (64, 256, 1, 262144, 2)]
+             (1024, 256, 1, 2048, 2), (512, 2048, 1, 1024, 2), (96, 160, 1, 1280, 1), (64, 256, 1, 262144, 2),
+             # >= 2^19 columns: the rule picks the 256-byte-piece tile (T128) for the small outputs, grouped ones included
+             (64, 128, 1, 524288, 2), (128, 128, 4, 524288, 1),
+             # ... and the 128 x 128 tile on 256-byte pieces (S128) from 250 MB of operands
+             (128, 256, 1, 524288, 1)]
 
 
 @pytest.mark.parametrize("cout,cin,groups,M,views", WG_SHAPES)
@@ -214,8 +218,8 @@ def test_wgrad_dma(cout, cin, groups, M, views, pro):
     assert torch.equal(dw, ops.conv1x1_wgrad(g, x, cout, cin, groups, M, views, tab, ops.ACT_RELU if pro else ops.ACT_NONE))
 
 
-# T, S, L (128-byte pieces), S32, M32, L32 (64-byte pieces), SG, LG (G through registers)
-@pytest.mark.parametrize("tile", range(8))
+# T, S, L (128-byte pieces), S32, M32, L32 (64-byte pieces), SG, LG (G through registers), T128, S128 (256-byte pieces)
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 10])
 @pytest.mark.parametrize("cout,cin,groups,M,views", [(256, 64, 1, 16384, 2), (1024, 256, 1, 2048, 2), (512, 1024, 4, 1024, 2),
                                                      (96, 160, 1, 1280, 1), (256, 512, 1, 64, 1), (320, 256, 1, 4160, 1)])
 def test_wgrad_every_tile_configuration(tile, cout, cin, groups, M, views):
