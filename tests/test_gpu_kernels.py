@@ -466,9 +466,11 @@ def test_search_candidate_overflow_rescan(dev):
     assert (i[0].cpu().numpy() == np.arange(1000, 1020)).all()
 
 
-@pytest.mark.parametrize("n,nq", [(1, 1), (31, 2), (33, 33), (127, 65), (4097, 40), (70001, 7)])
+@pytest.mark.parametrize("n,nq", [(1, 1), (31, 2), (33, 33), (64, 64), (65, 65), (127, 65), (4097, 40), (8191, 129),
+                                  (70001, 7)])
 def test_search_ragged_sizes(dev, n, nq):
-    """Row counts around the tile (32/64/128 rows) and sample (64k rows) boundaries, k > n included."""
+    """Row counts around the tile (32/64/128 rows: the 64-row ring stage of the bf16 scan ends inside its last tile) and
+    sample (64k rows) boundaries, query counts around the wave-shape switches (64 / 65, 128 / 129), k > n included."""
     from grafp_amd import ops
     from oracle import native
     db, q, _ = _planted(max(n, 64), max(nq, 8), f"ragged{n}")
