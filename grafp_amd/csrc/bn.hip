@@ -394,7 +394,10 @@ constexpr int BN1_SYNC_STRIDE = 64;                    // ints between row count
 
 constexpr unsigned BN1_EMPTY = 0xffffffffu;            // "not published yet" (a NaN pattern real sums are steered away from)
 
-// Publishes this workgroup's partial pair into slot s of its row and waits until every slot of the row is filled.
+// Publishes this workgroup's partial pair into slot s of its row and waits until slots [w_lo, w_hi) of the row are filled:
+// a workgroup needs the partials of ITS group (view) only -- the statistics of the views are independent -- and just
+// chunk 0, which also writes the per-row results over all views, needs every slot.  With two views the wait is for the
+// slowest of half as many workgroups (the rate of these kernels falls with the chunks per row: 5.2 TB/s at 16, 3.7 at 128).
 // No read-modify-write sits on the critical path: a slot is ONE 8-byte write-through store, the wait is wave 0 polling
 // the row's S slots with L2-bypassing loads (the successful poll already holds the data).  Returns with sp[0..S) set.
 // The wait is BOUNDED and never traps: after `spin_limit` polls the slots that are still empty are left marked in sp
@@ -402,8 +405,8 @@ constexpr unsigned BN1_EMPTY = 0xffffffffu;            // "not published yet" (a
 // same summation order => the same bits), so a workgroup never depends on row-mates that are not resident -- other
 // kernels holding CUs (RCCL all-reduces overlapping backward, several ranks on one device, CU masks) cost time, not
 // correctness.  Returns the number of slots the caller has to fill in (workgroup-uniform).
-__device__ __forceinline__ int bn1_publish_and_wait(float a, float b, unsigned long long *slots_row, int s, int S,
-                                                    float2 *sp, int *n_missing, int spin_limit, int tid) {
+__device__ __forceinline__ int bn1_publish_and_wait(float a, float b, unsigned long long *slots_row, int s, int w_lo,
+                                                    int w_hi, float2 *sp, int *n_missing, int spin_limit, int tid) {
     if (tid == 0) {
         unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
         if (ua == BN1_EMPTY) ua = 0xfffffffeu;          // still a NaN, but not the marker
@@ -415,7 +418,7 @@ __device__ __forceinline__ int bn1_publish_and_wait(float a, float b, unsigned l
         int spins = 0;
         for (;;) {
             int missing = 0;
-            for (int i = tid; i < S; i += 64) {
+            for (int i = w_lo + tid; i < w_hi; i += 64) {
                 const unsigned long long v = __hip_atomic_load(slots_row + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((unsigned)v == BN1_EMPTY) ++missing;
                 sp[i] = make_float2(__uint_as_float((unsigned)v), __uint_as_float((unsigned)(v >> 32)));
@@ -512,9 +515,10 @@ __global__ __launch_bounds__(BN1_THREADS) void bn_fwd1_kernel(const T *__restric
     const float2 r = block_sum2<BN1_THREADS>(a, q, scratch, tid);
     unsigned long long *slots_row = reinterpret_cast<unsigned long long *>(sync + (size_t)gridDim.y * BN1_SYNC_STRIDE) + (size_t)c * S;
     int *counter = sync + (size_t)c * BN1_SYNC_STRIDE;
-    if (bn1_publish_and_wait(r.x, r.y, slots_row, s, S, sp, &n_missing, spin_limit, tid) > 0) {
+    const int w_lo = s == 0 ? 0 : grp * Sg, w_hi = s == 0 ? S : (grp + 1) * Sg;     // chunk 0 also writes the running stats
+    if (bn1_publish_and_wait(r.x, r.y, slots_row, s, w_lo, w_hi, sp, &n_missing, spin_limit, tid) > 0) {
         // row-mates that did not show up in time: their partial sums straight from the row (identical order and bits)
-        for (int i = 0; i < S; ++i) {
+        for (int i = w_lo; i < w_hi; ++i) {
             if (__float_as_uint(sp[i].x) != BN1_EMPTY) continue;            // LDS value: workgroup-uniform branch
             const int g2 = i / Sg;
             const float sh2 = BnIO<T>::ld1(row + (int64_t)g2 * Mg) + pb;
@@ -650,8 +654,9 @@ __global__ __launch_bounds__(BN1_THREADS) void bn_bwd1_kernel(const T *__restric
     const float2 r = block_sum2<BN1_THREADS>(sd, sdx, scratch, tid);
     unsigned long long *slots_row = reinterpret_cast<unsigned long long *>(sync + (size_t)gridDim.y * BN1_SYNC_STRIDE) + (size_t)c * S;
     int *counter = sync + (size_t)c * BN1_SYNC_STRIDE;
-    if (bn1_publish_and_wait(r.x, r.y, slots_row, s, S, sp, &n_missing, spin_limit, tid) > 0) {
-        for (int i = 0; i < S; ++i) {
+    const int w_lo = s == 0 ? 0 : grp * Sg, w_hi = s == 0 ? S : (grp + 1) * Sg;     // chunk 0 also writes dgamma / dbeta
+    if (bn1_publish_and_wait(r.x, r.y, slots_row, s, w_lo, w_hi, sp, &n_missing, spin_limit, tid) > 0) {
+        for (int i = w_lo; i < w_hi; ++i) {
             if (__float_as_uint(sp[i].x) != BN1_EMPTY) continue;
             const int g2 = i / Sg;
             const float mean2 = save_mean[c * G + g2], invstd2 = save_invstd[c * G + g2];
