@@ -600,8 +600,8 @@ __global__ __launch_bounds__(BN1_THREADS) void bn_fwd1_kernel(const T *__restric
     if (tid == 0) bn1_rearm(checkout, S, counter, slots_row);
 }
 
-template <typename T, int ITEMS>
-__global__ __launch_bounds__(BN1_THREADS) void bn_bwd1_kernel(const T *__restrict__ x, const T *__restrict__ dz,
+template <typename T, int ITEMS, int THREADS = BN1_THREADS>
+__global__ __launch_bounds__(THREADS) void bn_bwd1_kernel(const T *__restrict__ x, const T *__restrict__ dz,
                                                              int64_t M, int64_t Mg, int Sg, int G,
                                                              const float *__restrict__ pre_bias,
                                                              const float *__restrict__ gamma,
@@ -612,8 +612,8 @@ __global__ __launch_bounds__(BN1_THREADS) void bn_bwd1_kernel(const T *__restric
                                                              int *__restrict__ sync, T *__restrict__ dx,
                                                              float *__restrict__ dgamma, float *__restrict__ dbeta,
                                                              float *__restrict__ dpre_bias, int spin_limit) {
-    constexpr int W = BnIO<T>::W, CHUNK = BN1_THREADS * ITEMS * W;
-    __shared__ float2 scratch[BN1_THREADS / 64];
+    constexpr int W = BnIO<T>::W, CHUNK = THREADS * ITEMS * W;
+    __shared__ float2 scratch[THREADS / 64];
     __shared__ float2 sp[BN1_MAX_S];
     __shared__ int n_missing;
     const int c = blockIdx.y, s = blockIdx.x, tid = threadIdx.x;
@@ -628,7 +628,7 @@ __global__ __launch_bounds__(BN1_THREADS) void bn_bwd1_kernel(const T *__restric
     typename BnIO<T>::Raw rx[ITEMS], rd[ITEMS];
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
-        const int64_t m = lo + ((int64_t)it * BN1_THREADS + tid) * W;
+        const int64_t m = lo + ((int64_t)it * THREADS + tid) * W;
         if (m < hi) {
             rx[it] = *reinterpret_cast<const typename BnIO<T>::Raw *>(row + m);
             rd[it] = *reinterpret_cast<const typename BnIO<T>::Raw *>(grow + m);
@@ -637,7 +637,7 @@ __global__ __launch_bounds__(BN1_THREADS) void bn_bwd1_kernel(const T *__restric
     float sd = 0.0f, sdx = 0.0f;
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
-        const int64_t m = lo + ((int64_t)it * BN1_THREADS + tid) * W;
+        const int64_t m = lo + ((int64_t)it * THREADS + tid) * W;
         if (m < hi) {
             float v[W], d[W];
             BnIO<T>::unpack(rx[it], v);
@@ -651,7 +651,7 @@ __global__ __launch_bounds__(BN1_THREADS) void bn_bwd1_kernel(const T *__restric
             }
         }
     }
-    const float2 r = block_sum2<BN1_THREADS>(sd, sdx, scratch, tid);
+    const float2 r = block_sum2<THREADS>(sd, sdx, scratch, tid);
     unsigned long long *slots_row = reinterpret_cast<unsigned long long *>(sync + (size_t)gridDim.y * BN1_SYNC_STRIDE) + (size_t)c * S;
     int *counter = sync + (size_t)c * BN1_SYNC_STRIDE;
     const int w_lo = s == 0 ? 0 : grp * Sg, w_hi = s == 0 ? S : (grp + 1) * Sg;     // chunk 0 also writes dgamma / dbeta
@@ -665,7 +665,7 @@ __global__ __launch_bounds__(BN1_THREADS) void bn_bwd1_kernel(const T *__restric
             float sd2 = 0.0f, sdx2 = 0.0f;
 #pragma unroll
             for (int it = 0; it < ITEMS; ++it) {
-                const int64_t m = lo2 + ((int64_t)it * BN1_THREADS + tid) * W;
+                const int64_t m = lo2 + ((int64_t)it * THREADS + tid) * W;
                 if (m < hi2) {
                     float v[W], d[W];
                     BnIO<T>::load(row + m, v);
@@ -679,7 +679,7 @@ __global__ __launch_bounds__(BN1_THREADS) void bn_bwd1_kernel(const T *__restric
                     }
                 }
             }
-            const float2 r2 = block_sum2<BN1_THREADS>(sd2, sdx2, scratch, tid);
+            const float2 r2 = block_sum2<THREADS>(sd2, sdx2, scratch, tid);
             if (tid == 0) sp[i] = r2;
         }
         __syncthreads();
@@ -710,7 +710,7 @@ __global__ __launch_bounds__(BN1_THREADS) void bn_bwd1_kernel(const T *__restric
     const float m1 = sd / (float)Mg, m2 = sdx / (float)Mg;
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
-        const int64_t m = lo + ((int64_t)it * BN1_THREADS + tid) * W;
+        const int64_t m = lo + ((int64_t)it * THREADS + tid) * W;
         if (m < hi) {
             float v[W], d[W];
             BnIO<T>::unpack(rx[it], v);
@@ -728,9 +728,9 @@ __global__ __launch_bounds__(BN1_THREADS) void bn_bwd1_kernel(const T *__restric
 }
 
 // single-pass plan: Sg chunks per group, or 0 when the shape does not qualify
-static int bn1_plan(int64_t Mg, int G, int W, int items) {
+static int bn1_plan(int64_t Mg, int G, int W, int items, int threads = BN1_THREADS) {
     if (Mg % W) return 0;
-    const int64_t chunk = (int64_t)BN1_THREADS * items * W;
+    const int64_t chunk = (int64_t)threads * items * W;
     const int64_t Sg = (Mg + chunk - 1) / chunk;
     if (Sg * G > BN1_MAX_S) return 0;
     return (int)Sg;
@@ -877,6 +877,23 @@ extern "C" int grafp_bn_bwd_1pass(const void *x, const void *dz, int dtype, int 
         if (ok && !f32 && (Sg == 0 || Sg * G > items8_from)) {
             items = 2 * BN1_ITEMS_BWD;
             Sg = bn1_plan(Mg, G, 8, items);
+        }
+        // ... and from 32 chunks per view on 512-thread workgroups: half the chunks again with the same registers per
+        // thread and the same waves per CU (two workgroups instead of four).  tools/bn_bench.py at 2048 clip-views: 64
+        // chunks per view (stage 0) 783 -> 703 us, 32 (stage 1) 681 -> 650; from 16 chunks (stage 2) it loses 1 %, and
+        // 1024-thread workgroups -- ONE per CU, whose phases overlap nobody's -- lose 10-20 % everywhere.
+        const int t512_from = GRAFP_TUNE_INT("GRAFP_BN_BWD_T512_FROM", 32);
+        if (ok && !f32 && t512_from > 0 && items == 2 * BN1_ITEMS_BWD && Sg >= t512_from) {
+            const int Sg2 = bn1_plan(Mg, G, 8, items, 512);
+            if (Sg2 > 0) {
+                const dim3 grid2(Sg2 * G, C);
+                hipLaunchKernelGGL((bn_bwd1_kernel<unsigned short, 2 * BN1_ITEMS_BWD, 512>), grid2, dim3(512), 0, s,
+                                   (const unsigned short *)x, (const unsigned short *)dz, M, Mg, Sg2, G, pre_bias, gamma,
+                                   beta, save_mean, save_invstd, act, slope, (int *)sync, (unsigned short *)dx,
+                                   dgamma, dbeta, dpre_bias, spin);
+                GRAFP_CHECK_LAUNCH("bn_bwd1_kernel");
+                return GRAFP_OK;
+            }
         }
         if (Sg > 0) {
             const dim3 grid(Sg * G, C);
