@@ -117,14 +117,20 @@ struct KeyList {
         for (int t = 0; t < K; ++t) k[t] = 0x7f7fffffu;       // the largest finite float: an empty slot
         next = 0x7f7fffffu;
     }
+    static __device__ __forceinline__ unsigned med3(unsigned a, unsigned b, unsigned c) {      // -> v_med3_u32
+        const unsigned lo = a < b ? a : b, hi = a < b ? b : a;
+        const unsigned m = hi < c ? hi : c;
+        return lo < m ? m : lo;
+    }
+    // With k ascending and next >= k[K-1], slot t of the new list is the MEDIAN of (its lower neighbour, itself, v): v
+    // below both -> the neighbour moves up, v between -> v, v above -> unchanged; the key that leaves is the median of
+    // (k[K-1], v, next).  K + 1 instructions per candidate instead of the 2 K + 1 of a min / max bubble (the scans are
+    // bound by exactly these VALU instructions), evaluated from the top so that every slot still sees its OLD neighbour.
     __device__ __forceinline__ void push(unsigned v) {
+        next = med3(k[K - 1], v, next);
 #pragma unroll
-        for (int t = 0; t < K; ++t) {
-            const unsigned lo = v < k[t] ? v : k[t];           // v_min_u32
-            v = v < k[t] ? k[t] : v;                           // v_max_u32
-            k[t] = lo;
-        }
-        next = v < next ? v : next;
+        for (int t = K - 1; t > 0; --t) k[t] = med3(k[t - 1], k[t], v);
+        k[0] = v < k[0] ? v : k[0];
     }
 };
 
