@@ -232,6 +232,12 @@ def test_bench_two_ranks_one_gpu(tmp_path):
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0      # the global batch is split
     assert line["config"]["global_batch"] == 32 and line["roofline"]["frac"] > 0
     assert line["hip_graph"].get("value", 0) > 0, line["hip_graph"]                        # the graph-replayed data-parallel step
+    # the headline is the faster of the two implementations of the step, the other one stays beside it
+    if line["step_impl"].startswith("HIP graphs"):
+        assert line["value"] == line["hip_graph"]["value"] and line["ms_per_step"] == line["hip_graph"]["ms_per_step"]
+        assert 0 < line["eager"]["value"] <= line["value"]
+    else:
+        assert line["step_impl"].startswith("eager") and "eager" not in line and line["value"] >= line["hip_graph"]["value"]
     w = line["weak_scaling_256_per_gpu"]                                                   # ... and 256 pairs per rank beside it
     assert w["global_batch"] == 512 and w["scaling"] == "weak" and w["value"] > 0
     rs = line["retrieval_sharded"]                 # config-5 shape: one 1.25 M-row shard per rank, planted queries
