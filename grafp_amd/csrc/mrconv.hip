@@ -43,6 +43,15 @@ __device__ __forceinline__ void mr_ld4(const unsigned short *p, float (&v)[4]) {
     v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
     v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
 }
+// a 4-element piece as it is loaded (what waits in registers while further slabs are in flight)
+template <typename T> struct MrRaw;
+template <> struct MrRaw<float> { typedef float4 type; static constexpr int NPAR = 2; };
+template <> struct MrRaw<unsigned short> { typedef uint2 type; static constexpr int NPAR = 4; };
+__device__ __forceinline__ void mr_unpack4(const float4 &t, float (&v)[4]) { v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+__device__ __forceinline__ void mr_unpack4(const uint2 &t, float (&v)[4]) {
+    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+}
 __device__ __forceinline__ unsigned mr_pack(float lo, float hi) {
     typedef float f2 __attribute__((ext_vector_type(2)));
     typedef __bf16 b2 __attribute__((ext_vector_type(2)));
@@ -192,38 +201,41 @@ __global__ __launch_bounds__(MR_THREADS) void mrconv_fwd_p_kernel(const T *__res
             MR_NEXT(4, N, c, n);
         }
     }
-    // TWO slabs in flight per workgroup (register sets 0 / 1): with one, 5 workgroups x 8 KB per CU = 10 MB on the whole
-    // chip, and bytes in flight / HBM latency (~3.5 us under load) is what the kernel ran at (3.5 TB/s)
-    float pv[2][MRP_ITEMS][4];
+    // SEVERAL slabs in flight per workgroup: with one, 5 workgroups x 8 KB per CU = 10 MB on the whole chip, and bytes
+    // in flight / HBM latency (~3.5 us under load) is what the kernel ran at (3.5 TB/s).  The pieces wait in registers
+    // as they were loaded (bf16: 8 bytes per piece instead of four floats), so the same 32 registers hold FOUR slabs of
+    // bf16 -- all a workgroup has with the usual 16 slabs per clip -- or two of f32.
+    typedef typename MrRaw<T>::type Raw;
+    constexpr int NPAR = MrRaw<T>::NPAR;
+    Raw pv[NPAR][MRP_ITEMS];
     auto fetch = [&](int par, int slab) {
         const int c0 = slab * CC, cc = min(CC, C - c0);
 #pragma unroll
         for (int it = 0; it < MRP_ITEMS; ++it)
-            if (pc[it] < cc) mr_ld4(xb + (size_t)(c0 + pc[it]) * x_sc + pn[it], pv[par][it]);
+            if (pc[it] < cc) pv[par][it] = *reinterpret_cast<const Raw *>(xb + (size_t)(c0 + pc[it]) * x_sc + pn[it]);
     };
     int slab = blockIdx.x;
     const int G = gridDim.x;
-    if (slab < nslab) fetch(0, slab);
-    if (slab + G < nslab) fetch(1, slab + G);
+#pragma unroll
+    for (int par = 0; par < NPAR; ++par)
+        if (slab + par * G < nslab) fetch(par, slab + par * G);
     stage_idx<I>(sidx, idx + (size_t)b * N * K, N, K, tid);
     while (slab < nslab) {
 #pragma unroll
-        for (int par = 0; par < 2; ++par) {
+        for (int par = 0; par < NPAR; ++par) {
             if (slab < nslab) {                    // workgroup-uniform
                 const int c0 = slab * CC, cc = min(CC, C - c0);
                 __syncthreads();                   // previous slab fully consumed (and sidx staged, first time round)
+                float xi[MRP_ITEMS][4];
+#pragma unroll
+                for (int it = 0; it < MRP_ITEMS; ++it) mr_unpack4(pv[par][it], xi[it]);
 #pragma unroll
                 for (int it = 0; it < MRP_ITEMS; ++it)
                     if (pc[it] < cc)                   // one 16-byte LDS write per piece (N % 4 == 0: aligned)
                         *reinterpret_cast<float4 *>(rows + pc[it] * N + pn[it]) =
-                            make_float4(pv[par][it][0], pv[par][it][1], pv[par][it][2], pv[par][it][3]);
+                            make_float4(xi[it][0], xi[it][1], xi[it][2], xi[it][3]);
                 __syncthreads();
-                float xi[MRP_ITEMS][4];
-#pragma unroll
-                for (int it = 0; it < MRP_ITEMS; ++it)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) xi[it][e] = pv[par][it][e];
-                if (slab + 2 * G < nslab) fetch(par, slab + 2 * G);
+                if (slab + NPAR * G < nslab) fetch(par, slab + NPAR * G);
 #pragma unroll
                 for (int it = 0; it < MRP_ITEMS; ++it) {
                     if (pc[it] < cc) {
@@ -508,15 +520,19 @@ __global__ __launch_bounds__(MR_THREADS) void mrconv_bwd_a_kernel(const unsigned
         ar_p[it] = arg + ((size_t)b * C + c) * (N / 4) + pn[it] / 4;
     }
     const int64_t ge_step = 2 * cstep * g_sc, dx_step = cstep * d_sc, ar_step = cstep * (N / 4);
-    float pe[2][MRB_ITEMS][4], po[2][MRB_ITEMS][4];                // g_even, g_odd of the TWO slabs in flight
-    unsigned pa[2][MRB_ITEMS];
+    // g_even, g_odd of the slabs in flight, as loaded (bf16: four slabs in the registers two took unpacked; see
+    // mrconv_fwd_p_kernel -- the kernel runs at bytes in flight / latency)
+    typedef typename MrRaw<T>::type Raw;
+    constexpr int NPAR = MrRaw<T>::NPAR;
+    Raw pe[NPAR][MRB_ITEMS], po[NPAR][MRB_ITEMS];
+    unsigned pa[NPAR][MRB_ITEMS];
     auto fetch = [&](int par, int slab) {                          // slabs are fetched in order, each G after the last
         const int cc = min(CC, C - slab * CC);
 #pragma unroll
         for (int it = 0; it < MRB_ITEMS; ++it) {
             if (pc[it] < cc) {
-                mr_ld4(ge_p[it], pe[par][it]);
-                mr_ld4(ge_p[it] + g_sc, po[par][it]);
+                pe[par][it] = *reinterpret_cast<const Raw *>(ge_p[it]);
+                po[par][it] = *reinterpret_cast<const Raw *>(ge_p[it] + g_sc);
                 pa[par][it] = *ar_p[it];
             }
             ge_p[it] += ge_step;
@@ -525,12 +541,13 @@ __global__ __launch_bounds__(MR_THREADS) void mrconv_bwd_a_kernel(const unsigned
     };
     int slab = blockIdx.x;
     const int G = gridDim.x;
-    if (slab < nslab) fetch(0, slab);
-    if (slab + G < nslab) fetch(1, slab + G);
+#pragma unroll
+    for (int par = 0; par < NPAR; ++par)
+        if (slab + par * G < nslab) fetch(par, slab + par * G);
     stage_idx<I>(sidx, idx + (size_t)b * N * K, N, K, tid);
     while (slab < nslab) {
 #pragma unroll
-        for (int par = 0; par < 2; ++par) {
+        for (int par = 0; par < NPAR; ++par) {
             if (slab < nslab) {                    // workgroup-uniform
                 const int cc = min(CC, C - slab * CC);
                 __syncthreads();                   // previous slab written out (and the edges staged, first time round)
@@ -543,18 +560,20 @@ __global__ __launch_bounds__(MR_THREADS) void mrconv_bwd_a_kernel(const unsigned
                         ak[it] = pa[par][it];
                         *reinterpret_cast<uint4 *>(acc + off[it]) = make_uint4(0, 0, 0, 0);
                         *reinterpret_cast<uint4 *>(acc + off[it] + 2) = make_uint4(0, 0, 0, 0);
+                        float ge[4];
+                        mr_unpack4(pe[par][it], ge);
+                        mr_unpack4(po[par][it], godd[it]);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            base[it][e] = pe[par][it][e] - po[par][it][e];   // identity branch minus the centre terms
-                            godd[it][e] = po[par][it][e];
-                            m = max(m, __float_as_uint(po[par][it][e]) & 0x7fffffffu);
+                            base[it][e] = ge[e] - godd[it][e];               // identity branch minus the centre terms
+                            m = max(m, __float_as_uint(godd[it][e]) & 0x7fffffffu);
                         }
                     }
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
                 if ((tid & 63) == 0) s_max[tid >> 6] = m;
                 __syncthreads();
-                if (slab + 2 * G < nslab) fetch(par, slab + 2 * G);
+                if (slab + NPAR * G < nslab) fetch(par, slab + NPAR * G);
                 m = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
                 bool poisoned;
                 float scale, inv_scale;
