@@ -37,6 +37,13 @@ PEAK_F32_MATRIX_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 
 PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s achievable)
 
 
+def host_threads():
+    """ONE policy for both CPU baselines of a bench line (the oracle's train step and the exact CPU search): every host
+    core up to 32 -- beyond 32 threads both legs get SLOWER on the GPU boxes' 128-core hosts (B = 32 step: 5 x slower at
+    128 threads; the search is memory-bound) -- and `cores` reports exactly the number of threads that ran."""
+    return max(1, min(32, os.cpu_count() or 1))
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -175,13 +182,12 @@ KERNEL_NAMES = ("conv1x1_gemm", "conv1x1_wgrad", "bn_bwd", "bn_affine", "bn_fwd"
 
 def cpu_baseline(cfg, seconds):
     """The oracle's CPU train step (test infrastructure used ONLY as the reported baseline): B = 32 pairs,
-    log-mel -> peak extractor -> GraphEncoder -> projector -> NT-Xent, fwd + bwd + Adam, f32, on at most 32 host
-    threads (more only adds contention at this batch size).  1 warm-up step, then timed steps until >= 2 steps
-    or `seconds` have elapsed."""
+    log-mel -> peak extractor -> GraphEncoder -> projector -> NT-Xent, fwd + bwd + Adam, f32, on `host_threads()`
+    threads.  1 warm-up step, then timed steps until >= 2 steps or `seconds` have elapsed."""
     from grafp_amd.train import build_model
     from oracle import model as om
     B = 32
-    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    torch.set_num_threads(host_threads())
     torch.manual_seed(0)
     sd = {k: v.clone() for k, v in build_model(dict(cfg, bsz_train=B)).state_dict().items()}
     for k, v in sd.items():
@@ -285,8 +291,16 @@ def retrieval_probe(device, cpu_check=True):
         # CPU exact search beside it (oracle/csrc/flat_search.c, OpenMP over database rows): ALL 4096 queries once --
         # ids and distances must be equal bit for bit -- and the nq = 41 batch repeatedly for the reported rate
         from oracle import native
-        threads = max(1, min(32, os.cpu_count() or 1))
-        os.environ["OMP_NUM_THREADS"] = str(threads)                  # read when libgomp starts its first team
+        # the same thread policy as the train-step baseline; torch has loaded libgomp long before this point, so the
+        # environment variable would come too late: set the runtime's thread count directly, and report what it says
+        import ctypes
+        threads = host_threads()
+        try:
+            gomp = ctypes.CDLL("libgomp.so.1")
+            gomp.omp_set_num_threads(threads)
+            threads = int(gomp.omp_get_max_threads())
+        except OSError:
+            os.environ["OMP_NUM_THREADS"] = str(threads)
         D, I = ops.search_l2(db, sq, q, 20, db_bf16=dbh)
         db_h, q_h = db.cpu().numpy(), q.cpu().numpy()
         native.flat_search_l2(db_h[:1000], q_h[:1], 20)                 # builds / loads the library outside the timing
@@ -298,11 +312,6 @@ def retrieval_probe(device, cpu_check=True):
             native.flat_search_l2(db_h, q_h[:41], 20)
             reps += 1
         dt = (time.perf_counter() - t0) / reps
-        try:
-            import ctypes
-            threads = int(ctypes.CDLL("libgomp.so.1").omp_get_max_threads())      # what the runtime really uses
-        except OSError:
-            pass
         res["cpu_baseline"] = {"value": round(41 / dt, 2), "unit": "queries/s", "cores": threads, "kind": "port",
                                "sample": f"the nq=41 batch against the full 1M x 128 database, exact search "
                                          f"(oracle/csrc/flat_search.c, OpenMP over database rows), {reps} passes of "
@@ -323,8 +332,36 @@ def timed_steps(fn, steps, barrier):
     return time.perf_counter() - t0, out
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves.
+
+    Runs BEFORE anything touches the GPU (`torch.cuda.device_count()` does not initialise it on this image) and starts
+    `python -m torch.distributed.run ... bench.py <same arguments>` as a CHILD process -- never an exec -- whose
+    stdout (rank 0's JSON line) and exit code are forwarded.  Fewer visible devices than ranks is an error, not a
+    one-rank run that prints `n_gpus: 1` (the --local-device test hook, where the ranks share a device, is exempt)."""
+    import socket
+    import subprocess
+    if args.local_device is None:
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            sys.stderr.write(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) visible; refusing to run fewer ranks "
+                             "than asked for\n")
+            return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(1, args.gpus))))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     from grafp_amd import dist as gdist
     from grafp_amd import ops
     from grafp_amd.train import Trainer, build_model, synthetic_batch
@@ -332,7 +369,7 @@ def main():
 
     rank, world, device = gdist.init_from_env(backend=args.backend, local_device=args.local_device)
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (the hot path has no CPU fallback)"
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.backends.cudnn.benchmark = False
     cfg = load_config()
     if args.batch_per_gpu is None:

@@ -65,8 +65,6 @@ SIGNATURES = {
     "grafp_bn_bwd_1pass": (_I, [_P, _P, _I, _I, _L, _I, _P, _P, _P, _P, _P, _I, _F, _I, _P, _P, _P, _P, _P, _Z, _P, _I, _P]),
     "grafp_ivfpq_scan_f32": (_I, [_P, _I, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _L, _P, _P, _P]),
     "grafp_debug_occupy": (_I, [_I, _I, _L, _P]),
-    "grafp_flag_bump": (_I, [_P, _P]),
-    "grafp_flag_wait": (_I, [_P, _I, _P]),
     "grafp_conv1x1_gemm_supported": (_I, [_I, _I, _I, _L, _I]),
     "grafp_conv1x1_gemm_partials": (_I, [_I, _I, _I, _L, _I]),
     "grafp_conv1x1_gemm_plan": (_I, [_I, _I, _I, _L, _I, _P]),

@@ -78,29 +78,6 @@ def ntxent_global(z_i, z_j, tau, group=None, loss_fn=None):
     return loss_fn(z_i, z_j, tau, zi_all, zj_all, rank_of(group) * z_i.shape[0])
 
 
-class ProgressFlag:
-    """A device counter a replayed HIP graph bumps when it passes a certain point (grafp_flag_bump, recorded into the
-    graph) and another stream waits for (grafp_flag_wait, enqueued after the replay): the stand-in for an external event,
-    which the HIP runtime of this image refuses under capture (include/grafp_hip.h)."""
-
-    def __init__(self, device):
-        from ._lib import check, lib
-        self._lib, self._check = lib, check
-        self.value = torch.zeros((), dtype=torch.int32, device=device)
-        self.bumps = 0                                   # how often the bump has EXECUTED (replays so far)
-
-    def record(self):
-        """Inside a capture: the bump becomes a node of the graph (it does not run now)."""
-        import ctypes
-        self._check(self._lib.grafp_flag_bump(ctypes.c_void_p(self.value.data_ptr()),
-                                              ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "flag_bump")
-
-    def make_wait(self, stream, count):
-        import ctypes
-        self._check(self._lib.grafp_flag_wait(ctypes.c_void_p(self.value.data_ptr()), int(count),
-                                              ctypes.c_void_p(stream.cuda_stream)), "flag_wait")
-
-
 class GradSync:
     """Flat-buffer gradient all-reduce (SUM) with bucketed launch from autograd hooks.
 
@@ -108,7 +85,11 @@ class GradSync:
     so the per-rank parameter gradients are the disjoint terms of the full gradient, exactly what
     DataParallel's reduce-to-GPU-0 adds up (train.py:165-168)."""
 
-    def __init__(self, params, group=None, n_buckets=4, overlap=True, force_flat=False):
+    def __init__(self, params, group=None, n_buckets=4, overlap=True, force_flat=False, tail_numel=1 << 20):
+        """n_buckets near-equal buckets in the order the gradients become ready, plus -- when the last of them would hold
+        more than `tail_numel` elements -- a small TAIL bucket for the parameters whose gradients arrive last (the stem and
+        stages 0-1: 0.6 M of the 18.4 M parameters, but half of backward's run time): the one all-reduce that nothing is
+        left to overlap with is then a few MB (latency-bound), not a quarter of the gradient."""
         self.group = group
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
@@ -122,13 +103,36 @@ class GradSync:
             self.bounds, self._hooks, self._handles = [], [], []
             return
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
-        # gradients become ready roughly in reverse registration order: lay the buffer out that way so
-        # every bucket is a contiguous slice that completes early
-        order = list(reversed(self.params))
+        self._n_buckets, self._tail_numel = n_buckets, tail_numel
+        # gradients become ready ROUGHLY in reverse registration order: start with that layout.  The first complete
+        # backward pass records the order in which they really arrive, and the next zero() re-lays the buffer out in
+        # it (as DDP rebuilds its buckets after the first iteration): a module registered late but used first -- the
+        # peak extractor sits between the projector and the encoder in SimCLR's registration order, and its gradient is
+        # the LAST of the whole pass -- would otherwise keep an early bucket open until backward ends.
+        self._layout(list(reversed(self.params)))
+        self._arrival, self._arrived, self._relaid = [], set(), False
+        self._hooks = []
+        self._cap_cut = None
+        self.paused = False            # Trainer.step_graph: backward is being captured, the buckets are reduced afterwards
+        self.capturing = False         # ... and each completed bucket ends one backward graph (begin_capture)
+        if overlap and (self.world > 1 or force_flat):
+            for p in self.params:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    def _layout(self, order):
+        """Cut the flat buffer into buckets for the parameters in `order` (expected arrival order of their gradients)."""
+        total, n_buckets, tail_numel = self.flat.numel(), self._n_buckets, self._tail_numel
         per_bucket = (total + n_buckets - 1) // max(1, n_buckets)
         self.bounds, self._bucket_of, self._view, self._members, off, b_lo = [], {}, {}, [[]], 0, 0
+        tail_cut = False
         for p in order:
             n = p.numel()
+            if (not tail_cut and tail_numel and off > b_lo and total - off <= tail_numel
+                    and total - b_lo > tail_numel):
+                # everything from here on fits the tail bucket: close the running bucket in front of it
+                self.bounds.append((b_lo, off))
+                self._members.append([])
+                b_lo, tail_cut = off, True
             self._view[id(p)] = self.flat[off:off + n].view_as(p)
             self._bucket_of[id(p)] = len(self.bounds)
             self._members[-1].append(p)
@@ -142,13 +146,25 @@ class GradSync:
         self._members = self._members[:len(self.bounds)]
         self._size = [len(m) for m in self._members]
         self._left, self._handles, self._fired = list(self._size), [], [False] * len(self.bounds)
-        self._hooks = []
-        self._cap_events = None
-        self.paused = False            # Trainer.step_graph: backward is being captured, the buckets are reduced afterwards
-        self.capturing = False         # ... and each bucket marks its completion with an external event (begin_capture)
-        if overlap and (self.world > 1 or force_flat):
-            for p in self.params:
-                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    def _maybe_relayout(self):
+        """Once, at the start of the step that follows the first COMPLETE backward pass (every parameter's gradient
+        arrived through the hooks): buckets in the observed arrival order.  Every rank runs the same autograd graph, so
+        the orders agree; rank 0's is broadcast anyway (a layout that differed between ranks would add up the wrong
+        slices), and nothing is in flight here (zero() has just waited)."""
+        if self._relaid or len(self._arrival) != len(self.params):
+            self._arrival, self._arrived = [], set()
+            return
+        index = {id(p): i for i, p in enumerate(self.params)}
+        order = torch.tensor([index[i] for i in self._arrival], dtype=torch.int64)
+        if self.world > 1:
+            dev_order = order.to(self.flat.device)
+            dist.broadcast(dev_order, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0,
+                           group=self.group)
+            order = dev_order.cpu()
+        self._layout([self.params[i] for i in order.tolist()])
+        self._relaid = True
+        self._arrival, self._arrived = [], set()
 
     def zero(self):
         """Use instead of optimizer.zero_grad(): autograd then ASSIGNS fresh gradients (no per-parameter accumulate
@@ -161,6 +177,8 @@ class GradSync:
             for h in self._handles:
                 h.wait()
             self._handles, self._left, self._fired = [], list(self._size), [False] * len(self.bounds)
+            if not self._relaid and not self.capturing:
+                self._maybe_relayout()
 
     def close(self):
         """Detach the autograd hooks (a second GradSync over the same parameters -- another Trainer on the same model --
@@ -192,57 +210,73 @@ class GradSync:
                                                  async_op=True))
         self._fired[b] = True
 
-    def begin_capture(self):
-        """Backward is about to be recorded into a HIP graph (Trainer.step_graph).  The hooks then do not launch
-        collectives; when a bucket's last gradient arrives they record the bucket's pack (one multi-tensor copy into the
-        flat buffer) and the bump of the bucket's ProgressFlag.  On replay a communication stream waits for flag b and
-        all-reduces bucket b while the rest of the backward graph is still running -- overlap without capturing RCCL."""
-        if not self._cap_events:
-            raise RuntimeError("GradSync.begin_capture: call prepare_capture() BEFORE the capture begins (the flags must "
-                               "not be allocated -- and zero-filled -- by the graph itself)")
+    def begin_capture(self, cut=None):
+        """Backward is about to be recorded into HIP graphs (Trainer.step_graph).  The hooks then launch no collective;
+        when a bucket's last gradient arrives they record the bucket's pack (one multi-tensor copy into the flat buffer)
+        and -- except for the last bucket -- call `cut(b)`, which ends the graph being recorded and begins the next one:
+        backward becomes one graph per bucket, and on replay bucket b's all-reduce is launched between graph b and graph
+        b + 1, i.e. it runs under the rest of backward exactly like the eager step's (no RCCL call is captured, no device-
+        side polling)."""
         self._cap_left, self._cap_done = list(self._size), [False] * len(self.bounds)
+        self._cap_cut = cut
+        self._cap_order = []
         self.capturing = True
 
-    def prepare_capture(self):
-        """Outside any capture: the per-bucket progress flags (ordinary device memory that outlives the graphs; allocated
-        inside the capture they would come from the graph's private pool and their zero-fill would be replayed)."""
-        self._cap_events = [ProgressFlag(self.flat.device) for _ in self.bounds]
-        torch.cuda.current_stream().synchronize()
+    def _cap_complete(self, b):
+        self._pack(b)
+        self._cap_done[b] = True
+        self._cap_order.append(b)
+        if self._cap_cut is not None and not all(self._cap_done):
+            self._cap_cut(b)
 
     def end_capture(self):
         """Still inside the capture, after backward: buckets whose parameters did not all receive a gradient are packed
-        and marked now.  Returns the per-bucket events (in bucket order = completion order of a backward pass)."""
+        into the last graph.  Returns, per recorded graph, the buckets whose packed gradients are complete when that
+        graph has run (the last entry may hold several)."""
+        cuts = [[b] for b in self._cap_order]
+        tail = []
         for b in range(len(self.bounds)):
             if not self._cap_done[b]:
                 self._pack(b)
-                self._cap_events[b].record()
                 self._cap_done[b] = True
-        self.capturing = False
-        return self._cap_events
+                tail.append(b)
+        if self._cap_cut is None:
+            cuts = [[b for c in cuts for b in c] + tail]
+        elif cuts and len(cuts) == len(self.bounds) and not tail:
+            pass                                     # the last bucket completed inside the last graph: no cut behind it
+        else:
+            cuts.append(tail)
+        self.capturing, self._cap_cut = False, None
+        return cuts
 
-    def reduce_buckets_after(self, events, comm_stream):
-        """The replay side of begin_capture(), called right AFTER the backward graph's replay was enqueued: bucket b's
-        all-reduce goes to `comm_stream` behind the wait for flag b; the CURRENT stream then waits for all of them (RCCL
-        backends; host-staged ones use reduce_all())."""
-        hs = []
-        for (lo, hi), ev in zip(self.bounds, events):
-            ev.bumps += 1
-            ev.make_wait(comm_stream, ev.bumps)
-            with torch.cuda.stream(comm_stream):
-                hs.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-        for h in hs:
+    def reduce_buckets(self, buckets):
+        """Launch (do not wait for) the all-reduce of the given buckets' slices of the flat buffer: the replay side of
+        begin_capture(), called right after the graph that packed them was enqueued.  RCCL orders the collective behind
+        everything enqueued on the current stream so far and runs it on its own stream, under whatever is enqueued next."""
+        if self.world > 1:
+            for b in buckets:
+                lo, hi = self.bounds[b]
+                self._handles.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group,
+                                                     async_op=True))
+
+    def wait_reduced(self):
+        """The current stream waits for every all-reduce launched by reduce_buckets(); .grad of every parameter becomes
+        its view of the reduced buffer."""
+        for h in self._handles:
             h.wait()
+        self._handles = []
         for p in self.params:
             p.grad = self._view[id(p)]
 
     def _on_grad(self, p):
+        if not self._relaid and id(p) not in self._arrived:
+            self._arrived.add(id(p))
+            self._arrival.append(id(p))
         if self.capturing:
             b = self._bucket_of[id(p)]
             self._cap_left[b] -= 1
             if self._cap_left[b] == 0 and not self._cap_done[b]:
-                self._pack(b)
-                self._cap_events[b].record()
-                self._cap_done[b] = True
+                self._cap_complete(b)
             return
         if self.paused:
             return

@@ -136,7 +136,8 @@ def conv_bn_act(conv, bn, x, residual=None, act=ops.ACT_NONE, slope=0.0, groups=
         z = ops.conv_bn_act(x2, w, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum, bn.eps,
                             bias, res, act, slope, cg, groups, getattr(conv, "_w_lowp", None) if weight is None else None,
                             token, token_role, getattr(conv, "_w_t", None) if weight is None else None,
-                            getattr(conv, "_w_aug", None) if weight is None else None, defer, defer_role)
+                            getattr(conv, "_w_aug", None) if weight is None else None, defer, defer_role,
+                            getattr(conv, "_lowp_owner", None) if weight is None else None)
         return z.reshape(cout, B, N)
     if defer is not None:
         raise RuntimeError("conv_bn_act: a DeferredNorm was handed to a layer outside the fused bf16 path")

@@ -650,10 +650,9 @@ class lowp_weights:
     possibly after an optimizer step, between the two) raises instead of differentiating against whatever the buffers
     hold by then."""
 
-    generation = 0                  # advanced by every refresh() of any instance
-
     def __init__(self, convs):
         self.convs = list(convs)
+        self.generation = 0             # advanced by every refresh() of THIS instance (its buffers are its own)
         self._dtype, self._dev = None, None
         self._fast, self._slow, self._slow_bufs = [], [], []
         self._table = self._tile_entry = None
@@ -698,7 +697,7 @@ class lowp_weights:
         if stale:
             self._build(dtype, dev)
             self._src_ptrs = [c.weight.data_ptr() for c in self.convs]
-        lowp_weights.generation += 1
+        self.generation += 1
         with torch.no_grad():
             if self._table is not None:
                 check(lib.grafp_weights_prepare(_p(self._table), _p(self._tile_entry), int(self._tile_entry.numel()),
@@ -708,6 +707,8 @@ class lowp_weights:
         self._publish()
 
     def _publish(self):
+        for c in self.convs:
+            c._lowp_owner = self
         for c, lo, wt, aug, Rg in self._fast:
             c._w_lowp = lo.view(c.weight.shape) if c.weight.dim() == 4 else lo
             c._w_t, c._w_aug = (None, wt) if aug else (wt, None)
@@ -717,6 +718,7 @@ class lowp_weights:
     def clear(self):
         for c in self.convs:
             c._w_lowp = c._w_t = c._w_aug = None
+            c._lowp_owner = None
 
 
 # ------------------------------------------------------------------------------------------------
@@ -901,7 +903,7 @@ class _ConvBnAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, w_lowp, conv_groups, views, gamma, beta, pre_bias, residual, running_mean, running_var,
                 training, momentum, eps, act, slope, token=None, token_role=0, w_t=None, w_aug=None, defer=None,
-                defer_role=0):
+                defer_role=0, lowp_owner=None):
         x = x.detach()
         # DeferredNorm: role 1 = this layer's BatchNorm + activation are applied by its only consumer while THAT stages
         # its operand (no normalise pass, the normalised tensor is never written); role 2 = that consumer
@@ -912,7 +914,8 @@ class _ConvBnAct(torch.autograd.Function):
         ctx.token, ctx.token_role = token, token_role        # 1: first layer of the block (consumes), 2: last (provides)
         ctx.w_t, ctx.w_aug = w_t, w_aug                      # prepared with the forward operand (lowp_weights), or None
         # shared prepared buffers in use: remember which preparation this forward pass saw
-        ctx.lowp_gen = lowp_weights.generation if (w_lowp is not None or w_t is not None or w_aug is not None) else None
+        shared = lowp_owner is not None and (w_lowp is not None or w_t is not None or w_aug is not None)
+        ctx.lowp_owner, ctx.lowp_gen = (lowp_owner, lowp_owner.generation) if shared else (None, None)
         K, M = x.shape
         R = w.shape[0]
         if w_lowp is not None and w_lowp.dtype == torch.bfloat16 and w_lowp.numel() == w.numel():
@@ -953,10 +956,10 @@ class _ConvBnAct(torch.autograd.Function):
     def backward(ctx, dz):
         x, wl, y, mean, invstd, g32, b32, pb = ctx.saved_tensors
         R, K, M, cg, views, act, slope, training, has_pb, has_res, wfull = ctx.cfg
-        if ctx.lowp_gen is not None and ctx.lowp_gen != lowp_weights.generation:
-            raise RuntimeError("conv_bn_act backward: the shared low-precision weight buffers were re-prepared (another encoder "
-                               "forward under autocast, possibly after an optimizer step) between this layer's forward "
-                               "and backward pass; run backward before the next forward")
+        if ctx.lowp_owner is not None and ctx.lowp_gen != ctx.lowp_owner.generation:
+            raise RuntimeError("conv_bn_act backward: the shared low-precision weight buffers were re-prepared (another forward "
+                               "of THIS encoder under autocast, possibly after an optimizer step) between this layer's "
+                               "forward and backward pass; run backward before the next forward")
         dz = dz.detach().to(torch.bfloat16).contiguous()
         dy, dgamma, dbeta, dpb = _bn_bwd(y, dz, R, M, views, pb if has_pb else None, g32, b32, mean, invstd, act, slope,
                                          training)
@@ -985,7 +988,7 @@ class _ConvBnAct(torch.autograd.Function):
         if has_res and tok is not None and ctx.token_role == 2 and tok.grad is None:
             tok.grad, dres = dz, None                      # the first layer's backward adds it (see above)
         return (dx, dw, None, None, None, dgamma, dbeta, dpb, dres, None, None, None, None, None, None, None, None, None,
-                None, None, None, None)
+                None, None, None, None, None)
 
 
 def conv_bn_act_supported(x, cout, conv_groups, views):
@@ -1021,7 +1024,7 @@ def defer_norm_pays(consumer_rows, consumer_operand_rows, M):
 
 def conv_bn_act(x, w, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, pre_bias=None,
                 residual=None, act=ACT_NONE, slope=0.0, conv_groups=1, views=1, w_lowp=None, token=None, token_role=0,
-                w_t=None, w_aug=None, defer=None, defer_role=0):
+                w_t=None, w_aug=None, defer=None, defer_role=0, lowp_owner=None):
     """act(BatchNorm(W x + pre_bias)) + residual for bf16 (K, M) rows (see _ConvBnAct).  token / token_role: a
     ShortcutToken shared by the first (role 1: its input IS the shortcut) and the last layer (role 2: `residual` is that
     same input) of a residual block."""
@@ -1042,7 +1045,7 @@ def conv_bn_act(x, w, gamma, beta, running_mean, running_var, training, momentum
         raise RuntimeError("conv_bn_act: deferred normalisation is a training-mode construct")
     return _ConvBnAct.apply(x.contiguous(), w, w_lowp, int(conv_groups), int(views), gamma, beta, pre_bias, residual,
                             running_mean, running_var, bool(training), float(momentum), float(eps), int(act),
-                            float(slope), token, int(token_role), w_t, w_aug, defer, int(defer_role))
+                            float(slope), token, int(token_role), w_t, w_aug, defer, int(defer_role), lowp_owner)
 
 
 def shortcut_token_supported(x, conv_groups=1):

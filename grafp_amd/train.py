@@ -23,17 +23,17 @@ def build_model(cfg, k=3, device=None):
 
 class Trainer:
     def __init__(self, cfg, model, device, amp_dtype=None, group=None, lr=None, n_buckets=4, ir_dir=None,
-                 noise_dir=None, aug_seed=None, data_parallel_graphs=None, overlap_graph_allreduce=False):
+                 noise_dir=None, aug_seed=None, data_parallel_graphs=None, overlap_graph_allreduce=True):
         self.cfg, self.model, self.device, self.group = cfg, model, device, group
         self.amp_dtype = amp_dtype
         self.world = gdist.world_size(group)
         # step_graph's data-parallel form (three graphs, eager collectives): by default whenever there is more than one
         # rank; True forces it for a one-rank process group too (the tests run RCCL that way on a one-GPU box)
         self._dp_graphs = self.world > 1 if data_parallel_graphs is None else bool(data_parallel_graphs)
-        # step_graph on an RCCL backend: True = each bucket's all-reduce starts behind its progress flag while the backward
-        # graph is still running (GradSync.reduce_buckets_after); False (default) = all buckets after the graph
+        # step_graph under data parallelism: True (default) = backward is recorded as one graph per gradient bucket and
+        # bucket b's all-reduce is launched between graph b and graph b + 1 (it runs under the rest of backward);
+        # False = one backward graph, all buckets reduced behind it
         self._overlap_graph_allreduce = bool(overlap_graph_allreduce)
-        self._comm = None
         # ir_dir / noise_dir: recordings for the batched device-side augmentation of the second view (train.py:150-151)
         self.augment = GPUTransformNeuralfp(dict(cfg, aug_seed=aug_seed), ir_dir, noise_dir, train=True).to(device)
         # train.py:174 (same Adam, defaults); on the GPU the update of all 271 parameter tensors is one fused launch
@@ -44,9 +44,10 @@ class Trainer:
         # REPLAY time, so CosineAnnealingLR (train.py:175,224: scheduler.step() once per epoch) keeps working under
         # step_graph instead of being frozen at its value at capture time
         lr0 = lr or cfg["lr"]
-        if on_gpu:
-            lr0 = torch.tensor(float(lr0), dtype=torch.float32, device=device)
-        self.opt = torch.optim.Adam(model.parameters(), lr=lr0, fused=on_gpu, capturable=on_gpu)
+        # the tensor belongs to the Trainer, not to the optimizer's dict: load_state_dict REPLACES param_group['lr'] with
+        # whatever the checkpoint holds (a float from a reference-format file), see load_checkpoint()
+        self._lr = torch.tensor(float(lr0), dtype=torch.float32, device=device) if on_gpu else None
+        self.opt = torch.optim.Adam(model.parameters(), lr=self._lr if on_gpu else lr0, fused=on_gpu, capturable=on_gpu)
         self._graph = None                     # (hipGraph, static x_i, static x_j, static loss) once captured
         self.sched = torch.optim.lr_scheduler.CosineAnnealingLR(self.opt, T_max=cfg["T_max"], eta_min=cfg["min_lr"])
         self.sync = gdist.GradSync(model.parameters(), group=group, n_buckets=n_buckets,
@@ -60,6 +61,7 @@ class Trainer:
     def step(self, x_i, x_j):
         """x_i, x_j: (B_local, T) waveforms already on the device.  Returns this rank's share of the loss
         (a 0-d device tensor; the shares sum to the global mean loss)."""
+        self._rebind_lr()                      # a util.load_ckp(optimizer=trainer.opt) in between swapped the lr object
         self.model.train()
         self.sync.zero()
         with torch.no_grad():
@@ -96,13 +98,14 @@ class Trainer:
         library warm-up, as torch.cuda.graphs asks), records the fourth and replays it; later calls copy the batch
         into the static input buffers and replay.  Shapes must not change between calls.
           * one process: ONE graph (augment, forward, loss, backward, Adam), ~700 launches as one graph launch;
-          * data parallel: THREE graphs with the two collectives between them, eager, exactly where step() has them --
-            [augment + forward] -> all-gather of (z_i, z_j) -> [global-negative loss + backward + pack of the gradient
-            buckets] -> bucket all-reduces -> [Adam].  The collectives are not captured (RCCL kernels inside a graph
-            are untested on this stack); the backward graph bumps one progress flag per gradient bucket
-            (GradSync.begin_capture), so on an RCCL backend bucket b's all-reduce starts on a communication stream as
-            soon as the graph has packed it, under the rest of backward -- the overlap of the eager step, with the ~700
-            launches of a step still folded into three graph launches."""
+          * data parallel: graphs with the collectives between them, eager, exactly where step() has them --
+            [augment + forward] -> all-gather of (z_i, z_j) -> [global-negative loss + backward up to the point where
+            gradient bucket 0 is complete and packed] -> all-reduce of bucket 0 (launched, not waited for) -> [backward up
+            to bucket 1] -> ... -> [Adam].  The collectives are not captured (RCCL kernels inside a graph are untested
+            on this stack): backward is cut into one graph per bucket (GradSync.begin_capture), so every bucket's
+            all-reduce runs under the backward graphs that follow it -- the overlap of the eager step, with the ~700
+            launches of a step folded into 2 + (number of buckets) graph launches."""
+        self._rebind_lr()
         if self._graph is None:
             if getattr(self.augment, "seed", None) is not None:
                 raise RuntimeError("step_graph: a private augmentation generator (aug_seed) is eager-only -- its draws "
@@ -139,17 +142,19 @@ class Trainer:
         return self._replay()
 
     def _capture_data_parallel(self, sx_i, sx_j):
+        import gc
+
         import torch.distributed as tdist
         from . import ops
         R, rank = self.world, gdist.rank_of(self.group)
         self.model.train()
         self.sync.zero()
         self.sync.paused = True                      # no collective from the autograd hooks while the graphs are recorded
-        self.sync.prepare_capture()                  # the buckets' progress flags: allocated before any capture
+        cap = torch.cuda.Stream()                    # ONE capture stream for all graphs: backward runs where forward ran
+        mode = "thread_local"                        # the process group's watchdog thread may query events meanwhile
         try:
             g_fwd = torch.cuda.CUDAGraph()
-            # thread_local: the process group's watchdog thread may query events while this thread records
-            with torch.cuda.graph(g_fwd, capture_error_mode="thread_local"):
+            with torch.cuda.graph(g_fwd, stream=cap, capture_error_mode=mode):
                 with torch.no_grad():
                     X_i, X_j = self.augment(sx_i, sx_j)
                 with self._autocast():
@@ -157,31 +162,54 @@ class Trainer:
                 mine = torch.stack((z_i.detach().float(), z_j.detach().float()), dim=0).contiguous()   # (2, B_loc, D)
             gathered = torch.empty((R * 2,) + tuple(mine.shape[1:]), dtype=mine.dtype, device=mine.device)
             tdist.all_gather_into_tensor(gathered, mine, group=self.group)
-            g_bwd = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_bwd, pool=g_fwd.pool(), capture_error_mode="thread_local"):
-                both = gathered.reshape(R, 2, *mine.shape[1:]).permute(1, 0, 2, 3)
-                zi_all = both[0].reshape(-1, mine.shape[2]).contiguous()
-                zj_all = both[1].reshape(-1, mine.shape[2]).contiguous()
-                loss = ops.ntxent(z_i, z_j, self.cfg["tau"], zi_all, zj_all, rank * z_i.shape[0])
-                self.sync.begin_capture()             # hooks: pack bucket b + bump flag b when it completes
-                loss.backward()
-                events = self.sync.end_capture()
-                loss = loss.detach()
+            # Backward as ONE GRAPH PER GRADIENT BUCKET: when a bucket's last gradient arrives its hook packs the bucket and
+            # ends the graph being recorded; the next one begins on the same stream and memory pool.  Autograd runs on THIS
+            # thread meanwhile (set_multithreading_enabled(False)): a capture must end on the thread that began it.
+            parts = []
+            pool = g_fwd.pool()
+            torch.cuda.synchronize()
+            gc.collect()
+            with torch.cuda.stream(cap):
+                cur = [torch.cuda.CUDAGraph()]
+                cur[0].capture_begin(pool=pool, capture_error_mode=mode)
+                try:
+                    def cut(_b):
+                        cur[0].capture_end()
+                        parts.append(cur[0])
+                        cur[0] = None
+                        nxt = torch.cuda.CUDAGraph()
+                        nxt.capture_begin(pool=pool, capture_error_mode=mode)
+                        cur[0] = nxt
+                    both = gathered.reshape(R, 2, *mine.shape[1:]).permute(1, 0, 2, 3)
+                    zi_all = both[0].reshape(-1, mine.shape[2]).contiguous()
+                    zj_all = both[1].reshape(-1, mine.shape[2]).contiguous()
+                    loss = ops.ntxent(z_i, z_j, self.cfg["tau"], zi_all, zj_all, rank * z_i.shape[0])
+                    self.sync.begin_capture(cut if self._overlap_graph_allreduce else None)
+                    with torch.autograd.set_multithreading_enabled(False):
+                        loss.backward()
+                    ready = self.sync.end_capture()       # per graph: the buckets complete once it has run
+                    loss = loss.detach()
+                finally:
+                    if cur[0] is not None:
+                        cur[0].capture_end()
+                        parts.append(cur[0])
+            assert len(ready) == len(parts), (len(ready), len(parts))
             self.sync.reduce_all()
             g_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_opt, pool=g_fwd.pool(), capture_error_mode="thread_local"):
+            with torch.cuda.graph(g_opt, pool=pool, stream=cap, capture_error_mode=mode):
                 self.opt.step()
         finally:
             self.sync.paused = False
             self.sync.capturing = False
-        return ("dp", (g_fwd, g_bwd, g_opt), sx_i, sx_j, loss, mine, gathered, events)
+        return ("dp", (g_fwd, parts, g_opt), sx_i, sx_j, loss, mine, gathered, ready)
 
     def _replay(self):
         if self._graph[0] == "single":
             self._graph[1].replay()
             return self._graph[4].clone()
         import torch.distributed as tdist
-        (g_fwd, g_bwd, g_opt), loss, mine, gathered = self._graph[1], self._graph[4], self._graph[5], self._graph[6]
+        (g_fwd, parts, g_opt), loss, mine, gathered = self._graph[1], self._graph[4], self._graph[5], self._graph[6]
+        ready = self._graph[7]
         # RCCL collectives are stream-ordered behind the replayed graph.  A host-staged backend (gloo: the two-ranks-on-
         # one-GPU tests) synchronises with the stream from its own thread, and doing that while a ~700-node graph
         # launch is still being enqueued costs SECONDS per step on this stack (measured: 1-11 s against 47 ms with the
@@ -191,24 +219,70 @@ class Trainer:
         if host_staged:
             torch.cuda.current_stream().synchronize()
         tdist.all_gather_into_tensor(gathered, mine, group=self.group)
-        g_bwd.replay()
         if host_staged:
+            for g in parts:
+                g.replay()
             torch.cuda.current_stream().synchronize()
             self.sync.reduce_all()
-        elif not self._overlap_graph_allreduce:
-            self.sync.reduce_all()                    # stream-ordered behind the graph
         else:
-            if self._comm is None:
-                self._comm = torch.cuda.Stream()
-            self.sync.reduce_buckets_after(self._graph[7], self._comm)
+            # bucket b's all-reduce is enqueued between backward graph b and b + 1: RCCL orders it behind graph b and runs
+            # it on its own stream under the graphs that follow -- the overlap of the eager step, without a captured
+            # collective and without device-side polling
+            for g, buckets in zip(parts, ready):
+                g.replay()
+                self.sync.reduce_buckets(buckets)
+            self.sync.wait_reduced()
         g_opt.replay()
         return loss.clone()
 
     def checkpoint(self, epoch, loss_log, hit_rate_log, hit_rates=None):
-        """The dict layout of train.py:212-220."""
+        """The dict layout of train.py:212-220; the learning rate is stored as the float the reference's files hold (not
+        the device tensor the captured Adam reads)."""
+        opt_sd = self.opt.state_dict()
+        opt_sd["param_groups"] = [dict(g, lr=float(g["lr"]), **({"initial_lr": float(g["initial_lr"])}
+                                                               if "initial_lr" in g else {}))
+                                  for g in opt_sd["param_groups"]]
         return {"epoch": epoch, "loss": loss_log, "valid_acc": hit_rate_log, "hit_rate": hit_rates,
-                "state_dict": self.model.state_dict(), "optimizer": self.opt.state_dict(),
+                "state_dict": self.model.state_dict(), "optimizer": opt_sd,
                 "scheduler": self.sched.state_dict()}
+
+    def _rebind_lr(self):
+        """After anything that may have replaced param_group['lr'] (optimizer.load_state_dict does): the loaded VALUE goes
+        into the Trainer's own device tensor -- the one a captured Adam graph reads at replay time and the scheduler
+        updates in place -- and the tensor goes back into the group."""
+        if self._lr is None:
+            return
+        for g in self.opt.param_groups:
+            if g["lr"] is not self._lr:
+                self._lr.fill_(float(g["lr"]))
+                g["lr"] = self._lr
+
+    def load_checkpoint(self, ckp):
+        """Resume from a checkpoint dict (train.py:212-220 layout; `ckp` may also be a path): model weights, Adam state,
+        scheduler.  Works before and after step_graph() has captured."""
+        if not isinstance(ckp, dict):
+            ckp = torch.load(ckp, map_location=self.device, weights_only=False)
+        from .util import strip_module_prefix
+        self.model.load_state_dict(strip_module_prefix(ckp["state_dict"]))
+        if self._graph is not None:
+            # a captured Adam updates the state tensors it was recorded with: copy INTO them instead of replacing them
+            loaded = torch.optim.Adam(self.model.parameters(), lr=float(self._lr), fused=True, capturable=True)
+            loaded.load_state_dict(ckp["optimizer"])
+            with torch.no_grad():
+                for p, st in self.opt.state.items():
+                    for k, v in st.items():
+                        if torch.is_tensor(v):
+                            v.copy_(loaded.state[p][k])
+            for g, gl in zip(self.opt.param_groups, loaded.param_groups):
+                self._lr.fill_(float(gl["lr"]))
+                if "initial_lr" in gl:
+                    g["initial_lr"] = float(gl["initial_lr"])
+        else:
+            self.opt.load_state_dict(ckp["optimizer"])
+        self._rebind_lr()
+        if ckp.get("scheduler") is not None:
+            self.sched.load_state_dict(ckp["scheduler"])
+        return ckp.get("epoch"), ckp.get("loss"), ckp.get("valid_acc")
 
 
 def synthetic_batch(batch, seed, device, n_samples=16000):

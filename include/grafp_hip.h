@@ -237,13 +237,6 @@ int grafp_ivfpq_scan_f32(const float *q, int nq, int d, const float *centroids, 
  * `clocks` shader cycles -- the BatchNorm rendezvous is tested next to it. */
 int grafp_debug_occupy(int blocks, int threads, int64_t clocks, grafp_stream_t stream);
 
-/* Progress flags (no reference counterpart; runtime plumbing of the data-parallel step -- /root/reference/train.py:165-168
- * lets DataParallel do its reduce inside backward): grafp_flag_bump, recorded INTO a HIP graph behind the work it marks,
- * adds 1 to a device int (release, device scope); grafp_flag_wait, enqueued on another stream after the graph's replay,
- * holds that stream (one polling wave) until the flag has reached `value`.  The wait is bounded (~10 s, then a trap). */
-int grafp_flag_bump(int32_t *flag, grafp_stream_t stream);
-int grafp_flag_wait(const int32_t *flag, int32_t value, grafp_stream_t stream);
-
 /* ---- K9 forward / data gradient: the 1x1 convolution itself as a streaming bf16 GEMM, BatchNorm folded in ----
  * y[r][m] = sum_k w[r][k] * f(x[k][m]) for every Conv2d(1x1) of the encoder (encoder/gcn_lib/torch_vertex.py:152-162,
  * torch_nn.py:56-60, encoder/graph_encoder.py:21-24,52-55) and, with w transposed by the caller, its data gradient

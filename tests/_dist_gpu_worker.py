@@ -13,12 +13,15 @@ from grafp_amd.train import Trainer, build_model, synthetic_batch      # noqa: E
 from grafp_amd.util import load_config                                 # noqa: E402
 
 
-def graph_mode(out, B, rccl_one_rank=False, overlap=False):
-    """Trainer.step_graph under data parallelism (three graphs, eager collectives between) against Trainer.step from
-    the same weights and optimizer state, on this rank's shard: losses and parameter updates.
+def graph_mode(out, B, rccl_one_rank=False, overlap=True, timeline=False):
+    """Trainer.step_graph under data parallelism (forward graph, one backward graph per gradient bucket, Adam graph, eager
+    collectives between) against Trainer.step from the same weights and optimizer state, on this rank's shard: losses
+    and parameter updates.
     rccl_one_rank: a ONE-rank process group on the `nccl` (= RCCL) backend with the data-parallel graph form forced --
-    the only way to run RCCL's kernels, the bucket progress flags and the communication stream on a one-GPU box;
-    overlap: the opt-in form that starts each bucket's all-reduce behind its flag (Trainer(overlap_graph_allreduce=True))."""
+    the only way to run RCCL's launches between the replayed graphs on a one-GPU box;
+    overlap=False: ONE backward graph with every bucket reduced behind it (Trainer(overlap_graph_allreduce=False));
+    timeline: also record WHEN work ordered behind each bucket's graph (where its all-reduce goes) completes relative to
+    the end of the last backward graph."""
     if rccl_one_rank:
         rank, world, device = 0, 1, torch.device("cuda", 0)
         torch.cuda.set_device(0)
@@ -40,6 +43,34 @@ def graph_mode(out, B, rccl_one_rank=False, overlap=False):
     sl = slice(rank * per, (rank + 1) * per)
     x_i, x_j = synthetic_batch(B, 7, device)
     tr.step_graph(x_i[sl], x_j[sl])                                # warm-up, capture, first replay
+    n_parts = len(tr._graph[1][1])
+    assert n_parts == (len(tr.sync.bounds) if overlap else 1), (n_parts, len(tr.sync.bounds))
+    marks = []
+    if timeline:
+        # where reduce_buckets() launches bucket b's all-reduce, ALSO put a marker on a side stream that waits for the main
+        # stream's position at that moment (what RCCL's own stream does): a small kernel + an event.  After the step:
+        # how long before the end of the last backward graph did each marker complete?
+        side = torch.cuda.Stream()
+        scratch = torch.zeros(1 << 16, device=device)
+        orig_reduce, orig_wait = tr.sync.reduce_buckets, tr.sync.wait_reduced
+
+        def reduce_and_mark(buckets):
+            orig_reduce(buckets)
+            here = torch.cuda.Event()
+            here.record()
+            side.wait_event(here)
+            with torch.cuda.stream(side):
+                scratch.add_(1.0)
+                done = torch.cuda.Event(enable_timing=True)
+                done.record()
+            marks[-1].append((list(buckets), done))
+
+        def wait_and_mark():
+            end = torch.cuda.Event(enable_timing=True)
+            end.record()                                             # behind the last backward graph
+            marks[-1].append(("end", end))
+            orig_wait()
+        tr.sync.reduce_buckets, tr.sync.wait_reduced = reduce_and_mark, wait_and_mark
 
     def snapshot():
         return ([p.detach().clone() for p in model.parameters()], [b.detach().clone() for b in model.buffers()],
@@ -62,11 +93,17 @@ def graph_mode(out, B, rccl_one_rank=False, overlap=False):
         loss_e = float(tr.step(y_i[sl], y_j[sl]))
         p_e = torch.cat([p.detach().flatten() for p in model.parameters()]).clone()
         restore(snap)
+        marks.append([])
         loss_g = float(tr.step_graph(y_i[sl], y_j[sl]))
         p_g = torch.cat([p.detach().flatten() for p in model.parameters()]).clone()
         p_0 = torch.cat([v.flatten() for v in snap[0]])
         res.append({"loss_e": loss_e, "loss_g": loss_g, "d_e": float((p_e - p_0).norm()),
-                    "d_diff": float((p_g - p_e).norm()), "p_sum": float(p_g.double().sum())})
+                    "d_diff": float((p_g - p_e).norm()), "p_sum": float(p_g.double().sum()), "n_graphs": n_parts + 2,
+                    "bucket_numel": [hi - lo for lo, hi in tr.sync.bounds]})
+        if timeline:
+            torch.cuda.synchronize()
+            end = [e for tag, e in marks[-1] if tag == "end"][0]
+            res[-1]["ms_before_backward_end"] = [(b, e.elapsed_time(end)) for b, e in marks[-1] if b != "end"]
     torch.cuda.synchronize()
     torch.save(res, f"{out}.{rank}.pt")
     torch.distributed.barrier()
@@ -75,8 +112,9 @@ def graph_mode(out, B, rccl_one_rank=False, overlap=False):
 
 def main():
     out, B = sys.argv[1], int(sys.argv[2])
-    if len(sys.argv) > 3 and sys.argv[3] in ("graph", "graph_rccl1", "graph_rccl1_overlap"):
-        return graph_mode(out, B, rccl_one_rank=sys.argv[3] != "graph", overlap=sys.argv[3] == "graph_rccl1_overlap")
+    if len(sys.argv) > 3 and sys.argv[3] in ("graph", "graph_rccl1", "graph_rccl1_single", "graph_rccl1_timeline"):
+        return graph_mode(out, B, rccl_one_rank=sys.argv[3] != "graph", overlap=sys.argv[3] != "graph_rccl1_single",
+                          timeline=sys.argv[3] == "graph_rccl1_timeline")
     rank, world, device = gdist.init_from_env(backend="gloo", local_device=0)
     cfg = load_config()
     cfg["bsz_train"] = B

@@ -403,6 +403,65 @@ def test_step_graph_follows_the_scheduler_and_restores_on_failure(dev, monkeypat
     assert 0.0 < moved <= 10.0 * float(lr)                   # Adam: |update| ~ lr per element
 
 
+def test_resume_then_step_graph_keeps_the_scheduler_in_charge(dev, tmp_path):
+    """optimizer.load_state_dict REPLACES param_group['lr'] (a float from a reference-format checkpoint, another
+    tensor from an own one).  Trainer.load_checkpoint -- and util.load_ckp on trainer.opt followed by any step -- put the
+    VALUE into the Trainer's own device tensor, so a capture after the resume still reads the rate at replay time; a resume
+    AFTER the capture keeps the captured state tensors.  checkpoint() stores the rate as a float (train.py:212-220)."""
+    from grafp_amd.train import Trainer, build_model, synthetic_batch
+    from grafp_amd.util import load_ckp, load_config, save_ckp
+    cfg = load_config()
+    cfg["bsz_train"] = 8
+    torch.manual_seed(9)
+    model = build_model(cfg, device=dev)
+    tr = Trainer(cfg, model, dev, amp_dtype=torch.bfloat16)
+    xi, xj = synthetic_batch(8, 61, dev)
+    tr.step(xi, xj)
+    tr.sched.step()
+    ckp = tr.checkpoint(1, [0.0], [0.0])
+    lr_saved = ckp["optimizer"]["param_groups"][0]["lr"]
+    assert isinstance(lr_saved, float) and 0.0 < lr_saved < cfg["lr"]
+    save_ckp(ckp, "m", str(tmp_path), "1")
+    path = str(tmp_path / "model_m_1.pth")
+
+    def flat(m):
+        return torch.cat([p.detach().flatten() for p in m.parameters()]).clone()
+
+    for how in ("load_checkpoint", "util.load_ckp"):
+        torch.manual_seed(10)
+        m2 = build_model(cfg, device=dev)
+        t2 = Trainer(cfg, m2, dev, amp_dtype=torch.bfloat16)
+        if how == "load_checkpoint":
+            t2.load_checkpoint(path)
+        else:
+            load_ckp(path, m2, optimizer=t2.opt, scheduler=t2.sched, map_location=dev)
+            assert t2.opt.param_groups[0]["lr"] is not t2._lr          # what torch does; the next step repairs it
+        assert torch.equal(flat(m2), flat(model))
+        t2.step_graph(xi, xj)                                          # capture AFTER the resume
+        lr = t2.opt.param_groups[0]["lr"]
+        assert lr is t2._lr and abs(float(lr) - lr_saved) < 1e-12 * max(1.0, lr_saved) + 1e-10
+        lr.fill_(0.0)
+        before = flat(m2)
+        t2.step_graph(xi, xj)
+        assert torch.equal(flat(m2), before)                           # the replay READS the tensor: lr = 0 moves nothing
+        lr.fill_(lr_saved)
+        t2.sched.step()
+        assert t2.opt.param_groups[0]["lr"] is t2._lr and 0.0 < float(lr) < lr_saved
+        t2.step_graph(xi, xj)
+        moved = float((flat(m2) - before).abs().max())
+        assert 0.0 < moved <= 10.0 * float(lr)
+    # resume AFTER the capture: the graph keeps running on its own state tensors, now holding the checkpoint's values
+    t2.load_checkpoint(path)
+    assert torch.equal(flat(m2), flat(model)) and t2.opt.param_groups[0]["lr"] is t2._lr
+    p0 = next(iter(tr.opt.state))
+    q0 = next(iter(t2.opt.state))
+    assert torch.equal(tr.opt.state[p0]["exp_avg"], t2.opt.state[q0]["exp_avg"])
+    t2._lr.fill_(0.0)
+    before = flat(m2)
+    t2.step_graph(xi, xj)
+    assert torch.equal(flat(m2), before)
+
+
 def test_backward_after_another_forward_refuses_the_shared_weight_copies(dev):
     """The bf16 / transposed weight copies of ops.lowp_weights are shared between passes and rewritten by every encoder
     forward under autocast: a backward pass whose forward saw an older preparation raises instead of
@@ -417,6 +476,17 @@ def test_backward_after_another_forward_refuses_the_shared_weight_copies(dev):
         z_i.sum().backward()
     with torch.autocast("cuda", dtype=torch.bfloat16):
         _, _, z_i, _ = model(xi.to(dev), xj.to(dev))
+    z_i.sum().backward()
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+    # the counter belongs to the ENCODER INSTANCE whose buffers it guards -- a forward pass of ANOTHER model
+    # (a teacher / EMA copy, a second Trainer) between this model's forward and backward touches none of them
+    _, other = _filled_model(dev)
+    for p in model.parameters():
+        p.grad = None
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        _, _, z_i, _ = model(xi.to(dev), xj.to(dev))
+        with torch.no_grad():
+            other(xi.to(dev), xj.to(dev))
     z_i.sum().backward()
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
 
