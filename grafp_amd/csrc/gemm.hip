@@ -68,7 +68,7 @@ typedef GemmCfg<1, 8, 4, 32> GemmN128;
 // (Measured and dropped, round 3: M = 2 x 2 waves, RT 4 -> 256 x 128 with THREE 24 KB stages + 2 KB staging slabs = 80 KB,
 //  i.e. two workgroups per CU that run out of phase by themselves, one's MFMA chain under the other's epilogue and store
 //  drain: 10-15 % SLOWER than L on every stage 2-3 shape, 37.6 vs 34.0 ms over a step's products at 2048 clip-views.)
-enum { GM_CFG_S = 0, GM_CFG_L = 1, GM_CFG_N32 = 2, GM_CFG_N64 = 3, GM_CFG_N128 = 4 };
+enum { GM_CFG_S = 0, GM_CFG_L = 1, GM_CFG_N32 = 2, GM_CFG_N64 = 3, GM_CFG_N128 = 4, GM_CFG_XL = 5 };   // XL: gemm_xl.h
 
 struct GemmPlan {
     int cfg;                                     // tile configuration (GM_CFG_*)
@@ -91,6 +91,13 @@ static GemmPlan gemm_plan(int Rg, int K, int groups, int64_t M, int views) {
     const bool large = (Rg >= 512 || (Rg >= 256 && (K >= 512 || Mg >= (1 << 19) || (K >= 128 && Mg >= (1 << 18))))) &&
                        Mg % GemmL::TN == 0;
     p.cfg = large ? GM_CFG_L : GM_CFG_S;
+    // Round 4: the four-wave 256 x 256 tile (gemm_xl.h) where it measured faster than the eight-wave one at 2048 clip-views
+    // (tools/gemm_bench.py --cfgs auto,L,XL; profiles/r04_gemm_xl_2048.txt): ungrouped products with 256 or 512 output rows
+    // and >= 512 operand rows, -4 ... -12 % (deep contractions most: its main loop keeps the matrix pipe fed, and its
+    // epilogue hides in the next tile).  With >= 1024 output rows or K <= 256 a tile is a short loop in front of 128 KB of
+    // stores per workgroup: the product is bound by the vector-memory pipe (LDS-DMA and stores do not overlap) and the two
+    // tiles tie or the eight-wave one wins by 3-6 %.
+    if (large && groups == 1 && Rg % 256 == 0 && Rg <= 512 && K >= 512) p.cfg = GM_CFG_XL;
     // <= 128 rows per group: the 512-column tiles where they measured faster than both --
     //   N128 (65 ... 128 rows, ungrouped): from 512 operand rows at 2^17 columns per view, from 128 operand rows at 2^19
     //        (-15 ... -25 % on the stage-1 shapes at 2048 clip-views, -10 % on the deep ones at 512; the shallow ones at
@@ -106,11 +113,14 @@ static GemmPlan gemm_plan(int Rg, int K, int groups, int64_t M, int views) {
         }
     }
     const int force = GRAFP_TUNE_INT("GRAFP_GEMM_CFG", -1);                 // measurement builds only (tuning.h)
-    if (force == GM_CFG_S || (force == GM_CFG_L && Mg % GemmL::TN == 0) ||
+    if (force == GM_CFG_S || ((force == GM_CFG_L || force == GM_CFG_XL) && Mg % GemmL::TN == 0) ||
         (force >= GM_CFG_N32 && force <= GM_CFG_N128 && Mg % GemmN64::TN == 0))
         p.cfg = force;
-    static const int trs[5] = {GemmS::TR, GemmL::TR, GemmN32::TR, GemmN64::TR, GemmN128::TR};
-    static const int tns[5] = {GemmS::TN, GemmL::TN, GemmN32::TN, GemmN64::TN, GemmN128::TN};
+    // the four-wave tile (gemm_xl.h) takes whole 256-row tiles and hides a tile's epilogue in the next tile's first four
+    // chunks: rows per group a multiple of 256, at least 128 operand rows
+    if (p.cfg == GM_CFG_XL && (Rg % 256 != 0 || K < 4 * GM_KC)) p.cfg = GM_CFG_L;
+    static const int trs[6] = {GemmS::TR, GemmL::TR, GemmN32::TR, GemmN64::TR, GemmN128::TR, 256};
+    static const int tns[6] = {GemmS::TN, GemmL::TN, GemmN32::TN, GemmN64::TN, GemmN128::TN, 256};
     p.tr = trs[p.cfg];
     p.tn = tns[p.cfg];
     p.wm = p.tn / 64;
@@ -519,6 +529,10 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::NW == 4 ? 2 : 1) void conv1x1_ge
     }
 }
 
+}  // namespace grafp
+#include "gemm_xl.h"
+namespace grafp {
+
 // Statistics of row c, view v from the P partials of the GEMM (n_p columns each): Chan's combination of
 // (count, mean, M2) in a fixed order (lane-strided partials, then a 6-step butterfly: deterministic) -> mean, invstd
 // saved for backward; (scale, shift) for the affine kernel / the next GEMM's PRO: z = act(y * scale + shift); running
@@ -764,6 +778,14 @@ static void gemm_launch(const GemmPlan &p, const GemmArgs &a, hipStream_t s) {
                        p.tiles_range, p.col_tiles_view, a.views, a.pro_tab, a.pro_act, a.pro_slope, a.part, p.P, p.nblocks,
                        a.x2, a.K1, a.epi_tab, a.epi_act, a.epi_slope);
 }
+template <bool STATS, bool CAT, bool EPI, int ABL = 0>
+static void gemm_launch_xl(const GemmPlan &p, const GemmArgs &a, hipStream_t s) {
+    (void)hipFuncSetAttribute((const void *)conv1x1_gemm_xl_kernel<STATS, CAT, EPI, ABL>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmXL::LDS);
+    hipLaunchKernelGGL((conv1x1_gemm_xl_kernel<STATS, CAT, EPI, ABL>), dim3(p.nblocks, 1, a.groups), dim3(GemmXL::THREADS),
+                       GemmXL::LDS, s, a.w, a.lda, a.x, a.y, a.M, a.Rg, a.Kg, p.row_tiles, p.ranges_view, p.tiles_range,
+                       p.col_tiles_view, a.views, a.part, p.P, p.nblocks, a.x2, a.K1, a.epi_tab, a.epi_act, a.epi_slope);
+}
 // plain / statistics / concatenated-operand forms of one tile configuration
 template <typename CFG, int NS> static void gemm_launch_cfg(const GemmPlan &p, const GemmArgs &a, hipStream_t s) {
     if (a.epi_tab) gemm_launch<CFG, NS, false, false, false, true>(p, a, s);
@@ -779,6 +801,7 @@ static void gemm_dispatch(const GemmPlan &p, const GemmArgs &a, hipStream_t s) {
         else gemm_launch<CFG, 3, true, false, false>(p, a, s);             \
     } while (0)
         switch (p.cfg) {
+        case GM_CFG_XL:                                  // (no normalise-on-load form of the four-wave tile: same tile grid)
         case GM_CFG_L: GM_PRO(GemmL); break;
         case GM_CFG_N32: GM_PRO(GemmN32); break;
         case GM_CFG_N64: GM_PRO(GemmN64); break;
@@ -789,6 +812,27 @@ static void gemm_dispatch(const GemmPlan &p, const GemmArgs &a, hipStream_t s) {
         return;
     }
     switch (p.cfg) {
+    case GM_CFG_XL:
+#ifdef GRAFP_MEASURE
+        switch (a.part && !a.x2 && !a.epi_tab ? GRAFP_TUNE_INT("GRAFP_XL_ABL", 0) : 0) {      // tools/gemm_bench.py --abl
+        case 1: gemm_launch_xl<true, false, false, 1>(p, a, s); return;
+        case 2: gemm_launch_xl<true, false, false, 2>(p, a, s); return;
+        case 3: gemm_launch_xl<true, false, false, 3>(p, a, s); return;
+        case 5: gemm_launch_xl<true, false, false, 5>(p, a, s); return;
+        case 7: gemm_launch_xl<true, false, false, 7>(p, a, s); return;
+        case 8: gemm_launch_xl<true, false, false, 8>(p, a, s); return;
+        case 10: gemm_launch_xl<true, false, false, 10>(p, a, s); return;
+        case 11: gemm_launch_xl<true, false, false, 11>(p, a, s); return;
+        case 13: gemm_launch_xl<true, false, false, 13>(p, a, s); return;
+        case 14: gemm_launch_xl<true, false, false, 14>(p, a, s); return;
+        default: break;
+        }
+#endif
+        if (a.epi_tab) gemm_launch_cfg<GemmL, 4>(p, a, s);          // eval-mode affine epilogue: the eight-wave tile (same grid)
+        else if (a.x2) gemm_launch_xl<false, true, false>(p, a, s);
+        else if (a.part) gemm_launch_xl<true, false, false>(p, a, s);
+        else gemm_launch_xl<false, false, false>(p, a, s);
+        break;
     case GM_CFG_L: gemm_launch_cfg<GemmL, 4>(p, a, s); break;       // four stages = all 160 KB (-2.7 % against three)
     case GM_CFG_N32: gemm_launch_cfg<GemmN32, 4>(p, a, s); break;
     case GM_CFG_N64: gemm_launch_cfg<GemmN64, 4>(p, a, s); break;

@@ -22,6 +22,7 @@ def test_wgrad_staging_registers_are_left_alone_by_the_compiler():
     assert res.returncode == 0, res.stdout
     assert "contract holds for 2 instantiations" in res.stdout
     assert "no high-register splat in a packed subtraction" in res.stdout
+    assert "accumulator registers untouched by the compiler (3 instantiations)" in res.stdout
 
 
 _FAKE = """
@@ -59,3 +60,33 @@ def test_checker_flags_the_high_register_splat():
     bad = good.replace("v[2:3] neg_lo", "v[2:3] op_sel:[0,1] neg_lo")
     assert tool.check_gemm_splat(good) == (1, [])
     assert len(tool.check_gemm_splat(bad)[1]) == 1
+
+
+_FAKE_XL = """
+_ZN5grafp22conv1x1_gemm_xl_kernelILb1ELb0ELb0ELi0EEEvPKt: ; @fake
+\t;;#ASMSTART
+\tv_mfma_f32_32x32x16_bf16 a[0:15], v[2:5], v[6:9], a[0:15]
+\t;;#ASMEND
+\t;;#ASMSTART
+\tv_accvgpr_read_b32 v3, a[4]
+\t;;#ASMEND
+{extra}
+\ts_endpgm
+  - .agpr_count:     {agpr}
+    .name:           _ZN5grafp22conv1x1_gemm_xl_kernelILb1ELb0ELb0ELi0EEEvPKt
+    .private_segment_fixed_size: 0
+    .vgpr_count:     484
+    .wavefront_size: 64
+"""
+
+
+def test_checker_guards_the_accumulator_file_of_the_four_wave_gemm():
+    """gemm_xl.h names its accumulators a0-a255 in asm text: a compiler-generated v_accvgpr_* (a parked value, a moved
+    placeholder), a scratch access or a descriptor without all 256 AGPRs must fail the build check; the shipped source
+    passes (asserted through the tool's own run above: its output names the kernel)."""
+    tool = _tool()
+    assert tool.check_gemm_xl(_FAKE_XL.format(extra="", agpr=256)) == (1, [])
+    assert len(tool.check_gemm_xl(_FAKE_XL.format(extra="\tv_accvgpr_write_b32 a17, v3", agpr=256))[1]) == 1
+    assert len(tool.check_gemm_xl(_FAKE_XL.format(extra="\tscratch_store_dword off, v0, off", agpr=256))[1]) == 1
+    assert len(tool.check_gemm_xl(_FAKE_XL.format(extra="", agpr=128))[1]) == 1
+    assert tool.check_gemm_xl("nothing here")[1]

@@ -30,7 +30,56 @@ SHAPES = [(64, 64, 1, 8192, 2), (256, 64, 1, 8192, 2), (64, 256, 1, 8192, 2), (1
           # the 512-column tiles of round 3 (<= 128 rows per group, >= 2^16 columns per view): N64, N32 (grouped: one
           # chunk per tile), N128, N128 with ragged rows, N64 with a ragged last column range, one-view N32
           (64, 256, 1, 131072, 2), (128, 128, 4, 131072, 2), (128, 512, 1, 262144, 2), (96, 160, 1, 524288, 1),
-          (64, 64, 1, 2 * 512 * 131, 2), (32, 96, 1, 65536, 1)]
+          (64, 64, 1, 2 * 512 * 131, 2), (32, 96, 1, 65536, 1),
+          # the four-wave 256 x 256 tile of round 4 (gemm_xl.h: 256 / 512 rows, >= 512 operand rows, ungrouped): ragged
+          # column ranges, one tile per workgroup, one view, a deep contraction
+          (256, 512, 1, 2 * 256 * 9, 2), (512, 1280, 1, 256 * 7, 1), (512, 512, 1, 256, 1), (256, 2560, 1, 2 * 256 * 33, 2)]
+
+
+def _plan_cfg(R, K, groups, M, views):
+    import ctypes
+    from grafp_amd._lib import lib
+    info = (ctypes.c_int * 8)()
+    assert lib.grafp_conv1x1_gemm_plan(R, K, groups, M, views, info) == 0
+    return info[0]
+
+
+def test_the_four_wave_tile_is_what_these_shapes_run_on():
+    """The shapes above that are meant for the four-wave tile (plan code 5) do take it, the others do not: 1024+ output
+    rows, K < 512 and grouped products stay on the eight-wave tile (measured: profiles/r04_gemm_xl_2048.txt)."""
+    for shape in ((256, 512, 1, 2 * 256 * 9, 2), (512, 1280, 1, 256 * 7, 1), (512, 512, 1, 256, 1), (512, 2048, 1, 1024, 2),
+                  (256, 768, 1, 2560, 2), (256, 2560, 1, 2 * 256 * 33, 2), (512, 1024, 1, 262144, 2)):
+        assert _plan_cfg(*shape) == 5, shape
+    for shape in ((2048, 512, 1, 1024, 1), (1024, 256, 1, 524288, 2), (1024, 1024, 4, 2048, 2), (256, 256, 1, 524288, 2),
+                  (64, 256, 1, 8192, 2)):
+        assert _plan_cfg(*shape) != 5, shape
+
+
+@pytest.mark.parametrize("R,K,M", [(256, 512, 256 * 12), (512, 1536, 256 * 6)])
+def test_four_wave_tile_launches_are_bit_identical_and_leave_no_trace_of_the_ring(R, K, M):
+    """The tile prefetches fragments across its chunk barrier and spreads a tile's epilogue over the next tile's chunks:
+    a misplaced wait shows up as run-to-run differences.  16 launches each of the plain, the statistics and the
+    concatenated-operand form on NaN-poisoned outputs: identical bits, every element written."""
+    from grafp_amd import ops
+    assert _plan_cfg(R, K, 1, M, 2) == 5
+    w, x = _rand((R, K), 11, 0.2), _rand((K, M), 12, 1.0, 0.3)
+    x1, x2 = x[:K - 256].contiguous(), x[K - 256:].contiguous()
+    first = None
+    for rep in range(16):
+        junk = torch.full((R, M), float("nan"), dtype=torch.bfloat16, device=DEV)
+        del junk
+        y, part = ops.conv1x1_gemm(w, x, 1, 2, stats=True)
+        yp = ops.conv1x1_gemm(w, x, 1, 2)
+        yc = ops.conv1x1_gemm_cat(w, x1, x2)
+        assert not bool(torch.isnan(y.float()).any())
+        got = (y.clone(), part.clone(), yp.clone(), yc.clone())
+        if first is None:
+            first = got
+        else:
+            assert all(torch.equal(a, b) for a, b in zip(first, got)), rep
+    assert torch.equal(first[0], first[2]) and torch.equal(first[0], first[3])
+    ref = (w.float() @ x.float()).to(torch.bfloat16)
+    _check_product(first[0], ref)
 
 
 @pytest.mark.parametrize("R,K,groups,M,views", SHAPES)

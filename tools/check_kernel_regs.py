@@ -83,6 +83,35 @@ def check_gemm_splat(asm):
     return kernels, errors
 
 
+def check_gemm_xl(asm):
+    """conv1x1_gemm_xl_kernel (gemm_xl.h): its 256 accumulators are AGPRs a0-a255 NAMED in asm text; the compiler only
+    knows sixteen placeholder values that occupy the file from the first instruction to the last.  Every build must show:
+    no v_accvgpr_* instruction outside the ;;#ASMSTART / ;;#ASMEND blocks (the compiler moving a placeholder or parking a
+    value of its own in an accumulator is silent corruption), no scratch access (spilled VGPRs), .agpr_count 256."""
+    errors, kernels = [], 0
+    for m in re.finditer(r"^(_ZN5grafp22conv1x1_gemm_xl_kernel\w+):\s*;[^\n]*\n(.*?)^\s*s_endpgm", asm, flags=re.S | re.M):
+        kernels += 1
+        name, in_asm = m.group(1), False
+        for ln in m.group(2).split("\n"):
+            t = ln.strip()
+            if ";;#ASMSTART" in t:
+                in_asm = True
+            elif ";;#ASMEND" in t:
+                in_asm = False
+            elif not in_asm and t.startswith("v_accvgpr"):
+                errors.append(f"{name[:60]}...: compiler-generated {t}")
+            elif t.startswith("scratch_"):
+                errors.append(f"{name[:60]}...: scratch access {t}")
+        meta = re.search(r"\.name:\s+" + re.escape(name) + r"\n(.*?)\.wavefront_size", asm, flags=re.S)
+        before = asm[:meta.start()] if meta else ""
+        agpr = re.findall(r"\.agpr_count:\s+(\d+)", before)
+        if not agpr or agpr[-1] != "256":
+            errors.append(f"{name[:60]}...: .agpr_count = {agpr[-1] if agpr else None}, expected 256")
+    if kernels == 0:
+        errors.append("no conv1x1_gemm_xl_kernel instantiation found in the assembly")
+    return kernels, errors[:20]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--hipcc", default=os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"))
@@ -107,12 +136,18 @@ def main():
         if res.returncode != 0:
             print(res.stdout)
             return 2
-        gk, gerrors = check_gemm_splat(open(out).read())
+        gemm_asm = open(out).read()
+        gk, gerrors = check_gemm_splat(gemm_asm)
+        xk, xerrors = check_gemm_xl(gemm_asm)
+    for e in xerrors:
+        print("ACCUMULATOR FILE TOUCHED BY THE COMPILER:", e)
+    if not xerrors:
+        print(f"conv1x1_gemm_xl_kernel: accumulator registers untouched by the compiler ({xk} instantiations)")
     for e in gerrors:
         print("HIGH-REGISTER SPLAT IN A PACKED SUBTRACTION:", e)
     if not gerrors:
         print(f"conv1x1_gemm_kernel: no high-register splat in a packed subtraction ({gk} instantiations)")
-    return 1 if (errors or gerrors) else 0
+    return 1 if (errors or gerrors or xerrors) else 0
 
 
 if __name__ == "__main__":

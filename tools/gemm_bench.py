@@ -19,7 +19,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from grafp_amd import ops  # noqa: E402
 from grafp_amd._lib import lib  # noqa: E402
 
-CFG_IDS = {"S": 0, "L": 1, "N32": 2, "N64": 3, "N128": 4}
+CFG_IDS = {"S": 0, "L": 1, "N32": 2, "N64": 3, "N128": 4, "XL": 5}
 CFG_NAMES = {v: k for k, v in CFG_IDS.items()}
 
 
