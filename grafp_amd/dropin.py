@@ -8,10 +8,14 @@
     from eval import eval_faiss, get_index, load_memmap_data
     from test_fp import create_fp_db, create_dummy_db    # -> grafp_amd.fpdb
     from generate import create_db
+    import faiss                                         # -> grafp_amd.faiss_standin (when no real faiss is installed)
 
-These are the names train.py:16-23, generate.py:10-17 and test_fp.py:18-26 import.
+These are the names train.py:16-23, generate.py:10-17 and test_fp.py:18-26 import.  With the reference's directory on
+sys.path, `python train.py` / `test_fp.py` / `generate.py` then run as they are (tests/test_host_cpu.py imports them that
+way); `util` and `modules.data` stay the reference's own host-side files there.
 """
 import importlib
+import importlib.util
 import sys
 
 _ALIASES = {
@@ -33,11 +37,52 @@ _ALIASES = {
     "generate": "grafp_amd.fpdb",
     "util": "grafp_amd.util",
 }
+# Host-side modules of the reference that this package only partly mirrors (dataset index / decoding helpers are out of
+# scope): inside a checkout of the reference -- its directory on sys.path -- the scripts keep THEIR OWN file, elsewhere
+# the alias applies.  `modules` is kept as the reference's package there too (modules/data.py is its dataset code), with
+# only modules.transformations replaced.
+_KEEP_OWN_IF_PRESENT = ("util", "modules")
 
 
-def install(overwrite=False):
+def _real_module_on_path(name):
+    """Is there a module `name` on sys.path that is not this package's alias?"""
+    if name in sys.modules and not getattr(sys.modules[name], "__name__", "").startswith("grafp_amd"):
+        return True
+    try:
+        spec = importlib.util.find_spec(name) if name not in sys.modules else None
+    except (ImportError, ValueError):
+        spec = None
+    return spec is not None
+
+
+def install(overwrite=False, faiss=True):
+    """Register the aliases (and, unless a real faiss is importable, `faiss` = grafp_amd.faiss_standin: the reference's
+    eval.py:3 and test_fp.py:7 import it at module level)."""
+    done = []
     for alias, target in _ALIASES.items():
         if alias in sys.modules and not overwrite:
             continue
+        if alias in _KEEP_OWN_IF_PRESENT:
+            saved = sys.modules.pop(alias, None) if overwrite else None
+            own = _real_module_on_path(alias)
+            if saved is not None and not own:
+                sys.modules[alias] = saved
+            if own:
+                continue
         sys.modules[alias] = importlib.import_module(target)
-    return sorted(_ALIASES)
+        parent, _, child = alias.rpartition(".")
+        if parent and parent in sys.modules:          # `import modules.transformations` binds the attribute as well
+            setattr(sys.modules[parent], child, sys.modules[alias])
+        done.append(alias)
+    if "modules.transformations" in sys.modules and "modules" not in sys.modules and _real_module_on_path("modules"):
+        pkg = importlib.import_module("modules")        # the reference's own package, with our transformations inside
+        setattr(pkg, "transformations", sys.modules["modules.transformations"])
+    if faiss and "faiss" not in sys.modules:
+        try:
+            real = importlib.util.find_spec("faiss")
+        except (ImportError, ValueError):
+            real = None
+        if real is None:
+            sys.modules["faiss"] = importlib.import_module("grafp_amd.faiss_standin")
+            done.append("faiss")
+    return sorted(done)
