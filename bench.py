@@ -96,11 +96,13 @@ def summarise_kernels(timed, esize=4):
     `bytes` = the ALGORITHMIC bytes of the timed launches (operands read once, results written once)."""
     from grafp_amd import ops
     out = {}
+    # the batched reduction of the weight gradients' partial sums (one launch per backward pass) belongs to that family
+    wgrad_reduce_ms = sum(ops.elapsed_ms(timed.get("conv1x1_wgrad_reduce") or []))
     for name, ev in timed.items():
-        if not ev:
+        if not ev or name == "conv1x1_wgrad_reduce":
             continue
         ms = ops.elapsed_ms(ev)
-        tot = sum(ms)
+        tot = sum(ms) + (wgrad_reduce_ms if name == "conv1x1_wgrad" else 0.0)
         row = {"calls": len(ev), "total_ms": round(tot, 4), "avg_us": round(1e3 * tot / len(ev), 2)}
         by = None
         if name == "knn_topk":
@@ -176,7 +178,7 @@ def summarise_kernels(timed, esize=4):
     return out
 
 
-KERNEL_NAMES = ("conv1x1_gemm", "conv1x1_wgrad", "bn_bwd", "bn_affine", "bn_fwd", "knn_split", "knn_topk", "knn_normalize",
+KERNEL_NAMES = ("conv1x1_gemm", "conv1x1_wgrad", "conv1x1_wgrad_reduce", "bn_bwd", "bn_affine", "bn_fwd", "knn_split", "knn_topk", "knn_normalize",
                 "mrconv_fwd", "mrconv_bwd", "ntxent", "logmel", "peak_extract_fwd", "peak_extract_bwd")
 
 

@@ -82,6 +82,8 @@ SIGNATURES = {
     "grafp_conv1x1_wgrad_pro_bf16": (_I, [_P, _P, _I, _I, _I, _L, _I, _P, _I, _F, _P, _P, _Z, _P]),
     "grafp_conv1x1_wgrad_tile_workspace": (_Z, [_I, _I, _I, _L, _I, _I]),
     "grafp_conv1x1_wgrad_tile_bf16": (_I, [_P, _P, _I, _I, _I, _L, _I, _P, _I, _F, _I, _P, _P, _Z, _P]),
+    "grafp_conv1x1_wgrad_partials_bf16": (_I, [_P, _P, _I, _I, _I, _L, _I, _P, _I, _F, _I, _P, _Z, _P, _P]),
+    "grafp_wgrad_reduce_multi": (_I, [_P, _P, _P, _P, _I, _P]),
     "grafp_conv1x1_wgrad_f32_workspace": (_Z, [_I, _I, _I, _L]),
     "grafp_conv1x1_wgrad_f32": (_I, [_P, _P, _I, _I, _I, _L, _P, _P, _Z, _P]),
     "grafp_ntxent_workspace": (_Z, [_I]),

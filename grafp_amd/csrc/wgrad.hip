@@ -772,11 +772,13 @@ extern "C" size_t grafp_conv1x1_wgrad_workspace(int Cout, int Cin, int groups, i
     return grafp_conv1x1_wgrad_pro_workspace(Cout, Cin, groups, M, 1);
 }
 
-extern "C" int grafp_conv1x1_wgrad_tile_bf16(const void *grad_out, const void *x, int Cout, int Cin, int groups,
-                                             int64_t M, int views, const float *pro_tab, int pro_act, float pro_slope,
-                                             int tile, float *dweight, void *ws, size_t ws_bytes, grafp_stream_t stream) {
+// dweight == nullptr: the partial sums only (n_slices receives how many there are per output element); the caller reduces
+// them later, together with other layers' (grafp_wgrad_reduce_multi)
+static int wgrad_tile_impl(const void *grad_out, const void *x, int Cout, int Cin, int groups, int64_t M, int views,
+                           const float *pro_tab, int pro_act, float pro_slope, int tile, float *dweight, void *ws,
+                           size_t ws_bytes, int *n_slices, grafp_stream_t stream) {
     using namespace grafp;
-    GRAFP_REQUIRE(grad_out && x && dweight, "conv1x1_wgrad: null pointer");
+    GRAFP_REQUIRE(grad_out && x && (dweight || n_slices), "conv1x1_wgrad: null pointer");
     GRAFP_REQUIRE(Cout > 0 && Cin > 0 && groups > 0 && M > 0 && Cout % groups == 0 && Cin % groups == 0,
                   "conv1x1_wgrad: bad shape Cout=%d Cin=%d groups=%d M=%lld", Cout, Cin, groups, (long long)M);
     GRAFP_REQUIRE((((uintptr_t)grad_out | (uintptr_t)x) & 15) == 0, "conv1x1_wgrad: operands must be 16-byte aligned");
@@ -840,6 +842,8 @@ extern "C" int grafp_conv1x1_wgrad_tile_bf16(const void *grad_out, const void *x
 #undef WG_LAUNCH
 #undef WG_LAUNCH_GR
         GRAFP_CHECK_LAUNCH("wgrad_dma_kernel");
+        if (n_slices) *n_slices = p.nslices;
+        if (!dweight) return GRAFP_OK;
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, s, (const float *)ws,
                            p.nslices, n, dweight);
         GRAFP_CHECK_LAUNCH("wgrad_reduce_kernel");
@@ -860,9 +864,93 @@ extern "C" int grafp_conv1x1_wgrad_tile_bf16(const void *grad_out, const void *x
                            (const unsigned short *)x, M, cout_g, cin_g, p.tiles_o, p.tiles_c, p.cols, (float *)ws);
     }
     GRAFP_CHECK_LAUNCH("wgrad_partial_kernel");
+    if (n_slices) *n_slices = p.S;
+    if (!dweight) return GRAFP_OK;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, s, (const float *)ws, p.S, n,
                        dweight);
     GRAFP_CHECK_LAUNCH("wgrad_reduce_kernel");
+    return GRAFP_OK;
+}
+
+extern "C" int grafp_conv1x1_wgrad_tile_bf16(const void *grad_out, const void *x, int Cout, int Cin, int groups,
+                                             int64_t M, int views, const float *pro_tab, int pro_act, float pro_slope,
+                                             int tile, float *dweight, void *ws, size_t ws_bytes, grafp_stream_t stream) {
+    GRAFP_REQUIRE(dweight, "conv1x1_wgrad: null pointer");
+    return wgrad_tile_impl(grad_out, x, Cout, Cin, groups, M, views, pro_tab, pro_act, pro_slope, tile, dweight, ws, ws_bytes,
+                           nullptr, stream);
+}
+
+extern "C" int grafp_conv1x1_wgrad_partials_bf16(const void *grad_out, const void *x, int Cout, int Cin, int groups,
+                                                 int64_t M, int views, const float *pro_tab, int pro_act, float pro_slope,
+                                                 int tile, void *ws, size_t ws_bytes, int *n_slices,
+                                                 grafp_stream_t stream) {
+    GRAFP_REQUIRE(n_slices, "conv1x1_wgrad_partials: null pointer");
+    return wgrad_tile_impl(grad_out, x, Cout, Cin, groups, M, views, pro_tab, pro_act, pro_slope, tile, nullptr, ws, ws_bytes,
+                           n_slices, stream);
+}
+
+// The reductions of MANY layers' partial sums in one launch: a training step has 64 weight gradients, each followed by a
+// ~4-8 us reduction launch of its own -- 3 % of the GPU time of a 128-pairs-per-GPU step (profiles/r04_a128_kernel_stats).
+// The table travels BY VALUE in the kernel arguments (no host-to-device copy: the launch is graph-capturable and needs
+// no device buffer); same 16 x 16 summation tree as wgrad_reduce_kernel, so the gradients are bit-identical.
+namespace grafp {
+constexpr int WG_MULTI = 64;
+struct WgReduceTable {
+    const float *part[WG_MULTI];
+    float *out[WG_MULTI];
+    int S[WG_MULTI], n[WG_MULTI], block_base[WG_MULTI + 1];
+    int count;
+};
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const WgReduceTable t) {
+    __shared__ float red[16][17];
+    int e = 0;
+    while (e + 1 < t.count && (int)blockIdx.x >= t.block_base[e + 1]) ++e;         // uniform, <= 64 steps
+    const float *__restrict__ part = t.part[e];
+    const int S = t.S[e];
+    const int64_t n = t.n[e];
+    const int tid = threadIdx.x, j = tid & 15, q = tid >> 4;
+    const int64_t i = (int64_t)(blockIdx.x - t.block_base[e]) * 16 + j;
+    float s = 0.0f;
+    if (i < n) {
+#pragma unroll 4
+        for (int k = q; k < S; k += 16) s += part[(size_t)k * n + i];
+    }
+    red[q][j] = s;
+    __syncthreads();
+    if (tid < 16 && i < n) {
+        float r = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) r += red[k][tid];
+        t.out[e][i] = r;
+    }
+}
+}  // namespace grafp
+
+extern "C" int grafp_wgrad_reduce_multi(const void *const *parts, const int *n_slices, const int64_t *n_out,
+                                        float *const *outs, int n_entries, grafp_stream_t stream) {
+    using namespace grafp;
+    GRAFP_REQUIRE(n_entries >= 0 && (n_entries == 0 || (parts && n_slices && n_out && outs)), "wgrad_reduce_multi: null pointer");
+    for (int e0 = 0; e0 < n_entries; e0 += WG_MULTI) {
+        WgReduceTable t;
+        t.count = n_entries - e0 < WG_MULTI ? n_entries - e0 : WG_MULTI;
+        int blocks = 0;
+        for (int e = 0; e < t.count; ++e) {
+            GRAFP_REQUIRE(parts[e0 + e] && outs[e0 + e] && n_slices[e0 + e] > 0 && n_out[e0 + e] > 0 && n_out[e0 + e] < (1ll << 31),
+                          "wgrad_reduce_multi: bad entry %d", e0 + e);
+            t.part[e] = (const float *)parts[e0 + e];
+            t.out[e] = outs[e0 + e];
+            t.S[e] = n_slices[e0 + e];
+            t.n[e] = (int)n_out[e0 + e];
+            t.block_base[e] = blocks;
+            blocks += (int)((n_out[e0 + e] + 15) / 16);
+        }
+        t.block_base[t.count] = blocks;
+        for (int e = t.count; e < WG_MULTI; ++e) {
+            t.part[e] = nullptr; t.out[e] = nullptr; t.S[e] = 0; t.n[e] = 0; t.block_base[e + 1] = blocks;
+        }
+        hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t);
+        GRAFP_CHECK_LAUNCH("wgrad_reduce_multi_kernel");
+    }
     return GRAFP_OK;
 }
 

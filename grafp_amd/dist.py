@@ -195,6 +195,9 @@ class GradSync:
         in this step (grad None) contributes zero: ONLY its own slice is cleared -- members whose .grad already is
         their flat view (gradient accumulation without zero()) keep what they hold."""
         members = self._members[b]
+        if self.flat.is_cuda:                         # gradients whose reduction is still queued (ops.defer_wgrad_reduce)
+            from . import ops
+            ops.flush_wgrad_reduce()
         missing = [p for p in members if p.grad is None]
         if missing:
             torch._foreach_zero_([self._view[id(p)] for p in missing])

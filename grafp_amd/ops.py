@@ -876,7 +876,45 @@ def _bn_bwd(y, dz, C, M, views, pb, g32, b32, mean, invstd, act, slope, training
     return dy, dgamma, dbeta, dpb
 
 
-def _wgrad_bf16(g, x, cout, cin, groups, M, views=1, pro_tab=None, pro_act=ACT_NONE, pro_slope=0.0, tile=-1):
+# ---- the reductions of a step's weight gradients, deferred and batched (grafp_wgrad_reduce_multi) ----
+_WGRAD_PENDING = None        # None: every weight gradient reduces its own partial sums at once; a list: they queue up
+
+
+def flush_wgrad_reduce():
+    """Reduce every queued weight gradient's partial sums now (one launch per 64 layers).  Called when the block below
+    ends and by whoever reads a gradient before that (dist.GradSync packs a bucket while backward is still running)."""
+    global _WGRAD_PENDING
+    q = _WGRAD_PENDING
+    if not q:
+        return
+    _WGRAD_PENDING = []
+    n = len(q)
+    parts = (ctypes.c_void_p * n)(*[ws.data_ptr() for ws, _, _, _ in q])
+    slices = (ctypes.c_int * n)(*[S for _, S, _, _ in q])
+    sizes = (ctypes.c_int64 * n)(*[dw.numel() for _, _, dw, _ in q])
+    outs = (ctypes.c_void_p * n)(*[dw.data_ptr() for _, _, dw, _ in q])
+    with _timed("conv1x1_wgrad_reduce", (n,)):
+        check(lib.grafp_wgrad_reduce_multi(parts, slices, sizes, outs, n, _stream()), "wgrad_reduce_multi")
+
+
+@contextlib.contextmanager
+def defer_wgrad_reduce():
+    """Inside the block (a backward pass) the bf16 weight gradients only run their split-K kernels; the partial sums of
+    all layers are reduced together when the block ends (or at flush_wgrad_reduce()): ~60 launches fewer per step, the
+    same bits.  The returned gradient tensors must not be READ inside the block without a flush."""
+    global _WGRAD_PENDING
+    if _WGRAD_PENDING is not None:                # nested: the outer block flushes
+        yield
+        return
+    _WGRAD_PENDING = []
+    try:
+        yield
+        flush_wgrad_reduce()
+    finally:
+        _WGRAD_PENDING = None
+
+
+def _wgrad_bf16(g, x, cout, cin, groups, M, views=1, pro_tab=None, pro_act=ACT_NONE, pro_slope=0.0, tile=-1, may_defer=True):
     """dW = g f(x)^T for bf16 (rows, M) operands -> (cout, cin/groups) f32; pro_tab (cin, views, 2): f = the BatchNorm
     + activation of the layer that produced x, applied on the fly (see conv1x1_gemm).  tile: -1 = the library's rule,
     otherwise that tile configuration (grafp_conv1x1_wgrad_tile_bf16; tests)."""
@@ -884,6 +922,16 @@ def _wgrad_bf16(g, x, cout, cin, groups, M, views=1, pro_tab=None, pro_act=ACT_N
     nbytes = lib.grafp_conv1x1_wgrad_tile_workspace(cout, cin, groups, M, views, int(tile))
     ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
     tab = None if pro_tab is None else _f32c(pro_tab)
+    # may_defer = False: the gradient is READ inside this backward pass (the weight is not a leaf: Downsample's tap matrix
+    # is a slice / permutation of its Conv2d parameter, and autograd scatters the gradient back through those views)
+    if _WGRAD_PENDING is not None and may_defer:
+        S = ctypes.c_int(0)
+        with _timed("conv1x1_wgrad", (cout, cin, groups, M)):
+            check(lib.grafp_conv1x1_wgrad_partials_bf16(_p(g), _p(x), cout, cin, groups, M, views, _p(tab), int(pro_act),
+                                                        float(pro_slope), int(tile), _p(ws), nbytes, ctypes.byref(S),
+                                                        _stream()), "conv1x1_wgrad_partials")
+        _WGRAD_PENDING.append((ws, int(S.value), dw, tab))       # (the workspace stays alive until its reduction ran)
+        return dw
     with _timed("conv1x1_wgrad", (cout, cin, groups, M)):
         check(lib.grafp_conv1x1_wgrad_tile_bf16(_p(g), _p(x), cout, cin, groups, M, views, _p(tab), int(pro_act),
                                                 float(pro_slope), int(tile), _p(dw), _p(ws), nbytes, _stream()),
@@ -911,6 +959,7 @@ class _ConvBnAct(torch.autograd.Function):
         if defer is not None and defer_role == 2 and defer.tab is not None:
             pro = (defer.tab, int(defer.act), float(defer.slope))
         ctx.pro = pro
+        ctx.w_leaf = bool(w.is_leaf)                         # its gradient goes straight to AccumulateGrad (never read here)
         ctx.token, ctx.token_role = token, token_role        # 1: first layer of the block (consumes), 2: last (provides)
         ctx.w_t, ctx.w_aug = w_t, w_aug                      # prepared with the forward operand (lowp_weights), or None
         # shared prepared buffers in use: remember which preparation this forward pass saw
@@ -981,9 +1030,9 @@ class _ConvBnAct(torch.autograd.Function):
         dw = None
         if ctx.needs_input_grad[1]:
             if ctx.pro is not None:                        # x is the producer's raw output: the same transform on load
-                dw = _wgrad_bf16(dy, x, R, K, cg, M, views, ctx.pro[0], ctx.pro[1], ctx.pro[2]).reshape(wfull)
+                dw = _wgrad_bf16(dy, x, R, K, cg, M, views, ctx.pro[0], ctx.pro[1], ctx.pro[2], may_defer=ctx.w_leaf).reshape(wfull)
             else:
-                dw = _wgrad_bf16(dy, x, R, K, cg, M).reshape(wfull)
+                dw = _wgrad_bf16(dy, x, R, K, cg, M, may_defer=ctx.w_leaf).reshape(wfull)
         dres = dz if has_res else None
         if has_res and tok is not None and ctx.token_role == 2 and tok.grad is None:
             tok.grad, dres = dz, None                      # the first layer's backward adds it (see above)

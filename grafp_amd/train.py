@@ -72,7 +72,9 @@ class Trainer:
             loss = gdist.ntxent_global(z_i, z_j, self.cfg["tau"], self.group)
         else:
             loss = ntxent_loss(z_i, z_j, self.cfg)
-        loss.backward()
+        from . import ops
+        with ops.defer_wgrad_reduce():            # the 64 weight gradients' partial sums: reduced together, not one by one
+            loss.backward()
         self.sync.finish()
         self.opt.step()
         return loss.detach()
@@ -185,7 +187,7 @@ class Trainer:
                     zj_all = both[1].reshape(-1, mine.shape[2]).contiguous()
                     loss = ops.ntxent(z_i, z_j, self.cfg["tau"], zi_all, zj_all, rank * z_i.shape[0])
                     self.sync.begin_capture(cut if self._overlap_graph_allreduce else None)
-                    with torch.autograd.set_multithreading_enabled(False):
+                    with torch.autograd.set_multithreading_enabled(False), ops.defer_wgrad_reduce():
                         loss.backward()
                     ready = self.sync.end_capture()       # per graph: the buckets complete once it has run
                     loss = loss.detach()

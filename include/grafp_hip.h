@@ -340,6 +340,17 @@ size_t grafp_conv1x1_wgrad_tile_workspace(int Cout, int Cin, int groups, int64_t
 int grafp_conv1x1_wgrad_tile_bf16(const void *grad_out, const void *x, int Cout, int Cin, int groups, int64_t M,
                                   int views, const float *pro_tab, int pro_act, float pro_slope, int tile,
                                   float *dweight, void *ws, size_t ws_bytes, grafp_stream_t stream);
+/* The two halves of the above as separate calls, for a training step's 64 weight gradients: _partials_ runs only the
+ * split-K kernel (n_slices receives the number of partial sums per output element, laid out (n_slices, Cout, Cin/groups)
+ * in ws); grafp_wgrad_reduce_multi later reduces the partial sums of many layers in ONE launch (host arrays of n_entries
+ * workspace pointers / slice counts / output sizes Cout*Cin/groups / output pointers; the table travels in the kernel
+ * arguments, so the launch is graph-capturable).  Same summation tree: the gradients are bit-identical to _tile_bf16's.
+ * (/root/reference/encoder/gcn_lib/torch_nn.py:56-60 under loss.backward(), train.py:78) */
+int grafp_conv1x1_wgrad_partials_bf16(const void *grad_out, const void *x, int Cout, int Cin, int groups, int64_t M,
+                                      int views, const float *pro_tab, int pro_act, float pro_slope, int tile, void *ws,
+                                      size_t ws_bytes, int *n_slices, grafp_stream_t stream);
+int grafp_wgrad_reduce_multi(const void *const *parts, const int *n_slices, const int64_t *n_out, float *const *outs,
+                             int n_entries, grafp_stream_t stream);
 /* f32 operands (the f32 "parity" mode of the step): the same split-K streaming reduction with each value split into
  * hi = bf16(v), lo = bf16(v - hi) on the way into LDS and three bf16 MFMAs per tile step (Gh Xh + Gh Xl + Gl Xh; the
  * dropped Gl Xl term and the 16-bit representation are ~2^-16 relative, f32 accumulation).  Same layouts as above

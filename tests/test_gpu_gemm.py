@@ -343,3 +343,33 @@ def test_gemm_affine_epilogue_equals_gemm_plus_affine(R, K, groups, M, views, ac
     want = ops.bn_affine(ops.conv1x1_gemm(w, x, groups, views), tab, views, act=act, slope=0.2)
     got = ops.conv1x1_gemm_affine(w, x, tab, groups, views, act=act, slope=0.2)
     assert torch.equal(got, want)
+
+
+def test_deferred_weight_gradient_reductions_are_bit_identical():
+    """ops.defer_wgrad_reduce(): inside the block the weight gradients run only their split-K kernels, and the partial sums
+    of ALL layers are reduced by one launch at its end (grafp_wgrad_reduce_multi; > 64 layers: two launches) -- the same
+    summation tree as the per-layer reduction, so the same bits; a flush in the middle (what GradSync does when a bucket is
+    complete) reduces what is queued so far; nested blocks reduce once, at the outer end."""
+    from grafp_amd import ops
+    shapes = [(64, 64, 1, 8192), (128, 128, 4, 4096), (256, 64, 1, 16384), (1024, 256, 1, 2048), (512, 512, 4, 1024),
+              (64, 256, 1, 8192), (96, 32, 1, 1280)]
+    ops_in = [(_rand((co, M), 20 + i), _rand((ci, M), 40 + i), co, ci, g, M) for i, (co, ci, g, M) in enumerate(shapes)]
+    want = [ops.conv1x1_wgrad(G, X, co, ci, g, M).clone() for G, X, co, ci, g, M in ops_in]
+    with ops.defer_wgrad_reduce():
+        got = []
+        for rep in range(10):                                   # 70 queued layers: more than one table
+            for G, X, co, ci, g, M in ops_in:
+                got.append(ops.conv1x1_wgrad(G, X, co, ci, g, M))
+        with ops.defer_wgrad_reduce():                          # nested: still queued
+            inner = ops.conv1x1_wgrad(*ops_in[0])
+        assert len(ops._WGRAD_PENDING) == 71
+    assert ops._WGRAD_PENDING is None
+    for i, dw in enumerate(got):
+        assert torch.equal(dw, want[i % len(shapes)]), i
+    assert torch.equal(inner, want[0])
+    with ops.defer_wgrad_reduce():
+        a = ops.conv1x1_wgrad(*ops_in[1])
+        ops.flush_wgrad_reduce()                                # a reader in the middle of backward
+        assert torch.equal(a, want[1]) and ops._WGRAD_PENDING == []
+        b = ops.conv1x1_wgrad(*ops_in[2])
+    assert torch.equal(b, want[2])
