@@ -71,6 +71,8 @@ SIGNATURES = {
     "grafp_conv1x1_gemm_bf16": (_I, [_P, _P, _I, _I, _I, _L, _I, _P, _I, _F, _P, _P, _P]),
     "grafp_conv1x1_gemm_affine_bf16": (_I, [_P, _P, _I, _I, _I, _L, _I, _P, _I, _F, _P, _P]),
     "grafp_conv1x1_gemm_cat_bf16": (_I, [_P, _P, _I, _P, _I, _I, _L, _P, _P]),
+    "grafp_split_bf16_planes": (_I, [_P, _L, _P, _P, _P]),
+    "grafp_conv1x1_gemm_split_f32": (_I, [_P, _P, _I, _I, _L, _P, _P]),
     "grafp_weights_prepare": (_I, [_P, _P, _I, _P]),
     "grafp_bn_finalize": (_I, [_P, _I, _I, _I, _L, _I, _P, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _P]),
     "grafp_bn_affine_bf16": (_I, [_P, _I, _L, _I, _P, _P, _I, _F, _P, _P]),

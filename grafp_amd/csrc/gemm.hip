@@ -168,7 +168,10 @@ __device__ __forceinline__ void gm_chan(float &n, float &mean, float &m2, float 
 // EPI: inference (eval-mode BatchNorm: scale and shift known before the product): z = act(bf16(W x) * scale + shift) is
 // formed in the epilogue -- the same arithmetic on the same rounded value as bn_affine_bf16_kernel, so the result is
 // bit-identical to GEMM + normalise pass, without writing and re-reading y (fingerprint generation: generate.py:34-57).
-template <typename CFG, int NS, bool PRO, bool STATS, bool CAT = false, bool EPI = false>
+// OUTF32 (round 4): the accumulators leave as f32 (Y points to R x M floats): the product of the f32 "parity" mode, whose
+// operands arrive as bf16 hi / lo planes and whose weight is [Wh | Wh | Wl] against the operand rows [Xh; Xl; Xh] (CAT) --
+// three exact bf16 products per term, summed in the f32 accumulators: ~2^-16 relative, 2-3 x the library's f32 GEMM rate.
+template <typename CFG, int NS, bool PRO, bool STATS, bool CAT = false, bool EPI = false, bool OUTF32 = false>
 __global__ __launch_bounds__(CFG::THREADS, CFG::NW == 4 ? 2 : 1) void conv1x1_gemm_kernel(
     const unsigned short *__restrict__ A, int lda, const unsigned short *__restrict__ X, unsigned short *__restrict__ Y,
     int64_t M, int Rg, int K, int row_tiles, int ranges_view, int tiles_range, int col_tiles_view, int views,
@@ -400,7 +403,22 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::NW == 4 ? 2 : 1) void conv1x1_ge
             const int64_t mcol = col0 + (int64_t)tile * TN + wm * 64;
 #pragma unroll
             for (int ri = 0; ri < RT; ++ri) {
-                if (rt_valid[ri]) {
+                if (OUTF32) {
+                    if (rt_valid[ri]) {
+                        // lane (l31, half) holds row l31 of the 32, columns mi*32 + 8 rg + 4 half + (0..3): 16-byte pieces
+                        float *y32 = reinterpret_cast<float *>(Y) + (size_t)(r0 + wr * 32 * RT + ri * 32 + l31) * M + mcol;
+#pragma unroll
+                        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                            for (int rg = 0; rg < 4; ++rg) {
+                                const f32x4 v = {acc[mi][ri][4 * rg + 0], acc[mi][ri][4 * rg + 1], acc[mi][ri][4 * rg + 2],
+                                                 acc[mi][ri][4 * rg + 3]};
+                                __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(y32 + mi * 32 + 8 * rg + 4 * half));
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) acc[mi][ri][4 * rg + e] = 0.0f;
+                            }
+                    }
+                } else if (rt_valid[ri]) {
                     if (STATS && tile == 0) {
                         // shift = the row's first rounded output of this wave (lane l31 of the lower half holds it)
                         const unsigned pk = gm_pack_bf16(acc[0][ri][0], 0.f);
@@ -479,7 +497,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::NW == 4 ? 2 : 1) void conv1x1_ge
                     }
                 }
             }
-            stored_now = stores_per_epi;
+            stored_now = OUTF32 ? 2 * stores_per_epi : stores_per_epi;      // (8 stores per 32-row tile instead of 4)
             ++tile;
         }
         // shift the issue history by one iteration
@@ -755,6 +773,7 @@ extern "C" int grafp_conv1x1_gemm_plan(int R, int K, int groups, int64_t M, int 
 
 namespace grafp {
 struct GemmArgs {
+    bool out_f32 = false;                        // y: R x M floats (split-bf16 product of the f32 mode; concatenated operands)
     const unsigned short *w, *x, *x2;
     unsigned short *y;
     int lda, K1;
@@ -768,12 +787,12 @@ struct GemmArgs {
     int epi_act = 0;
     float epi_slope = 0.0f;
 };
-template <typename CFG, int NS, bool PRO, bool STATS, bool CAT, bool EPI = false>
+template <typename CFG, int NS, bool PRO, bool STATS, bool CAT, bool EPI = false, bool OUTF32 = false>
 static void gemm_launch(const GemmPlan &p, const GemmArgs &a, hipStream_t s) {
     const size_t lds = (size_t)NS * CFG::STAGE + CFG::NW * CFG::OUT_BYTES + (PRO ? (size_t)a.Kg * 8 : 0);
-    (void)hipFuncSetAttribute((const void *)conv1x1_gemm_kernel<CFG, NS, PRO, STATS, CAT, EPI>,
+    (void)hipFuncSetAttribute((const void *)conv1x1_gemm_kernel<CFG, NS, PRO, STATS, CAT, EPI, OUTF32>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((conv1x1_gemm_kernel<CFG, NS, PRO, STATS, CAT, EPI>), dim3(p.nblocks, 1, a.groups),
+    hipLaunchKernelGGL((conv1x1_gemm_kernel<CFG, NS, PRO, STATS, CAT, EPI, OUTF32>), dim3(p.nblocks, 1, a.groups),
                        dim3(CFG::THREADS), lds, s, a.w, a.lda, a.x, a.y, a.M, a.Rg, a.Kg, p.row_tiles, p.ranges_view,
                        p.tiles_range, p.col_tiles_view, a.views, a.pro_tab, a.pro_act, a.pro_slope, a.part, p.P, p.nblocks,
                        a.x2, a.K1, a.epi_tab, a.epi_act, a.epi_slope);
@@ -788,7 +807,8 @@ static void gemm_launch_xl(const GemmPlan &p, const GemmArgs &a, hipStream_t s) 
 }
 // plain / statistics / concatenated-operand forms of one tile configuration
 template <typename CFG, int NS> static void gemm_launch_cfg(const GemmPlan &p, const GemmArgs &a, hipStream_t s) {
-    if (a.epi_tab) gemm_launch<CFG, NS, false, false, false, true>(p, a, s);
+    if (a.out_f32) gemm_launch<CFG, NS, false, false, true, false, true>(p, a, s);
+    else if (a.epi_tab) gemm_launch<CFG, NS, false, false, false, true>(p, a, s);
     else if (a.x2) gemm_launch<CFG, NS, false, false, true>(p, a, s);
     else if (a.part) gemm_launch<CFG, NS, false, true, false>(p, a, s);
     else gemm_launch<CFG, NS, false, false, false>(p, a, s);
@@ -828,7 +848,7 @@ static void gemm_dispatch(const GemmPlan &p, const GemmArgs &a, hipStream_t s) {
         default: break;
         }
 #endif
-        if (a.epi_tab) gemm_launch_cfg<GemmL, 4>(p, a, s);          // eval-mode affine epilogue: the eight-wave tile (same grid)
+        if (a.epi_tab || a.out_f32) gemm_launch_cfg<GemmL, 4>(p, a, s);   // affine epilogue, f32 output: the eight-wave tile (same grid)
         else if (a.x2) gemm_launch_xl<false, true, false>(p, a, s);
         else if (a.part) gemm_launch_xl<true, false, false>(p, a, s);
         else gemm_launch_xl<false, false, false>(p, a, s);
@@ -900,6 +920,57 @@ extern "C" int grafp_conv1x1_gemm_cat_bf16(const void *w, const void *x1, int K1
     a.pro_tab = nullptr; a.pro_act = 0; a.pro_slope = 0.0f; a.part = nullptr;
     gemm_dispatch(p, a, (hipStream_t)stream);
     GRAFP_CHECK_LAUNCH("conv1x1_gemm_kernel (cat)");
+    return GRAFP_OK;
+}
+
+// ---- the f32 mode's products on the bf16 matrix cores (round 4) ----
+namespace grafp {
+// v -> hi = bf16(v), lo = bf16(v - hi): |v - hi - lo| <= 2^-17 |v|; 8 elements per thread, rows stay rows
+__global__ __launch_bounds__(256) void split_planes_kernel(const float *__restrict__ x, int64_t n,
+                                                           unsigned short *__restrict__ hi, unsigned short *__restrict__ lo) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i >= n) return;
+    const float4 a = *reinterpret_cast<const float4 *>(x + i), b = *reinterpret_cast<const float4 *>(x + i + 4);
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        h[e] = gm_pack_bf16(v[2 * e], v[2 * e + 1]);
+        const float r0 = v[2 * e] - __uint_as_float(h[e] << 16), r1 = v[2 * e + 1] - __uint_as_float(h[e] & 0xffff0000u);
+        l[e] = gm_pack_bf16(r0, r1);
+    }
+    *reinterpret_cast<uint4 *>(hi + i) = make_uint4(h[0], h[1], h[2], h[3]);
+    *reinterpret_cast<uint4 *>(lo + i) = make_uint4(l[0], l[1], l[2], l[3]);
+}
+}  // namespace grafp
+
+extern "C" int grafp_split_bf16_planes(const float *x, int64_t n, void *hi, void *lo, grafp_stream_t stream) {
+    using namespace grafp;
+    GRAFP_REQUIRE(x && hi && lo && n > 0 && n % 8 == 0, "split_bf16_planes: null pointer or n %% 8 != 0");
+    GRAFP_REQUIRE((((uintptr_t)x | (uintptr_t)hi | (uintptr_t)lo) & 15) == 0, "split_bf16_planes: 16-byte alignment");
+    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, n,
+                       (unsigned short *)hi, (unsigned short *)lo);
+    GRAFP_CHECK_LAUNCH("split_planes_kernel");
+    return GRAFP_OK;
+}
+
+extern "C" int grafp_conv1x1_gemm_split_f32(const void *w3, const void *x_planes, int R, int K, int64_t M, float *y,
+                                            grafp_stream_t stream) {
+    using namespace grafp;
+    GRAFP_REQUIRE(w3 && x_planes && y, "conv1x1_gemm_split: null pointer");
+    GRAFP_REQUIRE(K > 0 && K % GM_KC == 0 && gemm_shape_ok(R, 3 * K, 1, M, 1),
+                  "conv1x1_gemm_split: unsupported shape R=%d K=%d M=%lld", R, K, (long long)M);
+    GRAFP_REQUIRE((((uintptr_t)w3 | (uintptr_t)x_planes | (uintptr_t)y) & 15) == 0, "conv1x1_gemm_split: 16-byte alignment");
+    GemmPlan p = gemm_plan(R, 3 * K, 1, M, 1);
+    GemmArgs a;
+    a.out_f32 = true;
+    a.w = (const unsigned short *)w3;
+    a.x = (const unsigned short *)x_planes;                              // rows [Xh; Xl]
+    a.x2 = (const unsigned short *)x_planes;                             // ... then Xh again
+    a.y = (unsigned short *)y; a.lda = 3 * K; a.K1 = 2 * K; a.M = M; a.Rg = R; a.Kg = 3 * K; a.groups = 1; a.views = 1;
+    a.pro_tab = nullptr; a.pro_act = 0; a.pro_slope = 0.0f; a.part = nullptr;
+    gemm_dispatch(p, a, (hipStream_t)stream);
+    GRAFP_CHECK_LAUNCH("conv1x1_gemm_kernel (split f32)");
     return GRAFP_OK;
 }
 

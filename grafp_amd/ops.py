@@ -51,6 +51,8 @@ class _Switches:
     fused_eval_affine = True      # False: eval-mode conv+BN+act as GEMM + normalise pass (same bits) instead of one kernel
     defer_norm = True             # False: every BatchNorm + activation by its own pass (no normalise-on-load at stages 0-1)
     mrconv_arg = True             # False: max-relative backward recomputes the arg-max from x instead of reading the record
+    f32_split_gemm = False        # True: the f32 mode's matrix-bound products (>= 256 operand rows) as split-bf16 MFMAs --
+    #                               2^-16 instead of 2^-24 per product: faster, but NOT inside the f32 mode's 1e-4 parity bars
 
 
 switches = _Switches()
@@ -559,6 +561,40 @@ def _block_diag_weight(w, groups, dtype=None):
     return out.reshape(cout, groups * cin_g)
 
 
+def split_planes(x):
+    """f32 (..., M) -> (hi, lo) bf16 planes with x ~= hi + lo to 2^-17 (grafp_split_bf16_planes); rows stay rows."""
+    _require_gpu(x)
+    x = _f32c(x)
+    hi = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    lo = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    check(lib.grafp_split_bf16_planes(_p(x), x.numel(), _p(hi), _p(lo), _stream()), "split_bf16_planes")
+    return hi, lo
+
+
+def split_gemm_supported(R, K, M):
+    # (measured: at stages 0-1 the products are HBM-bound and the split's extra passes cost what its matrix rate saves)
+    return bool(switches.f32_split_gemm) and R % 32 == 0 and K % 32 == 0 and M % 128 == 0 and max(R, K) >= 256
+
+
+def split_gemm_f32(w, x):
+    """y = w x for f32 w (R, K) and f32 x (K, M) on the bf16 matrix cores: operands split into bf16 hi / lo planes, y =
+    Wh Xh + Wh Xl + Wl Xh with every partial product exact and f32 accumulation (~2^-16 relative; the f32 mode's forward
+    and data-gradient products -- grafp_conv1x1_gemm_split_f32)."""
+    R, K = w.shape
+    M = x.shape[1]
+    planes = torch.empty((2 * K, M), dtype=torch.bfloat16, device=x.device)
+    x = _f32c(x)
+    check(lib.grafp_split_bf16_planes(_p(x), x.numel(), _p(planes[:K]), _p(planes[K:]), _stream()), "split_bf16_planes")
+    w = _f32c(w)
+    wh = w.to(torch.bfloat16)
+    wl = (w - wh.float()).to(torch.bfloat16)
+    w3 = torch.cat((wh, wh, wl), dim=1).contiguous()
+    y = torch.empty((R, M), dtype=torch.float32, device=x.device)
+    with _timed("conv1x1_gemm_split", (R, K, M)):
+        check(lib.grafp_conv1x1_gemm_split_f32(_p(w3), _p(planes), R, K, M, _p(y), _stream()), "conv1x1_gemm_split")
+    return y
+
+
 class _Conv1x1(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, groups, w_lowp=None):
@@ -584,7 +620,10 @@ class _Conv1x1(torch.autograd.Function):
             dense = w_lowp.detach().reshape(w2.shape)
         else:
             dense = w2.to(x.dtype)
-        y = torch.mm(dense, x)
+        ctx.split = bool(x.is_cuda and x.dtype == torch.float32 and x.numel() % 8 == 0
+                         and split_gemm_supported(dense.shape[0], dense.shape[1], x.shape[1])
+                         and split_gemm_supported(dense.shape[1], dense.shape[0], x.shape[1]))
+        y = split_gemm_f32(dense, x) if ctx.split else torch.mm(dense, x)
         ctx.save_for_backward(x, dense)
         ctx.groups, ctx.wshape, ctx.wfull = groups, tuple(w2.shape), tuple(w.shape)
         return y
@@ -599,6 +638,8 @@ class _Conv1x1(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if ctx.batched:
                 dx = torch.bmm(dense.transpose(1, 2), g.reshape(groups, cout // groups, -1)).reshape(x.shape)
+            elif getattr(ctx, "split", False):
+                dx = split_gemm_f32(dense.t().contiguous(), g)
             else:
                 dx = torch.mm(dense.t(), g)
         dw = None

@@ -277,6 +277,15 @@ int grafp_conv1x1_gemm_affine_bf16(const void *w, const void *x, int R, int K, i
  * enters the product against an identity block and the sum is rounded once. */
 int grafp_conv1x1_gemm_cat_bf16(const void *w, const void *x1, int K1, const void *x2, int K2, int R, int64_t M, void *y,
                                 grafp_stream_t stream);
+/* The f32 ("parity") mode's products on the bf16 matrix cores instead of the library's f32 GEMM
+ * (/root/reference/encoder/gcn_lib/torch_nn.py:56-60, encoder/graph_encoder.py:52-55 at the reference's f32 precision,
+ * train.py:174-177): grafp_split_bf16_planes writes hi = bf16(v) and lo = bf16(v - hi) of n f32 values (n % 8 == 0);
+ * grafp_conv1x1_gemm_split_f32 takes w3 (R, 3K) bf16 = [Wh | Wh | Wl] and x_planes (2K, M) bf16 = [Xh; Xl] and writes
+ * y (R, M) f32 = Wh Xh + Wh Xl + Wl Xh, every partial product exact, summed in f32 accumulators (the dropped Wl Xl term
+ * and the 16-bit representation: ~2^-16 relative).  K % 32 == 0, R % 32 == 0, M % 128 == 0. */
+int grafp_split_bf16_planes(const float *x, int64_t n, void *hi, void *lo, grafp_stream_t stream);
+int grafp_conv1x1_gemm_split_f32(const void *w3, const void *x_planes, int R, int K, int64_t M, float *y,
+                                 grafp_stream_t stream);
 
 /* All 1x1-convolution weights of one training step in ONE launch: per layer the bf16 copy (forward GEMM operand) and
  * the per-group transposed bf16 copy (data-gradient operand; with ld_t > R/g the columns beyond R/g -- an identity

@@ -373,3 +373,25 @@ def test_deferred_weight_gradient_reductions_are_bit_identical():
         assert torch.equal(a, want[1]) and ops._WGRAD_PENDING == []
         b = ops.conv1x1_wgrad(*ops_in[2])
     assert torch.equal(b, want[2])
+
+
+@pytest.mark.parametrize("R,K,M", [(64, 64, 8192), (256, 64, 16384), (64, 256, 131072), (1024, 256, 4096), (512, 2048, 1024),
+                                   (128, 96, 128 * 37), (2048, 512, 2560)])
+def test_split_bf16_product_of_the_f32_mode(R, K, M):
+    """ops.split_gemm_f32 (the f32 mode's forward / data-gradient products on the bf16 matrix cores): operands split into
+    hi + lo bf16 planes (exact to 2^-17), y = Wh Xh + Wh Xl + Wl Xh in f32 accumulators.  Against a float64 product of the
+    f32 operands: <= 3e-5 of the result's scale (the library's f32 GEMM: ~1e-6; bf16 operands alone: 4e-3) on every tile
+    configuration the plan picks for these shapes."""
+    from grafp_amd import ops
+    assert not ops.switches.f32_split_gemm            # opt-in: 2^-16 per product is outside the f32 mode's 1e-4 bars
+    g = torch.Generator().manual_seed(R + K)
+    w = (0.2 * torch.randn(R, K, generator=g)).to(DEV)
+    x = (torch.randn(K, M, generator=g) + 0.3).to(DEV)
+    hi, lo = ops.split_planes(x)
+    assert float((x - hi.float() - lo.float()).abs().max()) <= 2.0 ** -16 * float(x.abs().max())
+    y = ops.split_gemm_f32(w, x)
+    ref = (w.double() @ x.double())
+    scale = float(ref.abs().max())
+    assert float((y.double() - ref).abs().max()) <= 3e-5 * scale, float((y.double() - ref).abs().max()) / scale
+    assert float((torch.mm(w.to(torch.bfloat16).float(), x.to(torch.bfloat16).float()).double() - ref).abs().max()) > 1e-3 * scale
+    assert torch.equal(y, ops.split_gemm_f32(w, x))
