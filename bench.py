@@ -426,6 +426,7 @@ def main():
         weak = {"value": round(256 * world / dt, 2), "unit": "clips/s", "ms_per_step": round(dt * 1e3, 3),
                 "global_batch": 256 * world, "scaling": "weak", "note": "256 pairs per GPU, global negatives"}
         tw.sync.close()
+        trainer.sync.open()                                    # the headline trainer listens again (graph leg below)
         del tw, xw_i, xw_j
 
     sharded = None
@@ -503,8 +504,12 @@ def main():
             dt = max_over_ranks(dt)
             hip_graph = {"value": round(B * world * args.steps / dt, 2), "unit": "clips/s",
                          "ms_per_step": round(1e3 * dt / args.steps, 3), "steps": args.steps,
-                         "note": "three HIP graphs per step with the all-gather of (z_i, z_j) and the bucket "
-                                 "all-reduces eager between them (Trainer.step_graph); `value` above is the eager step"}
+                         "backward_graphs": len(trainer._graph[1][1]), "gradient_buckets": len(trainer.sync.bounds),
+                         "bucket_bytes": [int((hi - lo) * 4) for lo, hi in trainer.sync.bounds],
+                         "note": "forward graph | all-gather of (z_i, z_j) | one backward graph per gradient bucket, bucket "
+                                 "b's all-reduce launched right behind graph b (it runs under the graphs that follow; the "
+                                 "last bucket is the small tail bucket) | Adam graph (Trainer.step_graph); `value` above "
+                                 "is the eager step"}
         except Exception as exc:          # noqa: BLE001 -- report, do not fail the bench line
             hip_graph = {"error": f"{type(exc).__name__}: {exc}"[:200]}
 
@@ -574,9 +579,10 @@ def main():
                 line["eager"] = {"value": line["value"], "unit": "clips/s", "ms_per_step": line["ms_per_step"],
                                  "steps": args.steps}
                 line["value"], line["ms_per_step"] = hip_graph["value"], hip_graph["ms_per_step"]
-                line["step_impl"] = ("HIP graphs (Trainer.step_graph: forward | loss + backward + bucket packing | Adam, "
-                                     "the all-gather and the bucket all-reduces eager between them); the eager step of "
-                                     "the same run is under `eager`, the per-kernel figures come from the eager pass")
+                line["step_impl"] = ("HIP graphs (Trainer.step_graph: forward | one loss + backward graph per gradient bucket | "
+                                     "Adam, the all-gather and the bucket all-reduces eager between them, each all-reduce "
+                                     "under the backward graphs that follow it); the eager step of the same run is under "
+                                     "`eager`, the per-kernel figures come from the eager pass")
         if collectives is not None:
             line["collectives"] = collectives
         if weak is not None:

@@ -115,9 +115,8 @@ class GradSync:
         self._cap_cut = None
         self.paused = False            # Trainer.step_graph: backward is being captured, the buckets are reduced afterwards
         self.capturing = False         # ... and each completed bucket ends one backward graph (begin_capture)
-        if overlap and (self.world > 1 or force_flat):
-            for p in self.params:
-                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        self._overlap = bool(overlap and (self.world > 1 or force_flat))
+        self.open()
 
     def _layout(self, order):
         """Cut the flat buffer into buckets for the parameters in `order` (expected arrival order of their gradients)."""
@@ -179,6 +178,12 @@ class GradSync:
             self._handles, self._left, self._fired = [], list(self._size), [False] * len(self.bounds)
             if not self._relaid and not self.capturing:
                 self._maybe_relayout()
+
+    def open(self):
+        """Re-attach the autograd hooks after close() (bench.py lends the model to a second Trainer in between)."""
+        if self.flat is not None and not self._hooks and self._overlap:
+            for p in self.params:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
     def close(self):
         """Detach the autograd hooks (a second GradSync over the same parameters -- another Trainer on the same model --

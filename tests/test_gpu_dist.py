@@ -211,6 +211,8 @@ def test_bench_two_ranks_one_gpu(tmp_path):
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0      # the global batch is split
     assert line["config"]["global_batch"] == 32 and line["roofline"]["frac"] > 0
     assert line["hip_graph"].get("value", 0) > 0, line["hip_graph"]                        # the graph-replayed data-parallel step
+    assert line["hip_graph"]["backward_graphs"] == line["hip_graph"]["gradient_buckets"] >= 4           # overlap by default
+    assert line["hip_graph"]["bucket_bytes"][-1] <= 4 << 20                                  # ... and a small tail bucket
     # the headline is the faster of the two implementations of the step, the other one stays beside it
     if line["step_impl"].startswith("HIP graphs"):
         assert line["value"] == line["hip_graph"]["value"] and line["ms_per_step"] == line["hip_graph"]["ms_per_step"]
