@@ -23,7 +23,8 @@
 // Roofline: one pass streams n*(512+4) bytes; 2*128 flops per (row, query).  HBM-bound up to ~50
 // queries per pass, f32-matrix-bound (157.3 TFLOP/s) beyond.  See DESIGN.md "search_scan_kernel".
 // The default entry (grafp_knn_search_l2_pre, second half of this file) runs the same pipeline on a bf16 copy of the
-// database with a rigorous rounding margin and rescoring in exact f32: same bits out, 2-5x faster.
+// database with a rigorous rounding margin and rescoring in exact f32: same bits out, 2-5x faster; from 768 queries
+// on its scan runs in two parts with the bound tightened in between.
 #include <math.h>
 
 #include "common.h"
@@ -497,6 +498,7 @@ constexpr int SB_NS = 3;             // ring stages: two tiles in flight behind 
 constexpr int SB_STAGE = SB_TR * 256 + SB_TR * 4;   // rows (256 B, 16-byte pieces XOR-swizzled by row) + their norms
 constexpr int SB_PER = 5;            // LDS-DMA instructions per tile and wave: 4 x 1 KB of rows + 16 norms
 constexpr float SB_SLACK = 0.008f;
+constexpr int SB_WGS_NQS2 = 2;      // workgroups per CU of the two-query-set form (three: 168 registers, 16-21 dwords spilled, same time)
 
 __device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
     unsigned int u = __float_as_uint(f);
@@ -547,7 +549,9 @@ __device__ __forceinline__ void load_queries_bf16(const float *__restrict__ q, i
 // Wave (qw, rw) multiplies row blocks rw, rw + RW, ... of the tile with its NQS sets of 32 queries: on_block(t, rb, j, acc,
 // hv) per set j, hv = the norms of the lane's 16 accumulator rows (NaN past the end of the slice); on_tile(t) runs once
 // per tile on every thread at the quiescent point behind the tile barrier.
-template <int QW, int NQS, typename F, typename G>
+// ABL (measurement builds, tools/search_abl.py): bit 0 drops the MFMAs, bit 1 the per-block callback, bit 2 the DMA issue
+// after the prologue, bit 3 the fragment reads -- what the loop costs without each of its parts.
+template <int QW, int NQS, int ABL = 0, typename F, typename G>
 __device__ __forceinline__ void stream_tiles_bf16(const unsigned short *__restrict__ dbh, const float *__restrict__ dd,
                                                   int64_t row_begin, int64_t row_end, unsigned char *ring,
                                                   const bf16x8 (&bq)[NQS][8], F &&on_block, G &&on_tile) {
@@ -590,7 +594,7 @@ __device__ __forceinline__ void stream_tiles_bf16(const unsigned short *__restri
             __syncthreads();
         }
         const int free_stage = stage == 0 ? SB_NS - 1 : stage - 1;
-        issue(t + SB_NS - 1 < ntiles ? t + SB_NS - 1 : ntiles - 1, free_stage);
+        if (!(ABL & 4)) issue(t + SB_NS - 1 < ntiles ? t + SB_NS - 1 : ntiles - 1, free_stage);
 #pragma unroll
         for (int rb = rw; rb < SB_TR / 32; rb += RW) {
             // all LDS reads of the block -- eight row fragments and the 16 norms of this lane's accumulator rows -- go
@@ -599,11 +603,15 @@ __device__ __forceinline__ void stream_tiles_bf16(const unsigned short *__restri
             const unsigned char *arow = st + (rb * 32 + l31) * 256;
             bf16x8 a[8];
 #pragma unroll
-            for (int s2 = 0; s2 < 8; ++s2)
-                a[s2] = *reinterpret_cast<const bf16x8 *>(arow + (((2 * s2 + half) ^ (l31 & 15)) << 4));
+            for (int s2 = 0; s2 < 8; ++s2) {
+                if (ABL & 8) a[s2] = bq[0][s2];
+                else a[s2] = *reinterpret_cast<const bf16x8 *>(arow + (((2 * s2 + half) ^ (l31 & 15)) << 4));
+            }
             f32x4 hv4[4];
+            if (NQS == 1) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) hv4[g] = *reinterpret_cast<const f32x4 *>(sd + rb * 32 + 8 * g + 4 * half);
+                for (int g = 0; g < 4; ++g) hv4[g] = *reinterpret_cast<const f32x4 *>(sd + rb * 32 + 8 * g + 4 * half);
+            }
             __builtin_amdgcn_sched_barrier(0);
             // NQS independent accumulator chains share every row fragment: with two query sets per wave a fragment
             // read feeds two MFMAs and neither chain waits for the other's result
@@ -613,24 +621,39 @@ __device__ __forceinline__ void stream_tiles_bf16(const unsigned short *__restri
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
 #pragma unroll
-            for (int s2 = 0; s2 < 8; ++s2)
+            for (int s2 = 0; s2 < 8; ++s2) {
 #pragma unroll
-                for (int j = 0; j < NQS; ++j)
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s2], bq[j][s2], acc[j], 0, 0, 0);
+                for (int j = 0; j < NQS; ++j) {
+                    if (ABL & 1) acc[j][s2] += __builtin_bit_cast(float, (int)a[s2][0] | ((int)a[s2][7] << 16));
+                    else acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s2], bq[j][s2], acc[j], 0, 0, 0);
+                }
+                if (NQS == 2 && s2 == 3) {
+                    // two query sets: the norms are requested half way down the chains, into the registers of the
+                    // fragments already consumed (three waves per SIMD leave 168 registers)
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        hv4[g] = *reinterpret_cast<const f32x4 *>(sd + rb * 32 + 8 * g + 4 * half);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
             float hv[16];                      // hv[r]: norm of row mfma_row(r, half) of the block (NaN past the end)
 #pragma unroll
             for (int r = 0; r < 16; ++r) hv[r] = hv4[r >> 2][r & 3];
 #pragma unroll
-            for (int j = 0; j < NQS; ++j) on_block(t, rb, j, acc[j], hv);
+            for (int j = 0; j < NQS; ++j) {
+                if (ABL & 2) { if (acc[j][0] == 12345.678f && hv[3] == acc[j][5]) on_block(t, rb, j, acc[j], hv); }
+                else on_block(t, rb, j, acc[j], hv);
+            }
         }
         stage = stage + 1 == SB_NS ? 0 : stage + 1;
     }
     gm_wait_vm<0>();      // nothing of this wave's is in flight when the caller reuses LDS or the wave ends
 }
 
-template <int QW, int NQS>
-__global__ __launch_bounds__(256, NQS == 2 ? 2 : 3) void search_bound_bf16_kernel(
+template <int QW, int NQS, int ABL = 0>
+__global__ __launch_bounds__(256, NQS == 2 ? SB_WGS_NQS2 : 3) void search_bound_bf16_kernel(
     const unsigned short *__restrict__ dbh, const float *__restrict__ dd, int64_t n_sample, const float *__restrict__ q,
     const float *__restrict__ qq, int nq, int64_t rows_per_split, int *__restrict__ gmin) {
     constexpr int RW = 4 / QW;
@@ -656,7 +679,7 @@ __global__ __launch_bounds__(256, NQS == 2 ? 2 : 3) void search_bound_bf16_kerne
     // d~ + SLACK (qq + dd) = qk - 2 (<q^,x^> - dd kplus / 2): the lane keeps the MAXIMUM of the bracket (one fma per
     // element, maxima three at a time); rows past the end carry NaN and are ignored by fmaxf
     const float nhk = -0.5f * kplus;
-    stream_tiles_bf16<QW, NQS>(dbh, dd, row_begin, row_end, ring, bq,
+    stream_tiles_bf16<QW, NQS, ABL>(dbh, dd, row_begin, row_end, ring, bq,
                                [&](int, int, int j, const f32x16 &acc, const float (&hv)[16]) {
         float e[16];
 #pragma unroll
@@ -676,29 +699,29 @@ __global__ __launch_bounds__(256, NQS == 2 ? 2 : 3) void search_bound_bf16_kerne
 }
 
 // Hits are rare (a few hundred per query over the whole database) but a returning global atomic costs microseconds,
-// so the MFMA loop only appends (query, row) to an LDS queue with an LDS atomic; the queue is drained to the
-// per-query candidate lists by all 256 threads at once -- at a tile boundary when it is half full, and at the end.
-constexpr int HB_CAP = 384;       // 3.4 KB: with the 49 KB ring three workgroups still fit the 160 KB of a CU
+// so the MFMA loop only appends (query, row) to an LDS queue; a full queue is drained to the per-query candidate lists.
+// The queues are WAVE-PRIVATE: the fill count is a wave-uniform scalar, a hit's slot is count + (hit lanes below this
+// one) from the ballot -- no LDS atomic (its returning round trip was most of the ~650 cycles a block with a hit
+// cost, and every second block holds one), no workgroup barrier around a drain, no shared state at all.
+constexpr int HB_CAP = 96;        // entries per wave: 4 x 96 x 9 B = 3.4 KB; with the 49 KB ring three workgroups fit a CU
 
 template <int QW, int NQS>
-__global__ __launch_bounds__(256, NQS == 2 ? 2 : 3) void search_scan_bf16_kernel(
-    const unsigned short *__restrict__ dbh, const float *__restrict__ dd, int64_t n, const float *__restrict__ q,
-    const float *__restrict__ qq, int nq, int64_t rows_per_split, const float *__restrict__ thr, int *__restrict__ cnt,
-    int *__restrict__ cand_i, float *__restrict__ cand_e) {
+__global__ __launch_bounds__(256, NQS == 2 ? SB_WGS_NQS2 : 3) void search_scan_bf16_kernel(
+    const unsigned short *__restrict__ dbh, const float *__restrict__ dd, int64_t row0, int64_t n,
+    const float *__restrict__ q, const float *__restrict__ qq, int nq, int64_t rows_per_split,
+    const float *__restrict__ thr, int *__restrict__ cnt, int *__restrict__ cand_i, float *__restrict__ cand_e) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned char *ring = reinterpret_cast<unsigned char *>(smem);
-    __shared__ int hb_row[HB_CAP];
-    __shared__ float hb_e[HB_CAP];
-    __shared__ unsigned char hb_q[HB_CAP];
-    __shared__ int s_hits;
+    __shared__ int hb_row[4][HB_CAP];
+    __shared__ float hb_e[4][HB_CAP];
+    __shared__ unsigned char hb_q[4][HB_CAP];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int qw = wave % QW;
     int split, qgroup;
     search_block(split, qgroup);
     const int qbase = qgroup * QW * NQS * 32;        // the workgroup's queries: qbase + [0, 32 QW NQS)
-    const int64_t row_begin = (int64_t)split * rows_per_split;
+    const int64_t row_begin = row0 + (int64_t)split * rows_per_split;      // the launch covers rows [row0, n)
     const int64_t row_end = (row_begin + rows_per_split < n) ? row_begin + rows_per_split : n;
-    if (tid == 0) s_hits = 0;
     // keep iff d~ - SLACK (qq + dd) <= bound  <=>  <q^,x^> >= A_q + H_row
     const float kminus = 1.0f - SB_SLACK;
     bf16x8 bq[NQS][8];
@@ -710,18 +733,36 @@ __global__ __launch_bounds__(256, NQS == 2 ? 2 : 3) void search_scan_bf16_kernel
         a_q[j] = qi < nq ? 0.5f * (qq[qi] * kminus - thr[qi]) : INFINITY;
     }
     const int sub = split & (SR_NSUB - 1);
-    auto append = [&](int qg, int row, float ev) {            // to sub-list `sub` of the query's candidate list
-        const int pos = atomicAdd(&cnt[qg * SR_NSUB + sub], 1);
-        if (pos < SR_SUBCAP) {                                // beyond: the select kernel sees the count and rescans
-            cand_i[(size_t)qg * SR_CAP + sub * SR_SUBCAP + pos] = row;
-            cand_e[(size_t)qg * SR_CAP + sub * SR_SUBCAP + pos] = ev;   // E = <q^,x^> - dd kminus / 2: bounds d later
+    int *my_row = hb_row[wave];
+    float *my_e = hb_e[wave];
+    unsigned char *my_q = hb_q[wave];
+    int fill = 0;                                             // wave-uniform
+    auto drain = [&]() {                                      // this wave's queue -> sub-list `sub` of the queries' lists
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (int e = lane; e < fill; e += 64) {
+            const int qg = qbase + my_q[e];
+            const int pos = atomicAdd(&cnt[qg * SR_NSUB + sub], 1);
+            if (pos < SR_SUBCAP) {                            // beyond: the select kernel sees the count and rescans
+                cand_i[(size_t)qg * SR_CAP + sub * SR_SUBCAP + pos] = my_row[e];
+                cand_e[(size_t)qg * SR_CAP + sub * SR_SUBCAP + pos] = my_e[e];   // E = <q^,x^> - dd kminus / 2
+            }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        fill = 0;
     };
-    auto drain = [&]() {                                      // all threads; callers provide the barriers around it
-        const int nh = s_hits < HB_CAP ? s_hits : HB_CAP;
-        for (int e = tid; e < nh; e += 256) append(qbase + hb_q[e], hb_row[e], hb_e[e]);
+    auto push = [&](bool hit, int row, float ev, int ql) {    // wave-level call
+        const unsigned long long mask = __ballot(hit);
+        const int add = __popcll(mask);
+        if (fill + add > HB_CAP) drain();                     // uniform
+        const int slot = fill + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                               __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+        if (hit) {
+            my_row[slot] = row;
+            my_e[slot] = ev;
+            my_q[slot] = (unsigned char)ql;
+        }
+        fill += add;
     };
-    __syncthreads();
     const float hs = 0.5f * kminus;
     // keep iff <q^,x^> - H_row >= A_q.  Common case: 16 fmas, their maximum three at a time (NaN past the end of the
     // slice drops out of fmaxf), ONE compare and one branch per block -- no per-element lane masks, whose 16 dependent
@@ -735,46 +776,27 @@ __global__ __launch_bounds__(256, NQS == 2 ? 2 : 3) void search_scan_bf16_kernel
 #pragma unroll
         for (int r = 2; r < 16; r += 2) m = fmaxf(fmaxf(m, e[r]), e[r + 1]);
         if (__ballot(m >= a_q[j]) != 0) {
-            // A block holds a hit far more often than "rare" suggests -- 32 x 32 pairs against several hundred candidates
-            // per query in a million rows: every second block -- so this path must be cheap as well.  Only the lanes
-            // with a hit work: 16 compares into a bit mask (no branches), and in the usual case of ONE hit its value is
-            // the maximum already at hand.  (16 divergent `if`s, each with its own compare, exec save, branch and
-            // LDS atomic: 1 400 cycles per block with a hit, half of the kernel.)
-            if (m >= a_q[j]) {
-                unsigned bits = 0;
+            // A block holds a hit far more often than "rare" suggests -- 32 x 32 pairs against a few hundred candidates
+            // per query in a million rows: every second to fourth block -- so this path must be cheap as well: 16
+            // compares into a bit mask (no branches); in the usual case of ONE hit among a lane's 16 rows its value is
+            // the maximum already at hand.
+            unsigned bits = 0;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) bits |= e[r] >= a_q[j] ? 1u << r : 0u;
-                const int slab0 = (int)(row_begin + (int64_t)t * SB_TR + rb * 32) + 4 * half;
-                const int ql = (qw * NQS + j) * 32 + l31;             // < 256: fits the queue's byte
-                auto push = [&](int r, float ev) {                    // row mfma_row(r, half) of the block
-                    const int row = slab0 + (r & 3) + 8 * (r >> 2);
-                    const int slot = atomicAdd(&s_hits, 1);
-                    if (slot < HB_CAP) {
-                        hb_row[slot] = row;
-                        hb_e[slot] = ev;
-                        hb_q[slot] = (unsigned char)ql;
-                    } else {
-                        append(qbase + ql, row, ev);                  // queue full (tiny database, bound = +inf)
-                    }
-                };
-                if ((bits & (bits - 1)) == 0) {
-                    push(__builtin_ctz(bits), m);
-                } else {                                              // several hits in one lane's 16 rows: rare
+            for (int r = 0; r < 16; ++r) bits |= e[r] >= a_q[j] ? 1u << r : 0u;       // (NaN compares false)
+            const int slab0 = (int)(row_begin + (int64_t)t * SB_TR + rb * 32) + 4 * half;
+            const int ql = (qw * NQS + j) * 32 + l31;                 // < 256: fits the queue's byte
+            const bool single = (bits & (bits - 1)) == 0;
+            const int r0 = bits ? __builtin_ctz(bits) : 0;            // row mfma_row(r, half) of the block
+            push(bits != 0 && single, slab0 + (r0 & 3) + 8 * (r0 >> 2), m, ql);
+            if (__ballot(!single) != 0) {                             // several hits in one lane's 16 rows: rare
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        if ((bits >> r) & 1) push(r, e[r]);
+                for (int r = 0; r < 16; ++r) {
+                    const bool h = !single && ((bits >> r) & 1);
+                    if (__ballot(h) != 0) push(h, slab0 + (r & 3) + 8 * (r >> 2), e[r], ql);
                 }
             }
         }
-    }, [&](int) {
-        if (s_hits >= HB_CAP / 2) {                                    // uniform: nobody appends at this point
-            drain();
-            __syncthreads();
-            if (tid == 0) s_hits = 0;
-            __syncthreads();
-        }
-    });
-    __syncthreads();
+    }, [](int) {});
     drain();
 }
 
@@ -818,11 +840,14 @@ __device__ __forceinline__ void block_merge_tops(WaveTop &top, float (*wtop_d)[3
     }
 }
 
+// TIGHTEN: only phase A, over the candidates the first part of a two-part scan left: thr[qi] = min(thr[qi], the k-th
+// smallest upper bound) -- the bound the second part then scans with (at least k rows of the first part are that close).
+template <bool TIGHTEN>
 __global__ __launch_bounds__(256) void search_select_exact_kernel(const float *__restrict__ db,
                                                                   const float *__restrict__ dd, int64_t n,
                                                                   const float *__restrict__ q,
                                                                   const float *__restrict__ qq, int nq, int k,
-                                                                  int64_t id_base, const float *__restrict__ thr,
+                                                                  int64_t id_base, float *__restrict__ thr,
                                                                   const int *__restrict__ cnt,
                                                                   const int *__restrict__ cand_i,
                                                                   const float *__restrict__ cand_e,
@@ -895,6 +920,10 @@ __global__ __launch_bounds__(256) void search_select_exact_kernel(const float *_
         if (wave == 0 && lane == k - 1) s_thr2 = td;      // +inf when fewer than k candidates exist
         __syncthreads();
         thr2 = fminf(thr2, s_thr2);
+    }
+    if (TIGHTEN) {
+        if (tid == 0 && listed) thr[qi] = thr2;
+        return;
     }
     __syncthreads();                                       // sq visible; the merge buffers are free again
     // phase B: exact distances of the rows that can still be among the k best
@@ -1210,8 +1239,24 @@ extern "C" int grafp_knn_search_l2_pre(const float *db, const void *db_bf16, con
     const int qgroups = (nq + 32 * qw * nqs - 1) / (32 * qw * nqs);
     int splits, b_splits;
     int64_t rps, b_rps;
-    int64_t want = (nqs == 2 ? 512 : 768) / qgroups;
-    split_rows(n, SB_TR, want < 1 ? 1 : want, &splits, &rps);
+    int64_t want = (nqs == 2 ? 256 * SB_WGS_NQS2 : 768) / qgroups;
+    if (want < 1) want = 1;
+    // Large batches scan in two parts.  The pre-pass bound (k-th smallest of 64 group minima over n/16 rows) lets a few
+    // hundred rows per query through; the first n/4 rows are scanned with it, the k-th smallest UPPER bound among their
+    // candidates (at least k rows are truly that close -- the select kernel's own phase A, run early: 35 us at 4096
+    // queries) replaces it, and the other three quarters are scanned with the tighter one: their blocks hold a hit a
+    // third as often and the select kernel sorts ~40 % fewer candidates.  Measured (1M x 128, k = 20, same process,
+    // 30 repetitions): 4096 queries 1.46 -> 1.39 ms, 2048 0.765 -> 0.732, 1024 0.428 -> 0.412; a first part of n/3,
+    // n/6, n/8 gives 1.40, 1.40, 1.42 ms.  Below ~700 queries the two extra launches cost what the bound saves (256
+    // queries: 0.171 -> 0.183 ms): one part.
+    const int first_div = GRAFP_TUNE_INT("GRAFP_SEARCH_FIRST_DIV", 4);
+    int64_t n_first = 0;
+    if (nq >= GRAFP_TUNE_INT("GRAFP_SEARCH_TWO_PART_NQ", 768) && first_div > 1 && n / first_div >= 65536)
+        n_first = (n / first_div) / SB_TR * SB_TR;
+    int a_splits = 1;
+    int64_t a_rps = SB_TR;
+    if (n_first > 0) split_rows(n_first, SB_TR, want, &a_splits, &a_rps);
+    split_rows(n - n_first, SB_TR, want, &splits, &rps);
     int64_t b_rows = n / 16 > 65536 ? n / 16 : 65536;
     if (b_rows > n) b_rows = n;
     int64_t bwant = 1024 / qgroups;
@@ -1228,25 +1273,67 @@ extern "C" int grafp_knn_search_l2_pre(const float *db, const void *db_bf16, con
     const int64_t ng = (int64_t)nq * SR_GROUPS;
     hipLaunchKernelGGL(search_init_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, s, q, nq, qq, gmin, cnt);
     const size_t lds = (size_t)SB_NS * SB_STAGE;
-    const dim3 grid_b(b_splits, qgroups), grid(splits, qgroups);
+    const dim3 grid_b(b_splits, qgroups), grid_a(a_splits, qgroups), grid(splits, qgroups);
     const unsigned short *dbh = (const unsigned short *)db_bf16;
 #define SB_LAUNCH(QW, NQS)                                                                                          \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(search_bound_bf16_kernel<QW, NQS>), grid_b, dim3(256), lds, s, dbh,          \
                        db_sqnorm, b_rows, q, (const float *)qq, nq, b_rps, gmin);                                   \
     hipLaunchKernelGGL(search_thr_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, (const int *)gmin, nq, k, thr);      \
+    if (n_first > 0) {                                                                                              \
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(search_scan_bf16_kernel<QW, NQS>), grid_a, dim3(256), lds, s, dbh,       \
+                           db_sqnorm, (int64_t)0, n_first, q, (const float *)qq, nq, a_rps, (const float *)thr,     \
+                           cnt, cand_i, cand_e);                                                                    \
+        hipLaunchKernelGGL(search_select_exact_kernel<true>, dim3(nq), dim3(256), 0, s, db, db_sqnorm, n, q,        \
+                           (const float *)qq, nq, k, id_base, thr, (const int *)cnt, (const int *)cand_i,           \
+                           (const float *)cand_e, out_dist, out_ids);                                               \
+    }                                                                                                               \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(search_scan_bf16_kernel<QW, NQS>), grid, dim3(256), lds, s, dbh, db_sqnorm,  \
-                       n, q, (const float *)qq, nq, rps, (const float *)thr, cnt, cand_i, cand_e)
+                       n_first, n, q, (const float *)qq, nq, rps, (const float *)thr, cnt, cand_i, cand_e)
     if (qw == 2) { SB_LAUNCH(2, 1); }
     else if (nqs == 1) { SB_LAUNCH(4, 1); }
     else { SB_LAUNCH(4, 2); }
 #undef SB_LAUNCH
     GRAFP_CHECK_LAUNCH("search_bound_bf16_kernel / search_scan_bf16_kernel");
-    hipLaunchKernelGGL(search_select_exact_kernel, dim3(nq), dim3(256), 0, s, db, db_sqnorm, n, q, (const float *)qq, nq,
-                       k, id_base, (const float *)thr, (const int *)cnt, (const int *)cand_i, (const float *)cand_e,
-                       out_dist, out_ids);
+    hipLaunchKernelGGL(search_select_exact_kernel<false>, dim3(nq), dim3(256), 0, s, db, db_sqnorm, n, q,
+                       (const float *)qq, nq, k, id_base, thr, (const int *)cnt, (const int *)cand_i,
+                       (const float *)cand_e, out_dist, out_ids);
     GRAFP_CHECK_LAUNCH("search_select_exact_kernel");
     return GRAFP_OK;
 }
+
+#ifdef GRAFP_MEASURE
+// measurement builds only (tools/search_abl.py): the pre-pass loop over ALL n rows with parts of it removed
+extern "C" int grafp_measure_search_loop(const void *db_bf16, const float *db_sqnorm, int64_t n, const float *q,
+                                         const float *qq, int nq, int abl, int nqs, int *gmin, grafp_stream_t stream) {
+    using namespace grafp;
+    const int qgroups = (nq + 128 * nqs - 1) / (128 * nqs);
+    int splits;
+    int64_t rps;
+    int64_t want = 768 / qgroups;
+    split_rows(n, SB_TR, want < 1 ? 1 : want, &splits, &rps);
+    const size_t lds = (size_t)SB_NS * SB_STAGE;
+    const dim3 grid(splits, qgroups);
+    const unsigned short *dbh = (const unsigned short *)db_bf16;
+    hipStream_t s = (hipStream_t)stream;
+#define ABL_CASE(A)                                                                                                 \
+    case A:                                                                                                         \
+        if (nqs == 2)                                                                                               \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(search_bound_bf16_kernel<4, 2, A>), grid, dim3(256), lds, s, dbh,    \
+                               db_sqnorm, n, q, qq, nq, rps, gmin);                                                 \
+        else                                                                                                        \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(search_bound_bf16_kernel<4, 1, A>), grid, dim3(256), lds, s, dbh,    \
+                               db_sqnorm, n, q, qq, nq, rps, gmin);                                                 \
+        break
+    switch (abl) {
+        ABL_CASE(0); ABL_CASE(1); ABL_CASE(2); ABL_CASE(3); ABL_CASE(4); ABL_CASE(8); ABL_CASE(9); ABL_CASE(10);
+        ABL_CASE(11); ABL_CASE(12); ABL_CASE(14); ABL_CASE(15); ABL_CASE(6); ABL_CASE(7);
+        default: set_error("measure_search_loop: abl=%d not built", abl); return GRAFP_ERR_ARG;
+    }
+#undef ABL_CASE
+    GRAFP_CHECK_LAUNCH("search_bound_bf16_kernel (ablation)");
+    return GRAFP_OK;
+}
+#endif
 
 extern "C" int grafp_merge_topk(const float *part_dist, const int64_t *part_ids, int P, int nq, int k, float *out_dist,
                                 int64_t *out_ids, grafp_stream_t stream) {

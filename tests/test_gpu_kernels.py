@@ -519,6 +519,40 @@ def test_merge_topk_and_sharded_search(dev):
     assert np.array_equal(mi.cpu().numpy(), oi) and np.array_equal(md.cpu().numpy(), od)
 
 
+def test_search_two_part_scan_vs_c_oracle(dev):
+    """From 768 queries on (and n/4 >= 64k rows) the bf16 scan runs in two parts with the bound tightened in between
+    (knn_search.hip, grafp_knn_search_l2_pre).  300 000 rows x 800 queries: every query against the f32 path, a sample
+    against the C oracle; exact duplicates of one row planted on both sides of the part boundary (row 74 944) must come
+    back lowest id first; and a query whose first-part candidate list overflows (5 000 copies of one row inside part one)
+    must fall back to the exact rescan."""
+    from grafp_amd import ops
+    from oracle import native
+    n, nq, k = 300_000, 800, 20
+    db, q, rows = _planted(n, nq, "twopart")
+    db = db.copy()
+    dup = db[123].copy()
+    dups = (74_000, 74_943, 74_944, 74_945, 75_008, 200_000, 299_999)
+    for r in dups:
+        db[r] = dup
+    db[10_000:15_000] = db[10_000]                                    # overflow of one query's sub-lists in part one
+    q = q.copy()
+    q[5] = dup
+    q[6] = db[10_000]
+    dbt, qt = t(db).to(dev), t(q).to(dev)
+    d, i = _search(ops, dbt, qt, k)                                   # asserts pre-filter path == f32 path
+    d, i = d.cpu().numpy(), i.cpu().numpy()
+    assert list(i[5, :8]) == [123, *dups] and (d[5, :8] == d[5, 0]).all()
+    assert list(i[6]) == list(range(10_000, 10_020))
+    sample = np.r_[0:48, 5, 6, nq - 16:nq]
+    wd, wi = native.flat_search_l2(db, q[sample], k)
+    assert np.array_equal(i[sample], wi) and np.array_equal(d[sample], wd)
+    keep = ~np.isin(rows, dups) & ~((rows >= 10_000) & (rows < 15_000)) & (rows != 123)
+    keep[[5, 6]] = False
+    assert keep.sum() > 700 and np.array_equal(i[keep, 0], rows[keep])    # planted answers
+    d41, i41 = _search(ops, dbt, qt[:41], k)                          # one-part scan of the same queries: same bits
+    assert np.array_equal(i41.cpu().numpy(), i[:41]) and np.array_equal(d41.cpu().numpy(), d[:41])
+
+
 def test_search_1m_planted_top1(dev):
     """BASELINE config 4 size: 1 000 000 x 128 database resident on the GPU; planted noisy queries must
     come back top-1, and a sample of queries must match the CPU oracle exactly."""
