@@ -595,6 +595,12 @@ __device__ __forceinline__ void stream_tiles_bf16(const unsigned short *__restri
         }
         const int free_stage = stage == 0 ? SB_NS - 1 : stage - 1;
         if (!(ABL & 4)) issue(t + SB_NS - 1 < ntiles ? t + SB_NS - 1 : ntiles - 1, free_stage);
+        // (Measured and dropped, round 4: both blocks of the tile as one software pipeline in the 4x1 shape -- 16 fragment
+        // reads up front, the two MFMA chains interleaved, block 0's arithmetic behind them; 168 registers.  4096 queries
+        // 1.45 ms against 1.39, 2048 0.76 against 0.73, 512 0.243 against 0.262.  tools/search_abl.py and
+        // tools/microbench/mfma_data_bench.hip say why little moves here: with fingerprint-like operand bits the MFMA
+        // pipe itself delivers 20 ns per 32x32x16 instruction and SIMD (1.67 PFLOP/s, not the 2.5 of constant
+        // operands), the loop without its MFMAs costs as much again, and the two halves barely overlap.)
 #pragma unroll
         for (int rb = rw; rb < SB_TR / 32; rb += RW) {
             // all LDS reads of the block -- eight row fragments and the 16 norms of this lane's accumulator rows -- go
