@@ -27,6 +27,8 @@
 // on its scan runs in two parts with the bound tightened in between.
 #include <math.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "dma_ring.h"
 #include "tuning.h"
@@ -549,6 +551,20 @@ __device__ __forceinline__ void load_queries_bf16(const float *__restrict__ q, i
 // Wave (qw, rw) multiplies row blocks rw, rw + RW, ... of the tile with its NQS sets of 32 queries: on_block(t, rb, j, acc,
 // hv) per set j, hv = the norms of the lane's 16 accumulator rows (NaN past the end of the slice); on_tile(t) runs once
 // per tile on every thread at the quiescent point behind the tile barrier.
+// e[r] = hv[r] * k + acc[r] for the 16 accumulator rows of a lane, as eight v_pk_fma_f32 (two lanes of arithmetic per
+// issue slot; the scalar form is sixteen v_fmamk_f32 -- and every VALU slot of the scan loop is paid in full)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void fma16_pk(const float (&hv)[16], float k, const f32x16 &acc, float (&e)[16]) {
+    const f32x2 kk = {k, k};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const f32x2 h = {hv[2 * i], hv[2 * i + 1]}, c = {acc[2 * i], acc[2 * i + 1]};
+        const f32x2 r = __builtin_elementwise_fma(h, kk, c);
+        e[2 * i] = r[0];
+        e[2 * i + 1] = r[1];
+    }
+}
+
 // ABL (measurement builds, tools/search_abl.py): bit 0 drops the MFMAs, bit 1 the per-block callback, bit 2 the DMA issue
 // after the prologue, bit 3 the fragment reads -- what the loop costs without each of its parts.
 template <int QW, int NQS, int ABL = 0, typename F, typename G>
@@ -567,56 +583,78 @@ __device__ __forceinline__ void stream_tiles_bf16(const unsigned short *__restri
     const float *ddb = dd + row_begin;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);      // LDS-DMA bases travel in M0: scalar operands
     const int sub = lane >> 4, pos = lane & 15;
+    // Every VALU instruction of this loop is paid in full: on one SIMD the waves' MFMAs and their other vector
+    // instructions add up (tools/search_abl.py: 631 us of MFMA + 625 us of everything else = 1207 us, round 4).  So the
+    // addresses are strength-reduced: the DMA source of piece j in tile t is a per-lane pointer of tile 0 plus t * 16 KB
+    // (one 64-bit add; the clamp against the end of the slice only in its last, partial tile), and the ring stage is a
+    // compile-time constant (the tile loop is unrolled by SB_NS), so a fragment read is ds_read_b128 with one of eight
+    // per-lane registers and an immediate offset -- no address arithmetic per block at all.
+    const bool partial = (nrows & (SB_TR - 1)) != 0;
+    const unsigned char *src0[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = 4 * (wave_u * 4 + j) + sub;
+        src0[j] = rows + (size_t)r * 256 + ((pos ^ (r & 15)) << 4);
+    }
+    const float *nsrc0 = ddb + wave_u * 16 + pos;
     auto issue = [&](int t, int stage) {              // this wave's quarter of tile t (clamped by the caller)
         const unsigned st = __builtin_amdgcn_readfirstlane(lds0 + stage * SB_STAGE);
+        if (partial && t == ntiles - 1) {             // uniform; rows past the end: any readable data, their norm -> NaN
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int i = wave_u * 4 + j, r = 4 * i + sub;
-            int lr = t * SB_TR + r;
-            lr = lr < nrows ? lr : nrows - 1;          // rows past the end: any readable data, their norm becomes NaN
-            gm_dma16(rows + (size_t)lr * 256 + ((pos ^ (r & 15)) << 4), st + i * 1024);
+            for (int j = 0; j < 4; ++j) {
+                const int i = wave_u * 4 + j, r = 4 * i + sub;
+                int lr = t * SB_TR + r;
+                lr = lr < nrows ? lr : nrows - 1;
+                gm_dma16(rows + (size_t)lr * 256 + ((pos ^ (r & 15)) << 4), st + i * 1024);
+            }
+            int lr = t * SB_TR + wave_u * 16 + pos;    // norms of rows 16 w .. 16 w + 15: lanes 0-15 only
+            lr = lr < nrows ? lr : nrows - 1;
+            if (lane < 16) gm_dma4(ddb + lr, st + SB_TR * 256 + wave_u * 64);
+        } else {
+            const size_t off = (size_t)t * (SB_TR * 256);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) gm_dma16(src0[j] + off, st + (wave_u * 4 + j) * 1024);
+            if (lane < 16) gm_dma4(nsrc0 + (size_t)t * SB_TR, st + SB_TR * 256 + wave_u * 64);
         }
-        int lr = t * SB_TR + wave_u * 16 + pos;        // norms of rows 16 w .. 16 w + 15: lanes 0-15 only
-        lr = lr < nrows ? lr : nrows - 1;
-        if (lane < 16) gm_dma4(ddb + lr, st + SB_TR * 256 + wave_u * 64);
     };
 #pragma unroll
     for (int t0 = 0; t0 < SB_NS - 1; ++t0) issue(t0 < ntiles ? t0 : ntiles - 1, t0);
-    int stage = 0;
-    for (int t = 0; t < ntiles; ++t) {
+    const unsigned char *frag[8];                     // fragment s2 of block 0 in stage 0, this lane
+#pragma unroll
+    for (int s2 = 0; s2 < 8; ++s2) frag[s2] = ring + l31 * 256 + (((2 * s2 + half) ^ (l31 & 15)) << 4);
+    const float *nrm0 = reinterpret_cast<const float *>(ring + SB_TR * 256) + 4 * half;
+    auto tile = [&](auto stage_c, int t) {
+        constexpr int STAGE = decltype(stage_c)::value;
         gm_wait_vm<(SB_NS - 2) * SB_PER>();                   // this wave's part of tile t has landed
         __syncthreads();  // everybody's part has; every wave is done with tile t-1, whose stage is free again
         on_tile(t);       // quiescent point: no wave is inside on_block, so workgroup state is uniform here
-        unsigned char *st = ring + stage * SB_STAGE;
-        float *sd = reinterpret_cast<float *>(st + SB_TR * 256);
-        if (t == ntiles - 1 && (nrows & (SB_TR - 1)) != 0) {   // uniform: the slice ends inside this tile
+        if (partial && t == ntiles - 1) {                     // uniform: the slice ends inside this tile
+            float *sd = reinterpret_cast<float *>(ring + STAGE * SB_STAGE + SB_TR * 256);
             if (tid < SB_TR && t * SB_TR + tid >= nrows) sd[tid] = __builtin_nanf("");
             __syncthreads();
         }
-        const int free_stage = stage == 0 ? SB_NS - 1 : stage - 1;
-        if (!(ABL & 4)) issue(t + SB_NS - 1 < ntiles ? t + SB_NS - 1 : ntiles - 1, free_stage);
+        constexpr int FREE = STAGE == 0 ? SB_NS - 1 : STAGE - 1;
+        if (!(ABL & 4)) issue(t + SB_NS - 1 < ntiles ? t + SB_NS - 1 : ntiles - 1, FREE);
         // (Measured and dropped, round 4: both blocks of the tile as one software pipeline in the 4x1 shape -- 16 fragment
         // reads up front, the two MFMA chains interleaved, block 0's arithmetic behind them; 168 registers.  4096 queries
-        // 1.45 ms against 1.39, 2048 0.76 against 0.73, 512 0.243 against 0.262.  tools/search_abl.py and
-        // tools/microbench/mfma_data_bench.hip say why little moves here: with fingerprint-like operand bits the MFMA
-        // pipe itself delivers 20 ns per 32x32x16 instruction and SIMD (1.67 PFLOP/s, not the 2.5 of constant
-        // operands), the loop without its MFMAs costs as much again, and the two halves barely overlap.)
-#pragma unroll
-        for (int rb = rw; rb < SB_TR / 32; rb += RW) {
+        // 1.45 ms against 1.39, 2048 0.76 against 0.73, 512 0.243 against 0.262.)
+        auto block = [&](auto rb_c) {
+            constexpr int RB = decltype(rb_c)::value;
+            constexpr int OFF = STAGE * SB_STAGE + RB * 32 * 256, NOFF = STAGE * SB_STAGE + RB * 32 * 4;
             // all LDS reads of the block -- eight row fragments and the 16 norms of this lane's accumulator rows -- go
             // out as one batch ahead of the MFMA chain (left alone, the compiler recycles ONE fragment register quad:
             // read, wait, MFMA, eight times over, i.e. eight exposed LDS latencies per block)
-            const unsigned char *arow = st + (rb * 32 + l31) * 256;
             bf16x8 a[8];
 #pragma unroll
             for (int s2 = 0; s2 < 8; ++s2) {
                 if (ABL & 8) a[s2] = bq[0][s2];
-                else a[s2] = *reinterpret_cast<const bf16x8 *>(arow + (((2 * s2 + half) ^ (l31 & 15)) << 4));
+                else a[s2] = *reinterpret_cast<const bf16x8 *>(frag[s2] + OFF);
             }
             f32x4 hv4[4];
             if (NQS == 1) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) hv4[g] = *reinterpret_cast<const f32x4 *>(sd + rb * 32 + 8 * g + 4 * half);
+                for (int g = 0; g < 4; ++g)
+                    hv4[g] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const unsigned char *>(nrm0 + 8 * g) + NOFF);
             }
             __builtin_amdgcn_sched_barrier(0);
             // NQS independent accumulator chains share every row fragment: with two query sets per wave a fragment
@@ -639,7 +677,7 @@ __device__ __forceinline__ void stream_tiles_bf16(const unsigned short *__restri
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int g = 0; g < 4; ++g)
-                        hv4[g] = *reinterpret_cast<const f32x4 *>(sd + rb * 32 + 8 * g + 4 * half);
+                        hv4[g] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const unsigned char *>(nrm0 + 8 * g) + NOFF);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -649,11 +687,25 @@ __device__ __forceinline__ void stream_tiles_bf16(const unsigned short *__restri
             for (int r = 0; r < 16; ++r) hv[r] = hv4[r >> 2][r & 3];
 #pragma unroll
             for (int j = 0; j < NQS; ++j) {
-                if (ABL & 2) { if (acc[j][0] == 12345.678f && hv[3] == acc[j][5]) on_block(t, rb, j, acc[j], hv); }
-                else on_block(t, rb, j, acc[j], hv);
+                if (ABL & 2) { if (acc[j][0] == 12345.678f && hv[3] == acc[j][5]) on_block(t, RB, j, acc[j], hv); }
+                else on_block(t, RB, j, acc[j], hv);
             }
+        };
+        // (Also measured and dropped for the two-query-set form: the reads of both blocks in front of the first chain,
+        // 236-256 registers -- 4096 queries 1.201 ms against 1.203.)
+        if constexpr (RW == 1) {
+            block(std::integral_constant<int, 0>{});
+            block(std::integral_constant<int, 1>{});
+        } else {                                              // RW == 2: row-wave rw takes block rw
+            if (rw == 0) block(std::integral_constant<int, 0>{});
+            else block(std::integral_constant<int, 1>{});
         }
-        stage = stage + 1 == SB_NS ? 0 : stage + 1;
+    };
+    static_assert(SB_NS == 3 && (RW == 1 || RW == 2), "the tile loop is unrolled by hand over three ring stages");
+    for (int t = 0; t < ntiles; t += SB_NS) {
+        tile(std::integral_constant<int, 0>{}, t);
+        if (t + 1 < ntiles) tile(std::integral_constant<int, 1>{}, t + 1);
+        if (t + 2 < ntiles) tile(std::integral_constant<int, 2>{}, t + 2);
     }
     gm_wait_vm<0>();      // nothing of this wave's is in flight when the caller reuses LDS or the wave ends
 }
@@ -688,8 +740,7 @@ __global__ __launch_bounds__(256, NQS == 2 ? SB_WGS_NQS2 : 3) void search_bound_
     stream_tiles_bf16<QW, NQS, ABL>(dbh, dd, row_begin, row_end, ring, bq,
                                [&](int, int, int j, const f32x16 &acc, const float (&hv)[16]) {
         float e[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) e[r] = __builtin_fmaf(hv[r], nhk, acc[r]);
+        fma16_pk(hv, nhk, acc, e);
 #pragma unroll
         for (int r = 0; r < 16; r += 2) bestm[j] = fmaxf(fmaxf(bestm[j], e[r]), e[r + 1]);
     }, [](int) {});
@@ -776,8 +827,7 @@ __global__ __launch_bounds__(256, NQS == 2 ? SB_WGS_NQS2 : 3) void search_scan_b
     stream_tiles_bf16<QW, NQS>(dbh, dd, row_begin, row_end, ring, bq,
                                [&](int t, int rb, int j, const f32x16 &acc, const float (&hv)[16]) {
         float e[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) e[r] = __builtin_fmaf(hv[r], -hs, acc[r]);
+        fma16_pk(hv, -hs, acc, e);
         float m = fmaxf(e[0], e[1]);
 #pragma unroll
         for (int r = 2; r < 16; r += 2) m = fmaxf(fmaxf(m, e[r]), e[r + 1]);
@@ -1237,11 +1287,11 @@ extern "C" int grafp_knn_search_l2_pre(const float *db, const void *db_bf16, con
     // measured crossovers (1M x 128): the 1x4 shape only pays for a handful of queries (nq=16: 136 vs 127 us, nq=32:
     // 168 vs 143 us for the 2x2 shape)
     const int qw = nq <= 64 ? 2 : 4, rw = 4 / qw;      // (the 1x4 shape went with the 64-row ring stages)
-    // two query sets per wave (256 queries per workgroup, two workgroups per CU) once there are several query groups:
-    // every row fragment read from LDS feeds two independent MFMA chains and the database crosses L2 half as often
-    // (measured, 1M x 128, nq = 4096: 1.71 ms against 1.64 with one set -- the shipping plan is one set; the other stays
-    // reachable in the measurement build)
-    const int nqs = GRAFP_TUNE_INT("GRAFP_SEARCH_NQS", 1) == 2 && qw == 4 ? 2 : 1;
+    // two query sets per wave (256 queries per workgroup, two workgroups per CU) from 1024 queries on: every row fragment
+    // read from LDS feeds two independent MFMA chains and a tile's DMA, barrier and loop overhead is shared by twice the
+    // MFMAs (1M x 128, round 4, after the loop's address arithmetic went into immediates: 4096 queries 1.32 -> 1.20 ms,
+    // 2048 0.69 -> 0.645, 1024 0.380 -> 0.365, 512 0.231 -> 0.237; before that the two forms were level)
+    const int nqs = GRAFP_TUNE_INT("GRAFP_SEARCH_NQS", nq >= 1024 ? 2 : 1) == 2 && qw == 4 ? 2 : 1;
     const int qgroups = (nq + 32 * qw * nqs - 1) / (32 * qw * nqs);
     int splits, b_splits;
     int64_t rps, b_rps;
