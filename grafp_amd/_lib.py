@@ -64,6 +64,11 @@ SIGNATURES = {
     "grafp_bn_fwd_1pass": (_I, [_P, _I, _I, _L, _I, _P, _P, _P, _P, _I, _F, _F, _F, _I, _P, _P, _P, _P, _P, _P, _Z, _P, _I, _P]),
     "grafp_bn_bwd_1pass": (_I, [_P, _P, _I, _I, _L, _I, _P, _P, _P, _P, _P, _I, _F, _I, _P, _P, _P, _P, _P, _Z, _P, _I, _P]),
     "grafp_ivfpq_scan_f32": (_I, [_P, _I, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _L, _P, _P, _P]),
+    "grafp_pq_assign_f32": (_I, [_P, _L, _I, _I, _P, _P, _P, _I, _P, _P, _P]),
+    "grafp_kmeans_workspace": (_Z, [_L, _I, _I, _I]),
+    "grafp_kmeans_f32": (_I, [_P, _L, _I, _I, _P, _P, _P, _I, _I, _P, _P, _Z, _P]),
+    "grafp_ivfpq_probe_f32": (_I, [_P, _I, _I, _P, _I, _I, _P, _P]),
+    "grafp_ivfpq_search_f32": (_I, [_P, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P]),
     "grafp_debug_occupy": (_I, [_I, _I, _L, _P]),
     "grafp_conv1x1_gemm_supported": (_I, [_I, _I, _I, _L, _I]),
     "grafp_conv1x1_gemm_partials": (_I, [_I, _I, _I, _L, _I]),

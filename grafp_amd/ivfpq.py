@@ -4,8 +4,9 @@
 (inverted file over a k-means coarse quantiser, product quantisation of the RESIDUALS with M sub-quantisers of 2^nbits
 codewords, asymmetric distance computation at search time) and the two k-means are pinned to a seeded Lloyd iteration
 of our own, so results are reproducible but only STATISTICALLY comparable with faiss (its k-means initialisation is not
-reproducible without faiss).  Training and encoding are dense algebra on the device; the search scans the probed
-lists with the hand-written kernel of csrc/ivfpq.hip.
+reproducible without faiss).  Training (both k-means), encoding, the coarse probe and the search (scan of the
+probed lists with the top-k fused in) are hand-written kernels of csrc/ivfpq.hip; only the list bookkeeping of `add`
+(stable sort of the rows by list, list offsets) uses torch.
 
 Same surface as ops.FlatL2Index / the subset of faiss eval.py uses: d, ntotal, nprobe, train(x), add(x), search(q, k),
 plus rows() (the raw vectors, which the sequence rerank reads: the reference keeps them in a memmap, eval.py:214-232).
@@ -22,32 +23,49 @@ from ._lib import check, lib
 _vp = ctypes.c_void_p
 
 
-def kmeans(x, k, niter=25, seed=1234, chunk=1 << 14):
-    """Seeded Lloyd k-means on the device.  x (n, d) or batched (G, n, d) f32 -> centroids (k, d) / (G, k, d).
-    Initial centroids = k distinct training points (seeded permutation, the same for every batch entry); an empty
-    cluster keeps its previous centroid.  Deterministic for a given device, seed and input."""
-    squeeze = x.dim() == 2
-    x = x[None] if squeeze else x
-    G, n, d = x.shape
+def _stream():
+    return _vp(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return _vp(t.data_ptr()) if t is not None else None
+
+
+def pq_assign(x, G, cent, base=None, base_idx=None, as_codes=False):
+    """Nearest centroid of every (row, sub-space) (csrc/ivfpq.hip, grafp_pq_assign_f32).  x (n, D) f32 on the device,
+    cent (G, k, D/G); base / base_idx: residuals x[row] - base[base_idx[row]] are quantised instead of the rows.
+    -> (n, G) int32, or uint8 codes with as_codes (k <= 256)."""
+    n, D = x.shape
+    k = cent.shape[-2]
+    out = torch.empty((n, G), dtype=torch.uint8 if as_codes else torch.int32, device=x.device)
+    check(lib.grafp_pq_assign_f32(_ptr(x), n, D, G, _ptr(base), _ptr(base_idx), _ptr(cent), k,
+                                  None if as_codes else _ptr(out), _ptr(out) if as_codes else None, _stream()),
+          "pq_assign")
+    return out
+
+
+def kmeans_init_rows(n, k, seed):
+    """k distinct training rows (seeded permutation; repeated when there are fewer rows than centroids)."""
     gen = torch.Generator().manual_seed(int(seed))
-    perm = torch.randperm(n, generator=gen)[:k].to(x.device)
-    if perm.numel() < k:                                            # fewer points than centroids: repeat
+    perm = torch.randperm(n, generator=gen)[:k]
+    if perm.numel() < k:
         perm = perm.repeat((k + perm.numel() - 1) // perm.numel())[:k]
-    cent = x[:, perm].clone()
-    for _ in range(niter):
-        sums = torch.zeros_like(cent)
-        cnt = torch.zeros((G, k), dtype=torch.float32, device=x.device)
-        c2 = (cent * cent).sum(-1)                                  # (G, k)
-        for lo in range(0, n, chunk):
-            xb = x[:, lo:lo + chunk]
-            dist = c2[:, None, :] - 2.0 * torch.bmm(xb, cent.transpose(1, 2))        # + |x|^2: constant per row
-            a = dist.argmin(dim=2)                                  # (G, nb)
-            # cluster sums as a one-hot product: a fixed summation order (scatter_add's atomics are not reproducible)
-            oh = torch.nn.functional.one_hot(a, k).to(torch.float32)                 # (G, nb, k)
-            sums += torch.bmm(oh.transpose(1, 2), xb)
-            cnt += oh.sum(dim=1)
-        cent = torch.where(cnt[:, :, None] > 0, sums / cnt.clamp_min(1.0)[:, :, None], cent)
-    return cent[0] if squeeze else cent
+    return perm.to(torch.int64)
+
+
+def kmeans(x, G, k, niter=25, seed=1234, base=None, base_idx=None):
+    """Seeded Lloyd k-means wholly on the device (csrc/ivfpq.hip, grafp_kmeans_f32): x (n, D) f32 split into G
+    sub-spaces -> centroids (G, k, D/G).  Initial centroids = k distinct training rows (seeded permutation, the same for
+    every sub-space); cluster sums in a fixed order (reproducible bit for bit, restated by oracle/csrc/ivfpq.c); an
+    empty cluster keeps its previous centroid."""
+    n, D = x.shape
+    init = kmeans_init_rows(n, k, seed).to(x.device)
+    cent = torch.empty((G, k, D // G), dtype=torch.float32, device=x.device)
+    ws_bytes = int(lib.grafp_kmeans_workspace(n, D, G, k))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+    check(lib.grafp_kmeans_f32(_ptr(x), n, D, G, _ptr(base), _ptr(base_idx), _ptr(init), k, int(niter), _ptr(cent),
+                               _ptr(ws), ws_bytes, _stream()), "kmeans")
+    return cent
 
 
 class IVFPQIndex:
@@ -80,23 +98,18 @@ class IVFPQIndex:
             x = x.reshape(-1, self.d)[sel.to(x.device)] if torch.is_tensor(x) else np.asarray(x).reshape(-1, self.d)[sel.numpy()]
         x = torch.as_tensor(np.ascontiguousarray(x) if isinstance(x, np.ndarray) else x).to(self.device, torch.float32)
         x = x.reshape(-1, self.d)
-        self.centroids = kmeans(x, self.nlist, self.niter, self.seed).contiguous()
-        res = x - self.centroids[self._assign_lists(x)]
-        sub = res.reshape(-1, self.M, self.dsub).permute(1, 0, 2).contiguous()          # (M, n, dsub)
-        self.codebooks = kmeans(sub, 256, self.niter, self.seed + 2, chunk=1 << 14).contiguous()
+        x = x.contiguous()
+        self.centroids = kmeans(x, 1, self.nlist, self.niter, self.seed)[0].contiguous()
+        a = pq_assign(x, 1, self.centroids[None]).reshape(-1)
+        self.codebooks = kmeans(x, self.M, 256, self.niter, self.seed + 2, base=self.centroids, base_idx=a).contiguous()
         self.is_trained = True
-
-    def _assign_lists(self, x):
-        c = self.centroids
-        return ((c * c).sum(1)[None, :] - 2.0 * x @ c.t()).argmin(dim=1)
 
     def encode(self, x):
         """x (n, d) on the device -> (list id (n) int64, codes (n, M) uint8)."""
-        a = self._assign_lists(x)
-        sub = (x - self.centroids[a]).reshape(-1, self.M, self.dsub).permute(1, 0, 2)     # (M, n, dsub)
-        cb = self.codebooks
-        dist = (cb * cb).sum(-1)[:, None, :] - 2.0 * torch.bmm(sub, cb.transpose(1, 2))  # (M, n, 256)
-        return a, dist.argmin(dim=2).t().contiguous().to(torch.uint8)
+        x = x.contiguous()
+        a = pq_assign(x, 1, self.centroids[None]).reshape(-1)
+        codes = pq_assign(x, self.M, self.codebooks, base=self.centroids, base_idx=a, as_codes=True)
+        return a.to(torch.int64), codes
 
     def add(self, x, chunk=1 << 16):
         if not self.is_trained:
@@ -127,44 +140,25 @@ class IVFPQIndex:
         self._materialise()
         return self._raw[0]
 
-    # ---- search: nprobe nearest lists, asymmetric distances of their codes (csrc/ivfpq.hip), top-k --------------------
-    def search(self, q, k, max_queries_per_launch=None, scratch_bytes=1 << 30):
-        """max_queries_per_launch: None = as many queries per scan launch as `scratch_bytes` (default 1 GiB) of distance /
-        position scratch allow -- a launch needs 8 bytes per (query, code of a probed list), and the probed lists hold
-        about nprobe / nlist of the index, so the dense form grows with ntotal (at the protocol's dummy-DB sizes a fixed
-        256-query launch would ask for tens of GB)."""
+    # ---- search: nprobe nearest lists (grafp_ivfpq_probe_f32), then ONE launch that scans their codes with the running
+    # top-k fused in (grafp_ivfpq_search_f32): no (query x probed codes) scratch, no host round trip ------------------------
+    def search(self, q, k):
         as_numpy = isinstance(q, np.ndarray)
         qt = torch.as_tensor(np.ascontiguousarray(q) if as_numpy else q).to(self.device, torch.float32).reshape(-1, self.d)
+        qt = qt.contiguous()
         nq = qt.shape[0]
+        if not 1 <= k <= 32:
+            raise ValueError("IVFPQIndex.search: 1 <= k <= 32 (GRAFP_SEARCH_MAX_K), as for the exact index")
         D = torch.full((nq, k), float("inf"), device=self.device)
         I = torch.full((nq, k), -1, dtype=torch.int64, device=self.device)
         if self.ntotal and nq:
-            codes, ids, start, counts = self._materialise()
+            codes, ids, start, _counts = self._materialise()
             nprobe = max(1, min(int(self.nprobe), self.nlist))
-            c = self.centroids
-            coarse = (c * c).sum(1)[None, :] - 2.0 * qt @ c.t()
-            probe = torch.topk(coarse, nprobe, dim=1, largest=False).indices.to(torch.int32).contiguous()
-            stream = _vp(torch.cuda.current_stream().cuda_stream)
-            if max_queries_per_launch is None:
-                # upper bound of a query's probed codes (the nprobe longest lists): one host read per search() call
-                per_query = int(torch.topk(counts, nprobe).values.sum().item()) * 8
-                max_queries_per_launch = max(1, min(256, int(scratch_bytes // max(per_query, 1))))
-            for lo in range(0, nq, max_queries_per_launch):
-                pb = probe[lo:lo + max_queries_per_launch]
-                qb = qt[lo:lo + max_queries_per_launch].contiguous()
-                lens = counts[pb.long()]                                                  # (nb, nprobe)
-                ostart = (torch.cumsum(lens, 1) - lens).contiguous()
-                stride = max(int(lens.sum(1).max().item()), 1)
-                dist = torch.full((qb.shape[0], stride), float("inf"), device=self.device)
-                pos = torch.full((qb.shape[0], stride), -1, dtype=torch.int32, device=self.device)
-                check(lib.grafp_ivfpq_scan_f32(_vp(qb.data_ptr()), qb.shape[0], self.d, _vp(c.data_ptr()), self.nlist,
-                                               _vp(self.codebooks.data_ptr()), self.M, _vp(codes.data_ptr()),
-                                               _vp(start.data_ptr()), _vp(pb.data_ptr()), nprobe, _vp(ostart.data_ptr()),
-                                               stride, _vp(dist.data_ptr()), _vp(pos.data_ptr()), stream), "ivfpq_scan")
-                kk = min(k, stride)
-                dv, di = torch.topk(dist, kk, dim=1, largest=False)
-                pv = torch.gather(pos, 1, di).long()
-                found = pv >= 0
-                D[lo:lo + qb.shape[0], :kk] = torch.where(found, dv, torch.full_like(dv, float("inf")))
-                I[lo:lo + qb.shape[0], :kk] = torch.where(found, ids[pv.clamp_min(0)], torch.full_like(pv, -1))
+            probe = torch.empty((nq, nprobe), dtype=torch.int32, device=self.device)
+            stream = _stream()
+            check(lib.grafp_ivfpq_probe_f32(_ptr(qt), nq, self.d, _ptr(self.centroids), self.nlist, nprobe, _ptr(probe),
+                                            stream), "ivfpq_probe")
+            check(lib.grafp_ivfpq_search_f32(_ptr(qt), nq, self.d, _ptr(self.centroids), self.nlist, _ptr(self.codebooks),
+                                             self.M, _ptr(codes), _ptr(start), _ptr(ids), _ptr(probe), nprobe, k, _ptr(D),
+                                             _ptr(I), stream), "ivfpq_search")
         return (D.cpu().numpy(), I.cpu().numpy()) if as_numpy else (D, I)

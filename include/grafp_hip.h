@@ -233,6 +233,36 @@ int grafp_ivfpq_scan_f32(const float *q, int nq, int d, const float *centroids, 
                          const int64_t *out_start, int64_t row_stride, float *out_dist, int32_t *out_pos,
                          grafp_stream_t stream);
 
+/* ---- IVF-PQ parity index: training, encoding, probing and the fused search (round 4) ------------------------------------
+ * faiss.IndexIVFPQ.train / add / search of eval.py:65-69,122,212-213,269-270 (test_fp.py:276 defaults to it).  All
+ * arithmetic is fixed so that oracle/csrc/ivfpq.c restates it bit for bit:
+ *   residual r = x[row] - base[base_idx[row]]   (base == NULL: r = x[row]);   G sub-spaces of d = D / G dims;
+ *   dist(row, g, j) = fmaf chain over c ascending of (r[g d + c] - cent[g][j][c])^2, start 0;   argmin: lowest j on ties.
+ * grafp_pq_assign_f32: out (n, G) int32 and/or out_u8 (n, G) uint8 (k <= 256) -- coarse assignment (G = 1, k = nlist) and
+ * PQ encoding (G = M, k = 256, base = the coarse centroids, base_idx = the coarse assignment) alike.
+ * grafp_kmeans_f32: seeded Lloyd iterations wholly on the device.  cent (G, k, d) <- the residuals of rows init_rows[0..k);
+ * `niter` times: assignment as above; per cluster the sum of its residuals over rows in 1024-row chunks (row order inside
+ * a chunk, f32 adds), chunk sums added in chunk order, centroid = sum / (float)count, a cluster without rows keeps its
+ * centroid.  faiss's own k-means (initialisation, sub-sampling order) is not reproducible without faiss: the trained
+ * quantisers are comparable with it only statistically; everything downstream of them is deterministic. */
+int grafp_pq_assign_f32(const float *x, int64_t n, int D, int G, const float *base /* (nbase, D) or NULL */,
+                        const int32_t *base_idx /* (n) or NULL */, const float *cent /* (G, k, D/G) */, int k,
+                        int32_t *out /* (n, G) or NULL */, uint8_t *out_u8 /* (n, G) or NULL */, grafp_stream_t stream);
+size_t grafp_kmeans_workspace(int64_t n, int D, int G, int k);
+int grafp_kmeans_f32(const float *x, int64_t n, int D, int G, const float *base, const int32_t *base_idx,
+                     const int64_t *init_rows /* (k) */, int k, int niter, float *cent /* (G, k, D/G) */, void *ws,
+                     size_t ws_bytes, grafp_stream_t stream);
+/* probe (nq, nprobe) int32: the nprobe nearest lists of every query by (dist, list id), dist = fmaf chain of
+ * (q_c - centroid_c)^2.  */
+int grafp_ivfpq_probe_f32(const float *q, int nq, int d, const float *centroids, int nlist, int nprobe, int32_t *probe,
+                          grafp_stream_t stream);
+/* The search proper: for every query the k <= GRAFP_SEARCH_MAX_K smallest asymmetric distances over the codes of its
+ * probed lists, ordered by (distance, id), ids = ids[position in the list-ordered code array] (< 2^31); missing results
+ * are (+inf, -1).  Estimates as in grafp_ivfpq_scan_f32 (sub-space terms added in m order); no scratch. */
+int grafp_ivfpq_search_f32(const float *q, int nq, int d, const float *centroids, int nlist, const float *codebooks, int M,
+                           const uint8_t *codes, const int64_t *list_start, const int64_t *ids, const int32_t *probe,
+                           int nprobe, int k, float *out_dist, int64_t *out_ids, grafp_stream_t stream);
+
 /* Test helper (no reference counterpart, no state): a kernel that merely occupies `blocks` x `threads` CU slots for
  * `clocks` shader cycles -- the BatchNorm rendezvous is tested next to it. */
 int grafp_debug_occupy(int blocks, int threads, int64_t clocks, grafp_stream_t stream);

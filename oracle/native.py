@@ -51,6 +51,17 @@ def lib():
         L.oracle_ir_convolve.restype = None
         L.oracle_mix_snr.argtypes = [f32p, ctypes.c_int, ctypes.c_int, f32p, i64p, i32p, i32p, i32p, f32p, f32p]
         L.oracle_mix_snr.restype = None
+        u8p = ctypes.POINTER(ctypes.c_uint8)
+        L.oracle_pq_assign.argtypes = [f32p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, f32p, i32p, f32p, ctypes.c_int, i32p]
+        L.oracle_pq_assign.restype = None
+        L.oracle_kmeans.argtypes = [f32p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, f32p, i32p, i64p, ctypes.c_int,
+                                    ctypes.c_int, f32p]
+        L.oracle_kmeans.restype = ctypes.c_int
+        L.oracle_ivfpq_probe.argtypes = [f32p, ctypes.c_int, ctypes.c_int, f32p, ctypes.c_int, ctypes.c_int, i32p]
+        L.oracle_ivfpq_probe.restype = None
+        L.oracle_ivfpq_search.argtypes = [f32p, ctypes.c_int, ctypes.c_int, f32p, f32p, ctypes.c_int, u8p, i64p, i64p,
+                                          i32p, ctypes.c_int, ctypes.c_int, f32p, i64p]
+        L.oracle_ivfpq_search.restype = ctypes.c_int
         _LIB = L
     return _LIB
 
@@ -163,3 +174,67 @@ def mix_snr(x, noise_bank, noise_len, noise_index, noise_offset, snr_db, noise_s
                          ln.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), nip, nop, sp,
                          out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
     return out
+
+
+# ---- IVF-PQ (csrc/ivfpq.c) ---------------------------------------------------------------------------------------------
+def _pi32(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+
+
+def _opt_base(base, base_idx):
+    if base is None:
+        return None, None, None, None
+    b, bp = _f32(base)
+    bi = np.ascontiguousarray(base_idx, dtype=np.int32)
+    return b, bp, bi, _pi32(bi)
+
+
+def pq_assign(x, G, cent, base=None, base_idx=None):
+    """x (n, D), cent (G, k, D/G) -> (n, G) int32: nearest codeword of every (row, sub-space) of the residuals."""
+    x, xp = _f32(x)
+    c, cp = _f32(cent)
+    n, D = x.shape
+    k = c.shape[-2]
+    _b, bp, _bi, bip = _opt_base(base, base_idx)
+    out = np.empty((n, G), dtype=np.int32)
+    lib().oracle_pq_assign(xp, n, D, G, bp, bip, cp, k, _pi32(out))
+    return out
+
+
+def kmeans(x, G, k, init_rows, niter, base=None, base_idx=None):
+    """Seeded Lloyd iterations with the summation order fixed in csrc/ivfpq.c -> centroids (G, k, D/G) f32."""
+    x, xp = _f32(x)
+    n, D = x.shape
+    init = np.ascontiguousarray(init_rows, dtype=np.int64)
+    _b, bp, _bi, bip = _opt_base(base, base_idx)
+    cent = np.empty((G, k, D // G), dtype=np.float32)
+    rc = lib().oracle_kmeans(xp, n, D, G, bp, bip, _i64(init), k, niter,
+                             cent.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+    if rc != 0:
+        raise MemoryError("oracle_kmeans")
+    return cent
+
+
+def ivfpq_probe(q, cent, nprobe):
+    q, qp = _f32(q)
+    c, cp = _f32(cent)
+    probe = np.empty((q.shape[0], nprobe), dtype=np.int32)
+    lib().oracle_ivfpq_probe(qp, q.shape[0], q.shape[1], cp, c.shape[0], nprobe, _pi32(probe))
+    return probe
+
+
+def ivfpq_search(q, cent, books, codes, list_start, ids, probe, k):
+    """codes (n, M) uint8 and ids (n) int64 in list order -> (D (nq, k) f32, I (nq, k) int64) by (estimate, id)."""
+    q, qp = _f32(q)
+    c, cp = _f32(cent)
+    b, bp = _f32(books)
+    codes = np.ascontiguousarray(codes, dtype=np.uint8)
+    ls = np.ascontiguousarray(list_start, dtype=np.int64)
+    ids = np.ascontiguousarray(ids, dtype=np.int64)
+    probe = np.ascontiguousarray(probe, dtype=np.int32)
+    D = np.empty((q.shape[0], k), dtype=np.float32)
+    I = np.empty((q.shape[0], k), dtype=np.int64)
+    lib().oracle_ivfpq_search(qp, q.shape[0], q.shape[1], cp, bp, b.shape[0],
+                              codes.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), _i64(ls), _i64(ids), _pi32(probe),
+                              probe.shape[1], k, D.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), _i64(I))
+    return D, I

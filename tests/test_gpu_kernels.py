@@ -1051,34 +1051,65 @@ def test_bn_single_pass_never_depends_on_absent_row_mates(dev, monkeypatch):
 
 # =============================================================== IVF-PQ parity index
 def test_ivfpq_index_vs_oracle_and_exact(dev):
-    """grafp_amd.ivfpq.IVFPQIndex (seeded k-means on the device, HIP asymmetric-distance scan) against the numpy
-    restatement given the SAME quantisers: identical codes (outside near-ties), identical search results; and against
-    the exact index statistically: recall of the true nearest neighbour among its top-20."""
-    from grafp_amd.ivfpq import IVFPQIndex
+    """grafp_amd.ivfpq.IVFPQIndex -- k-means, encoding, probe and the fused scan + top-k all in csrc/ivfpq.hip -- against
+    oracle/csrc/ivfpq.c BIT FOR BIT (trained quantisers, list ids, codes, probed lists, result ids and distances), against
+    the numpy (float64) restatement of the published definition within rounding, and against the exact index
+    statistically: recall of the true nearest neighbour among its top-20."""
+    from grafp_amd.ivfpq import IVFPQIndex, kmeans_init_rows
     from grafp_amd.ops import FlatL2Index
     from oracle import ivfpq as oq
+    from oracle import native
     rng = np.random.RandomState(3)
     n, d = 6000, 128
     base = rng.randn(40, d).astype(np.float32)
     x = (base[rng.randint(0, 40, n)] + 0.35 * rng.randn(n, d)).astype(np.float32)       # clustered, like fingerprints
     x /= np.linalg.norm(x, axis=1, keepdims=True)
-    idx = IVFPQIndex(d, nlist=16, M=64)
+    idx = IVFPQIndex(d, nlist=16, M=64, niter=6)
     idx.train(x)
-    idx2 = IVFPQIndex(d, nlist=16, M=64)
+    idx2 = IVFPQIndex(d, nlist=16, M=64, niter=6)
     idx2.train(x)
     assert torch.equal(idx.centroids, idx2.centroids) and torch.equal(idx.codebooks, idx2.codebooks)   # seeded
+    # training == the C restatement of the same seeded Lloyd iterations, bit for bit
+    cent_o = native.kmeans(x, 1, 16, kmeans_init_rows(n, 16, idx.seed).numpy(), 6)[0]
+    assert np.array_equal(idx.centroids.cpu().numpy(), cent_o)
+    a_tr = native.pq_assign(x, 1, cent_o[None])[:, 0]
+    books_o = native.kmeans(x, 64, 256, kmeans_init_rows(n, 256, idx.seed + 2).numpy(), 6, base=cent_o, base_idx=a_tr)
+    assert np.array_equal(idx.codebooks.cpu().numpy(), books_o)
     idx.add(x[:2500]); idx.add(x[2500:])
     idx.nprobe = 5
-    cent, books = idx.centroids.cpu().numpy(), idx.codebooks.cpu().numpy()
-    a_o, codes_o = oq.encode(x, cent, books)
+    cent, books = cent_o, books_o
     a_g, codes_g = torch.cat(idx._assign).cpu().numpy(), torch.cat(idx._codes).cpu().numpy()
+    assert np.array_equal(a_g, a_tr)                                                    # coarse assignment: C oracle
+    assert np.array_equal(codes_g, native.pq_assign(x, 64, books, base=cent, base_idx=a_tr).astype(np.uint8))
+    a_o, codes_o = oq.encode(x, cent, books)                                            # float64 definition
     assert (a_g == a_o).mean() > 0.999 and (codes_g == codes_o).mean() > 0.999          # f32 vs f64 near-ties only
     q = (x[::60] + 0.05 * rng.randn(100, d)).astype(np.float32)
     D, I = idx.search(q, 20)
-    Do, Io = oq.search(q, a_g, codes_g, cent, books, 5, 20)                               # the index's own codes
+    order = np.argsort(a_g, kind="stable")
+    start = np.r_[0, np.cumsum(np.bincount(a_g, minlength=16))]
+    probe_o = native.ivfpq_probe(q, cent, 5)
+    Dc, Ic = native.ivfpq_search(q, cent, books, codes_g[order], start, order, probe_o, 20)
+    assert np.array_equal(I, Ic) and np.array_equal(D, Dc)                               # search: C oracle, bit for bit
+    Do, Io = oq.search(q, a_g, codes_g, cent, books, 5, 20)                               # float64 definition
     np.testing.assert_allclose(D, Do, rtol=2e-4, atol=2e-5)
     assert (I == Io).mean() > 0.99
-    # torch tensors in, tensors out; k larger than a probe's content
+    # duplicates: equal estimates come back lowest id first; fewer candidates than k: (+inf, -1) padding
+    dup = IVFPQIndex(d, nlist=4, M=64, niter=2)
+    dup.train(x[:600])
+    dup.add(np.tile(x[:7], (5, 1)))
+    dup.nprobe = 4
+    Dd, Id = dup.search(x[:3], 32)
+    for r in range(3):
+        assert list(Id[r, :5]) == [r, r + 7, r + 14, r + 21, r + 28] and (Dd[r, :5] == Dd[r, 0]).all()
+    few = IVFPQIndex(d, nlist=4, M=64, niter=2)
+    few.train(x[:600])
+    few.add(x[:3])
+    few.nprobe = 4
+    Df, If = few.search(x[:2], 10)
+    assert (If[:, 3:] == -1).all() and np.isinf(Df[:, 3:]).all() and sorted(If[0, :3]) == [0, 1, 2]
+    with pytest.raises(ValueError):                                                      # k <= 32, as for the exact index
+        idx.search(q, 33)
+    # torch tensors in, tensors out
     Dt, It = idx.search(torch.from_numpy(q[:3]).to(dev), 4)
     assert Dt.is_cuda and torch.equal(It.cpu(), torch.from_numpy(I[:3, :4]))
     # against the exact index: the planted neighbour is found
@@ -1090,6 +1121,43 @@ def test_ivfpq_index_vs_oracle_and_exact(dev):
     _, Iall = idx.search(q, 20)
     assert (Iall == Ie[:, :1]).any(axis=1).mean() > 0.97
     assert idx.rows().shape == (n, d) and idx.ntotal == n
+
+
+def test_ivfpq_dense_scan_agrees_with_the_fused_search(dev):
+    """grafp_ivfpq_scan_f32 (every estimate of the probed lists out, the round-1 form) followed by a host-side selection
+    gives the fused kernel's results: the two share the table and the order of the sub-space sum."""
+    import ctypes
+    from grafp_amd._lib import check, lib
+    from grafp_amd.ivfpq import IVFPQIndex
+    rng = np.random.RandomState(5)
+    n, d = 3000, 128
+    x = rng.randn(n, d).astype(np.float32)
+    idx = IVFPQIndex(d, nlist=8, M=64, niter=3)
+    idx.train(x)
+    idx.add(x)
+    idx.nprobe = 3
+    q = torch.from_numpy(x[:17] + 0.01).to(dev)
+    D, I = idx.search(q, 10)
+    codes, ids, start, counts = idx._materialise()
+    probe = torch.empty((17, 3), dtype=torch.int32, device=dev)
+    vp = ctypes.c_void_p
+    st = vp(torch.cuda.current_stream().cuda_stream)
+    check(lib.grafp_ivfpq_probe_f32(vp(q.data_ptr()), 17, d, vp(idx.centroids.data_ptr()), 8, 3, vp(probe.data_ptr()), st),
+          "probe")
+    lens = counts[probe.long()]
+    ostart = (torch.cumsum(lens, 1) - lens).contiguous()
+    stride = int(lens.sum(1).max().item())
+    dist = torch.full((17, stride), float("inf"), device=dev)
+    pos = torch.full((17, stride), -1, dtype=torch.int32, device=dev)
+    check(lib.grafp_ivfpq_scan_f32(vp(q.data_ptr()), 17, d, vp(idx.centroids.data_ptr()), 8, vp(idx.codebooks.data_ptr()), 64,
+                                   vp(codes.data_ptr()), vp(start.data_ptr()), vp(probe.data_ptr()), 3, vp(ostart.data_ptr()),
+                                   stride, vp(dist.data_ptr()), vp(pos.data_ptr()), st), "scan")
+    dist, pos, ids = dist.cpu().numpy(), pos.cpu().numpy(), ids.cpu().numpy()
+    for r in range(17):
+        ok = pos[r] >= 0
+        cand_i, cand_d = ids[pos[r][ok]], dist[r][ok]
+        sel = np.lexsort((cand_i, cand_d))[:10]
+        assert np.array_equal(cand_i[sel], I[r].cpu().numpy()) and np.array_equal(cand_d[sel], D[r].cpu().numpy())
 
 
 def test_eval_faiss_with_the_ivfpq_index(dev, tmp_path, monkeypatch):

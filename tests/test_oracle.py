@@ -421,3 +421,37 @@ def test_ivfpq_restatement_is_the_distance_to_the_dequantised_vector():
     assert (I == order).mean() > 0.98                                               # ties aside
     D2, I2 = ivfpq.search(q, a, codes, cent, books, nprobe=2, k=10)                   # fewer lists: a subset, never better
     assert (D2[:, 0] >= D[:, 0] - 1e-12).all() and ((I2 >= 0).sum(1) <= 10).all()
+
+
+def test_ivfpq_c_restatement_agrees_with_the_float64_definition():
+    """oracle/csrc/ivfpq.c (f32, the accumulation orders the HIP kernels follow) against oracle/ivfpq.py (float64, the
+    published definition): identical list ids and codes away from near-ties, identical result ids, distances within f32
+    rounding; the seeded Lloyd iterations reduce the quantisation error monotonically."""
+    from oracle import ivfpq, native
+    rng = np.random.RandomState(0)
+    x = rng.randn(3000, 16).astype(np.float32)
+    init = np.arange(8) * 7
+    errs = []
+    for niter in (0, 1, 4):
+        cent = native.kmeans(x, 1, 8, init, niter)[0]
+        a = native.pq_assign(x, 1, cent[None])[:, 0]
+        errs.append(float(((x - cent[a]) ** 2).sum()))
+    assert errs[0] > errs[1] > errs[2]
+    assert np.array_equal(native.kmeans(x, 1, 8, init, 0)[0], x[init])                  # no iteration: the seeds
+    assert (a == ivfpq.assign(x, cent)).mean() > 0.999
+    books = native.kmeans(x, 8, 256, np.arange(256) * 3, 3, base=cent, base_idx=a)
+    codes = native.pq_assign(x, 8, books, base=cent, base_idx=a).astype(np.uint8)
+    a64, codes64 = ivfpq.encode(x, cent, books)
+    assert (codes == codes64).mean() > 0.999
+    order = np.argsort(a, kind="stable")
+    start = np.r_[0, np.cumsum(np.bincount(a, minlength=8))]
+    q = x[:40] + 0.01
+    probe = native.ivfpq_probe(q, cent, 3)
+    D, I = native.ivfpq_search(q, cent, books, codes[order], start, order, probe, 10)
+    D64, I64 = ivfpq.search(q, a, codes, cent, books, 3, 10)
+    assert (I == I64).mean() > 0.99
+    np.testing.assert_allclose(D, D64, rtol=1e-5, atol=1e-5)
+    # an empty cluster keeps its centroid: two identical seeds, the second loses every tie of the first assignment
+    init2 = np.array([0, 0, 5, 9, 11, 13, 17, 19])
+    c2 = native.kmeans(x, 1, 8, init2, 1)[0]
+    assert np.array_equal(c2[1], x[0]) and not np.array_equal(c2[0], x[0])
