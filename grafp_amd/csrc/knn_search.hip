@@ -759,7 +759,7 @@ __global__ __launch_bounds__(256, NQS == 2 ? SB_WGS_NQS2 : 3) void search_scan_b
 // TIGHTEN: only phase A, over the candidates the first part of a two-part scan left: thr[qi] = min(thr[qi], the k-th
 // smallest upper bound) -- the bound the second part then scans with (at least k rows of the first part are that close).
 template <bool TIGHTEN>
-__global__ __launch_bounds__(256) void search_select_exact_kernel(const float *__restrict__ db,
+__global__ __launch_bounds__(256, 4) void search_select_exact_kernel(const float *__restrict__ db,
                                                                   const float *__restrict__ dd, int64_t n,
                                                                   const float *__restrict__ q,
                                                                   const float *__restrict__ qq, int nq, int k,
@@ -806,6 +806,158 @@ __global__ __launch_bounds__(256) void search_select_exact_kernel(const float *_
     WaveTop top;
     float td;
     int ti;
+    auto exact = [&](int64_t row) {                        // the oracle's chain over the 512-byte row
+        // the whole row is requested before the dependent fmaf chain starts (every lane reads a different row)
+        f32x4 xr[SR_D / 4];
+        const f32x4 *rp = reinterpret_cast<const f32x4 *>(db) + row * (SR_D / 4);
+#pragma unroll
+        for (int c4 = 0; c4 < SR_D / 4; ++c4) xr[c4] = rp[c4];
+        const float ddr = dd[row];
+        float ip = 0.0f;
+#pragma unroll
+        for (int c4 = 0; c4 < SR_D / 4; ++c4) {
+            ip = __builtin_fmaf(xr[c4][0], sq[4 * c4 + 0], ip);
+            ip = __builtin_fmaf(xr[c4][1], sq[4 * c4 + 1], ip);
+            ip = __builtin_fmaf(xr[c4][2], sq[4 * c4 + 2], ip);
+            ip = __builtin_fmaf(xr[c4][3], sq[4 * c4 + 3], ip);
+        }
+        const float d = (myqq + ddr) - 2.0f * ip;
+        return d < 0.0f ? 0.0f : d;
+    };
+    // ---- the usual case: a few hundred candidates.  No sorting networks at all (a 64-lane bitonic sort is ~1 700 cycles,
+    // and the fold + three-sort merge of the general path below ran twice per query: 16 of the kernel's 29 us at 41
+    // queries, tools' stop-point timing, round 4):
+    //   phase A  the candidates (row, E, hi) stay in registers (up to eight per thread); the bound is read from a 256-bin histogram of hi between its
+    //            minimum and maximum -- the upper edge (plus one bin against the rounding of the bin index) of the bin
+    //            the k-th smallest falls into: >= the k-th smallest hi, so still a valid bound, a bin or two looser;
+    //   phase B  the rows with lo <= bound are compacted, their exact distances computed one per thread, and every
+    //            thread finds the RANK of its row by counting the (distance, id) pairs before it -- ranks < k are the
+    //            answer, written in place.  O(need^2 / 256) compares per thread: 40 at the usual hundred rows.
+    constexpr int SF_CAP = 2048, SF_NEED = 512, SF_PER = SF_CAP / 256;
+    __shared__ int f_row[SF_NEED];
+    __shared__ float f_hi[SF_NEED];
+    __shared__ int f_hist[256];
+    __shared__ float f_red[2][4];
+    if (listed && c <= SF_CAP) {
+        int row[SF_PER];
+        float ev[SF_PER], ddv[SF_PER], hi[SF_PER];
+#pragma unroll
+        for (int u = 0; u < SF_PER; ++u) {                 // every load of a kind in flight at once; the rounds past the
+            row[u] = 0;                                    // end of the list (u * 256 >= c: uniform) load nothing
+            ev[u] = 0.0f;
+            if (u * 256 < c) {
+                const int e = u * 256 + tid;
+                const size_t sl = (size_t)qi * SR_CAP + slot_of(e < c ? e : c - 1);
+                row[u] = cand_i[sl];
+                ev[u] = cand_e[sl];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < SF_PER; ++u) ddv[u] = u * 256 < c ? dd[row[u]] : 0.0f;
+        float mn = INFINITY, mx = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < SF_PER; ++u) {
+            hi[u] = __builtin_fmaf(dspan, ddv[u], __builtin_fmaf(-2.0f, ev[u], qhi));
+            hi[u] = hi[u] < 0.0f ? 0.0f : hi[u];
+            if (u * 256 + tid < c) {
+                mn = fminf(mn, hi[u]);
+                mx = fmaxf(mx, hi[u]);
+            }
+        }
+        f_hist[tid] = 0;
+#pragma unroll
+        for (int j = 1; j < 64; j <<= 1) {
+            mn = fminf(mn, __shfl_xor(mn, j));
+            mx = fmaxf(mx, __shfl_xor(mx, j));
+        }
+        if (lane == 0) {
+            f_red[0][wave] = mn;
+            f_red[1][wave] = mx;
+        }
+        __syncthreads();
+        const float lo_h = fminf(fminf(f_red[0][0], f_red[0][1]), fminf(f_red[0][2], f_red[0][3]));
+        const float hi_h = fmaxf(fmaxf(f_red[1][0], f_red[1][1]), fmaxf(f_red[1][2], f_red[1][3]));
+        const float w = (hi_h - lo_h) * (1.0f / 256.0f);
+        const float inv = (w > 0.0f && w < INFINITY) ? 1.0f / w : 0.0f;
+#pragma unroll
+        for (int u = 0; u < SF_PER; ++u) {
+            if (u * 256 + tid < c) {
+                int b = (int)((hi[u] - lo_h) * inv);
+                b = b < 0 ? 0 : (b > 255 ? 255 : b);
+                atomicAdd(&f_hist[b], 1);
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {                                   // bins 4 lane .. 4 lane + 3: inclusive scan over the lanes
+            const int h0 = f_hist[4 * lane], h1 = f_hist[4 * lane + 1], h2 = f_hist[4 * lane + 2], h3 = f_hist[4 * lane + 3];
+            const int mine = h0 + h1 + h2 + h3;
+            int cum = mine;
+#pragma unroll
+            for (int j = 1; j < 64; j <<= 1) {
+                const int o = __shfl_up(cum, j);
+                if (lane >= j) cum += o;
+            }
+            const int before = cum - mine;                 // candidates in the bins of the lanes below
+            if (c < k) {
+                if (lane == 0) s_thr2 = INFINITY;          // fewer than k candidates exist
+            } else if (before < k && cum >= k) {           // exactly one lane
+                int b = 4 * lane, run = before + h0;
+                if (run < k) { ++b; run += h1; }
+                if (run < k) { ++b; run += h2; }
+                if (run < k) { ++b; }
+                s_thr2 = fminf(hi_h, __builtin_fmaf((float)(b + 2), w, lo_h));
+            }
+        }
+        __syncthreads();
+        thr2 = fminf(thr2, s_thr2);
+        if (TIGHTEN) {
+            if (tid == 0) thr[qi] = thr2;
+            return;
+        }
+        const float qlo = myqq * kminus;
+        if (tid == 0) s_nneed = 0;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < SF_PER; ++u)
+            if (u * 256 + tid < c && __builtin_fmaf(-2.0f, ev[u], qlo) <= thr2)          // lo: no dd[row] needed
+                need_rows[atomicAdd(&s_nneed, 1)] = row[u];
+        __syncthreads();
+        const int nneed = s_nneed;
+        if (nneed <= SF_NEED) {                            // (uniform) else: the general path below, from the lists
+            float dmine[SF_NEED / 256];
+            int rmine[SF_NEED / 256];
+#pragma unroll
+            for (int v = 0; v < SF_NEED / 256; ++v) {
+                const int i = v * 256 + tid;
+                rmine[v] = i < nneed ? need_rows[i] : 0;
+                dmine[v] = (v * 256 < nneed) ? (i < nneed ? exact(rmine[v]) : INFINITY) : INFINITY;
+                if (i < nneed) {
+                    f_hi[i] = dmine[v];
+                    f_row[i] = rmine[v];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int v = 0; v < SF_NEED / 256; ++v) {
+                const int i = v * 256 + tid;
+                if (v * 256 < nneed) {                     // uniform
+                    int rank = 0;
+                    for (int j = 0; j < nneed; ++j) rank += lex_lt(f_hi[j], f_row[j], dmine[v], rmine[v]) ? 1 : 0;
+                    if (i < nneed && rank < k) {
+                        out_d[(size_t)qi * k + rank] = dmine[v];
+                        out_i[(size_t)qi * k + rank] = id_base + (int64_t)rmine[v];
+                    }
+                }
+            }
+            if (tid >= nneed && tid < k) {                 // fewer rows than k (k <= 32 < 256)
+                out_d[(size_t)qi * k + tid] = INFINITY;
+                out_i[(size_t)qi * k + tid] = -1;
+            }
+            return;
+        }
+        thr2 = thr[qi];                                    // the general path recomputes its own bound
+        __syncthreads();
+    }
     if (listed) {                                          // phase A: k-th smallest upper bound
         top.init(pend_d[wave], pend_i[wave], INFINITY);
         // four candidates per thread and round, every load of a kind in flight at once (indices clamped to the last
@@ -844,24 +996,6 @@ __global__ __launch_bounds__(256) void search_select_exact_kernel(const float *_
     __syncthreads();                                       // sq visible; the merge buffers are free again
     // phase B: exact distances of the rows that can still be among the k best
     top.init(pend_d[wave], pend_i[wave], thr2);
-    auto exact = [&](int64_t row) {                        // the oracle's chain over the 512-byte row
-        // the whole row is requested before the dependent fmaf chain starts (every lane reads a different row)
-        f32x4 xr[SR_D / 4];
-        const f32x4 *rp = reinterpret_cast<const f32x4 *>(db) + row * (SR_D / 4);
-#pragma unroll
-        for (int c4 = 0; c4 < SR_D / 4; ++c4) xr[c4] = rp[c4];
-        const float ddr = dd[row];
-        float ip = 0.0f;
-#pragma unroll
-        for (int c4 = 0; c4 < SR_D / 4; ++c4) {
-            ip = __builtin_fmaf(xr[c4][0], sq[4 * c4 + 0], ip);
-            ip = __builtin_fmaf(xr[c4][1], sq[4 * c4 + 1], ip);
-            ip = __builtin_fmaf(xr[c4][2], sq[4 * c4 + 2], ip);
-            ip = __builtin_fmaf(xr[c4][3], sq[4 * c4 + 3], ip);
-        }
-        const float d = (myqq + ddr) - 2.0f * ip;
-        return d < 0.0f ? 0.0f : d;
-    };
     if (listed) {
         // the rows still in question (lo <= the bound of phase A: a few dozen of the several hundred) are compacted
         // into an LDS list first, then fetched one per thread side by side -- picked out of the candidate rounds where
@@ -1175,7 +1309,10 @@ extern "C" int grafp_knn_search_l2_pre(const float *db, const void *db_bf16, con
     split_rows(n - n_first, SB_TR, want, &splits, &rps);
     int64_t b_rows = n / 16 > 65536 ? n / 16 : 65536;
     if (b_rows > n) b_rows = n;
-    int64_t bwant = 1024 / qgroups;
+    // pre-pass workgroups: ONE per CU, four or more ring stages each (round 4; 1024 one-tile workgroups paid their prologue
+    // -- the query operand, the ring fill -- for a single tile: 41 queries 0.092 -> 0.079 ms, 1 query 0.080 -> 0.070, no
+    // batch size slower); never fewer than the 64 (split, row-wave, half) groups the threshold kernel selects from
+    int64_t bwant = GRAFP_TUNE_INT("GRAFP_SEARCH_BWANT", 256) / qgroups;
     const int64_t bneed = (32 + rw - 1) / rw;
     if (bwant < bneed) bwant = bneed;
     split_rows(b_rows, SB_TR, bwant, &b_splits, &b_rps);
