@@ -391,6 +391,54 @@ constexpr int SB_NS = 3;             // ring stages: two tiles in flight behind 
 constexpr int SB_STAGE = SB_TR * 256 + SB_TR * 4;   // rows (256 B, 16-byte pieces XOR-swizzled by row) + their norms
 constexpr int SB_PER = 5;            // LDS-DMA instructions per tile and wave: 4 x 1 KB of rows + 16 norms
 constexpr float SB_SLACK = 0.008f;
+
+// The bf16 pre-filter path's form of launches 0 and 2 in one: query norm (the serial chain of search_init_kernel, lane 0),
+// empty candidate lists, and the bound from the pre-pass's raw group maxima gmax[q][ngroups] (group g belongs to class
+// g & 63; d~ + SLACK (qq + dd) = qq kplus - 2 max, and the fma is monotone, so the class minimum of the bounds is the
+// bound of the class maximum: the same bits the per-lane atomicMin of rounds 1-3 produced).  One wave per query.
+__global__ __launch_bounds__(256) void search_thr_pre_kernel(const float *__restrict__ q, int nq,
+                                                             const float *__restrict__ gmax, int ngroups, int k,
+                                                             float *__restrict__ qq, float *__restrict__ thr,
+                                                             int *__restrict__ cnt) {
+    const int lane = threadIdx.x & 63;
+    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (qi >= nq) return;
+    float m = -INFINITY;
+    {                                                      // eight loads in flight per lane (ngroups is 64 ... 1024)
+        const float *gq = gmax + (size_t)qi * ngroups;
+        int g = lane;
+        for (; g + 7 * 64 < ngroups; g += 8 * 64) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = gq[g + 64 * u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) m = fmaxf(m, v[u]);
+        }
+        for (; g < ngroups; g += 64) m = fmaxf(m, gq[g]);
+    }
+    // the query's norm: the serial chain of row_sqnorm_kernel, every lane running it on broadcasts (v_readlane) of the two
+    // coalesced loads that fetched the row -- one lane walking the row element by element was 5 of this kernel's 8 us
+    const float v0 = q[(size_t)qi * SR_D + lane], v1 = q[(size_t)qi * SR_D + 64 + lane];
+    float s = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 64; ++c) {
+        const float x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v0), c));
+        s = __builtin_fmaf(x, x, s);
+    }
+#pragma unroll
+    for (int c = 0; c < 64; ++c) {
+        const float x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v1), c));
+        s = __builtin_fmaf(x, x, s);
+    }
+    if (lane == 0) qq[qi] = s;
+    if (lane < SR_NSUB) cnt[qi * SR_NSUB + lane] = 0;
+    float d = m > -INFINITY ? __builtin_fmaf(-2.0f, m, s * (1.0f + SB_SLACK)) : INFINITY;
+    d = d < 0.0f ? 0.0f : d;
+    int i = lane;
+    wave_sort64(d, i, lane);
+    if (lane == k - 1) thr[qi] = d;      // +inf when fewer than k groups saw a row: every row is a candidate
+}
+
 constexpr int SB_WGS_NQS2 = 2;      // workgroups per CU of the two-query-set form (three: 168 registers, 16-21 dwords spilled, same time)
 
 __device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
@@ -604,7 +652,7 @@ __device__ __forceinline__ void stream_tiles_bf16(const unsigned short *__restri
 template <int QW, int NQS, int ABL = 0>
 __global__ __launch_bounds__(256, NQS == 2 ? SB_WGS_NQS2 : 3) void search_bound_bf16_kernel(
     const unsigned short *__restrict__ dbh, const float *__restrict__ dd, int64_t n_sample, const float *__restrict__ q,
-    const float *__restrict__ qq, int nq, int64_t rows_per_split, int *__restrict__ gmin) {
+    int nq, int64_t rows_per_split, float *__restrict__ gmax, int ngroups) {
     constexpr int RW = 4 / QW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned char *ring = reinterpret_cast<unsigned char *>(smem);
@@ -617,12 +665,11 @@ __global__ __launch_bounds__(256, NQS == 2 ? SB_WGS_NQS2 : 3) void search_bound_
     const float kplus = 1.0f + SB_SLACK;
     bf16x8 bq[NQS][8];
     int qi[NQS];
-    float qk[NQS], bestm[NQS];
+    float bestm[NQS];
 #pragma unroll
     for (int j = 0; j < NQS; ++j) {
         qi[j] = ((qgroup * QW + qw) * NQS + j) * 32 + l31;
         load_queries_bf16(q, qi[j], qi[j] < nq, half, bq[j]);
-        qk[j] = qi[j] < nq ? qq[qi[j]] * kplus : 0.0f;
         bestm[j] = -INFINITY;
     }
     // d~ + SLACK (qq + dd) = qk - 2 (<q^,x^> - dd kplus / 2): the lane keeps the MAXIMUM of the bracket (one fma per
@@ -635,15 +682,12 @@ __global__ __launch_bounds__(256, NQS == 2 ? SB_WGS_NQS2 : 3) void search_bound_
 #pragma unroll
         for (int r = 0; r < 16; r += 2) bestm[j] = fmaxf(fmaxf(bestm[j], e[r]), e[r + 1]);
     }, [](int) {});
+    // every (split, row-wave, half) group of a query has ONE writer: the raw maximum of the bracket goes out as it is
+    // (-inf when the group saw no row) and search_thr_pre_kernel folds the groups into the 64 classes -- no atomics, so no
+    // launch in front of this one to initialise them (round 4: the init kernel was 5 us of a 79 us search)
 #pragma unroll
-    for (int j = 0; j < NQS; ++j) {
-        float best = bestm[j] > -INFINITY ? __builtin_fmaf(-2.0f, bestm[j], qk[j]) : INFINITY;
-        best = best < 0.0f ? 0.0f : best;
-        if (qi[j] < nq && best < INFINITY) {
-            const int g = (((split * RW + rw) * 2) + half) & (SR_GROUPS - 1);
-            atomicMin(&gmin[(size_t)qi[j] * SR_GROUPS + g], __float_as_int(best));
-        }
-    }
+    for (int j = 0; j < NQS; ++j)
+        if (qi[j] < nq) gmax[(size_t)qi[j] * ngroups + ((split * RW + rw) * 2 + half)] = bestm[j];
 }
 
 // Hits are rare (a few hundred per query over the whole database) but a returning global atomic costs microseconds,
@@ -1254,11 +1298,44 @@ extern "C" int grafp_f32_to_bf16(const float *src, int64_t n_elems, void *dst, g
     return GRAFP_OK;
 }
 
+namespace grafp {
+// launch plan of the bf16 pre-filter path (shared by the workspace size and the entry)
+struct PrePlan {
+    int qw, rw, nqs, qgroups, b_splits, ngroups;
+    int64_t b_rows, b_rps;
+};
+static PrePlan pre_plan(int64_t n, int nq) {
+    PrePlan p;
+    // measured crossovers (1M x 128): the 1x4 shape only pays for a handful of queries (nq=16: 136 vs 127 us, nq=32:
+    // 168 vs 143 us for the 2x2 shape)
+    p.qw = nq <= 64 ? 2 : 4;                            // (the 1x4 shape went with the 64-row ring stages)
+    p.rw = 4 / p.qw;
+    // two query sets per wave (256 queries per workgroup, two workgroups per CU) from 1024 queries on: every row fragment
+    // read from LDS feeds two independent MFMA chains and a tile's DMA, barrier and loop overhead is shared by twice the
+    // MFMAs (1M x 128, round 4, after the loop's address arithmetic went into immediates: 4096 queries 1.32 -> 1.20 ms,
+    // 2048 0.69 -> 0.645, 1024 0.380 -> 0.365, 512 0.231 -> 0.237; before that the two forms were level)
+    p.nqs = GRAFP_TUNE_INT("GRAFP_SEARCH_NQS", nq >= 1024 ? 2 : 1) == 2 && p.qw == 4 ? 2 : 1;
+    p.qgroups = (nq + 32 * p.qw * p.nqs - 1) / (32 * p.qw * p.nqs);
+    p.b_rows = n / 16 > 65536 ? n / 16 : 65536;
+    if (p.b_rows > n) p.b_rows = n;
+    // pre-pass workgroups: ONE per CU, four or more ring stages each (round 4; 1024 one-tile workgroups paid their prologue
+    // -- the query operand, the ring fill -- for a single tile: 41 queries 0.092 -> 0.079 ms, 1 query 0.080 -> 0.070, no
+    // batch size slower); never fewer than the 64 (split, row-wave, half) groups the threshold kernel selects from
+    int64_t bwant = GRAFP_TUNE_INT("GRAFP_SEARCH_BWANT", 256) / p.qgroups;
+    const int64_t bneed = (32 + p.rw - 1) / p.rw;
+    if (bwant < bneed) bwant = bneed;
+    split_rows(p.b_rows, SB_TR, bwant, &p.b_splits, &p.b_rps);
+    p.ngroups = p.b_splits * p.rw * 2;
+    return p;
+}
+}  // namespace grafp
+
 extern "C" size_t grafp_knn_search_pre_workspace(int64_t n, int nq, int d, int k) {
     using namespace grafp;
     if (n <= 0 || nq <= 0 || d != SR_D || k < 1) return 0;
+    const PrePlan p = pre_plan(n, nq);
     return align256((size_t)nq * sizeof(float)) * 2 + align256((size_t)nq * SR_NSUB * sizeof(int)) +
-           align256((size_t)nq * SR_GROUPS * sizeof(int)) + align256((size_t)nq * SR_CAP * sizeof(int)) +
+           align256((size_t)nq * p.ngroups * sizeof(float)) + align256((size_t)nq * SR_CAP * sizeof(int)) +
            align256((size_t)nq * SR_CAP * sizeof(float));
 }
 
@@ -1278,17 +1355,11 @@ extern "C" int grafp_knn_search_l2_pre(const float *db, const void *db_bf16, con
         return GRAFP_ERR_WORKSPACE;
     }
     hipStream_t s = (hipStream_t)stream;
-    // measured crossovers (1M x 128): the 1x4 shape only pays for a handful of queries (nq=16: 136 vs 127 us, nq=32:
-    // 168 vs 143 us for the 2x2 shape)
-    const int qw = nq <= 64 ? 2 : 4, rw = 4 / qw;      // (the 1x4 shape went with the 64-row ring stages)
-    // two query sets per wave (256 queries per workgroup, two workgroups per CU) from 1024 queries on: every row fragment
-    // read from LDS feeds two independent MFMA chains and a tile's DMA, barrier and loop overhead is shared by twice the
-    // MFMAs (1M x 128, round 4, after the loop's address arithmetic went into immediates: 4096 queries 1.32 -> 1.20 ms,
-    // 2048 0.69 -> 0.645, 1024 0.380 -> 0.365, 512 0.231 -> 0.237; before that the two forms were level)
-    const int nqs = GRAFP_TUNE_INT("GRAFP_SEARCH_NQS", nq >= 1024 ? 2 : 1) == 2 && qw == 4 ? 2 : 1;
-    const int qgroups = (nq + 32 * qw * nqs - 1) / (32 * qw * nqs);
-    int splits, b_splits;
-    int64_t rps, b_rps;
+    const PrePlan pl = pre_plan(n, nq);
+    const int qw = pl.qw, nqs = pl.nqs, qgroups = pl.qgroups, b_splits = pl.b_splits;
+    const int64_t b_rows = pl.b_rows, b_rps = pl.b_rps;
+    int splits;
+    int64_t rps;
     int64_t want = (nqs == 2 ? 256 * SB_WGS_NQS2 : 768) / qgroups;
     if (want < 1) want = 1;
     // Large batches scan in two parts.  The pre-pass bound (k-th smallest of 64 group minima over n/16 rows) lets a few
@@ -1307,31 +1378,21 @@ extern "C" int grafp_knn_search_l2_pre(const float *db, const void *db_bf16, con
     int64_t a_rps = SB_TR;
     if (n_first > 0) split_rows(n_first, SB_TR, want, &a_splits, &a_rps);
     split_rows(n - n_first, SB_TR, want, &splits, &rps);
-    int64_t b_rows = n / 16 > 65536 ? n / 16 : 65536;
-    if (b_rows > n) b_rows = n;
-    // pre-pass workgroups: ONE per CU, four or more ring stages each (round 4; 1024 one-tile workgroups paid their prologue
-    // -- the query operand, the ring fill -- for a single tile: 41 queries 0.092 -> 0.079 ms, 1 query 0.080 -> 0.070, no
-    // batch size slower); never fewer than the 64 (split, row-wave, half) groups the threshold kernel selects from
-    int64_t bwant = GRAFP_TUNE_INT("GRAFP_SEARCH_BWANT", 256) / qgroups;
-    const int64_t bneed = (32 + rw - 1) / rw;
-    if (bwant < bneed) bwant = bneed;
-    split_rows(b_rows, SB_TR, bwant, &b_splits, &b_rps);
     char *w = (char *)ws;
     float *qq = (float *)w;                 w += align256((size_t)nq * sizeof(float));
     float *thr = (float *)w;                w += align256((size_t)nq * sizeof(float));
     int *cnt = (int *)w;                    w += align256((size_t)nq * SR_NSUB * sizeof(int));
-    int *gmin = (int *)w;                   w += align256((size_t)nq * SR_GROUPS * sizeof(int));
+    float *gmax = (float *)w;               w += align256((size_t)nq * pl.ngroups * sizeof(float));
     int *cand_i = (int *)w;                 w += align256((size_t)nq * SR_CAP * sizeof(int));
     float *cand_e = (float *)w;
-    const int64_t ng = (int64_t)nq * SR_GROUPS;
-    hipLaunchKernelGGL(search_init_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, s, q, nq, qq, gmin, cnt);
     const size_t lds = (size_t)SB_NS * SB_STAGE;
     const dim3 grid_b(b_splits, qgroups), grid_a(a_splits, qgroups), grid(splits, qgroups);
     const unsigned short *dbh = (const unsigned short *)db_bf16;
 #define SB_LAUNCH(QW, NQS)                                                                                          \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(search_bound_bf16_kernel<QW, NQS>), grid_b, dim3(256), lds, s, dbh,          \
-                       db_sqnorm, b_rows, q, (const float *)qq, nq, b_rps, gmin);                                   \
-    hipLaunchKernelGGL(search_thr_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, (const int *)gmin, nq, k, thr);      \
+                       db_sqnorm, b_rows, q, nq, b_rps, gmax, pl.ngroups);                                          \
+    hipLaunchKernelGGL(search_thr_pre_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, q, nq, (const float *)gmax,      \
+                       pl.ngroups, k, qq, thr, cnt);                                                                \
     if (n_first > 0) {                                                                                              \
         hipLaunchKernelGGL(HIP_KERNEL_NAME(search_scan_bf16_kernel<QW, NQS>), grid_a, dim3(256), lds, s, dbh,       \
                            db_sqnorm, (int64_t)0, n_first, q, (const float *)qq, nq, a_rps, (const float *)thr,     \
@@ -1358,6 +1419,7 @@ extern "C" int grafp_knn_search_l2_pre(const float *db, const void *db_bf16, con
 // measurement builds only (tools/search_abl.py): the pre-pass loop over ALL n rows with parts of it removed
 extern "C" int grafp_measure_search_loop(const void *db_bf16, const float *db_sqnorm, int64_t n, const float *q,
                                          const float *qq, int nq, int abl, int nqs, int *gmin, grafp_stream_t stream) {
+    (void)qq;
     using namespace grafp;
     const int qgroups = (nq + 128 * nqs - 1) / (128 * nqs);
     int splits;
@@ -1372,10 +1434,10 @@ extern "C" int grafp_measure_search_loop(const void *db_bf16, const float *db_sq
     case A:                                                                                                         \
         if (nqs == 2)                                                                                               \
             hipLaunchKernelGGL(HIP_KERNEL_NAME(search_bound_bf16_kernel<4, 2, A>), grid, dim3(256), lds, s, dbh,    \
-                               db_sqnorm, n, q, qq, nq, rps, gmin);                                                 \
+                               db_sqnorm, n, q, nq, rps, (float *)gmin, 2 * splits);                                \
         else                                                                                                        \
             hipLaunchKernelGGL(HIP_KERNEL_NAME(search_bound_bf16_kernel<4, 1, A>), grid, dim3(256), lds, s, dbh,    \
-                               db_sqnorm, n, q, qq, nq, rps, gmin);                                                 \
+                               db_sqnorm, n, q, nq, rps, (float *)gmin, 2 * splits);                                \
         break
     switch (abl) {
         ABL_CASE(0); ABL_CASE(1); ABL_CASE(2); ABL_CASE(3); ABL_CASE(4); ABL_CASE(8); ABL_CASE(9); ABL_CASE(10);

@@ -26,7 +26,7 @@ def main():
     sq = ops.row_sqnorm(db)
     qq = ops.row_sqnorm(q)
     dbh = ops.rows_to_bf16(db)
-    gmin = torch.full((nq, 64), 0x7f800000, dtype=torch.int32, device=dev)
+    gmin = torch.zeros((nq, 256), dtype=torch.int32, device=dev)      # raw group maxima (floats) land here
     fn = lib.grafp_measure_search_loop
     fn.restype = ctypes.c_int
     fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
