@@ -901,27 +901,58 @@ struct WgReduceTable {
     int S[WG_MULTI], n[WG_MULTI], block_base[WG_MULTI + 1];
     int count;
 };
+// A workgroup takes WG_MULTI_RG groups of 16 consecutive outputs of ONE entry (found by bisection of block_base: the table
+// sits in kernel-argument memory, and the 64-step linear walk of the first version cost every one of a million 16-output
+// workgroups ~2 us -- 1.1 ms per step, more than the 64 launches it replaced).  Per output the order of the sum is that of
+// wgrad_reduce_kernel: 16 split-lanes k = q, q + 16, ..., then the 16 lane sums in lane order.
+constexpr int WG_MULTI_RG = 8;
 __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const WgReduceTable t) {
-    __shared__ float red[16][17];
-    int e = 0;
-    while (e + 1 < t.count && (int)blockIdx.x >= t.block_base[e + 1]) ++e;         // uniform, <= 64 steps
+    __shared__ float red[16][WG_MULTI_RG * 16 + 1];
+    int lo = 0, hi = t.count - 1;                                                  // uniform, <= 6 steps
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if ((int)blockIdx.x >= t.block_base[mid]) lo = mid;
+        else hi = mid - 1;
+    }
+    const int e = lo;
     const float *__restrict__ part = t.part[e];
     const int S = t.S[e];
     const int64_t n = t.n[e];
     const int tid = threadIdx.x, j = tid & 15, q = tid >> 4;
-    const int64_t i = (int64_t)(blockIdx.x - t.block_base[e]) * 16 + j;
-    float s = 0.0f;
-    if (i < n) {
-#pragma unroll 4
-        for (int k = q; k < S; k += 16) s += part[(size_t)k * n + i];
-    }
-    red[q][j] = s;
-    __syncthreads();
-    if (tid < 16 && i < n) {
-        float r = 0.0f;
+    const int64_t i0 = (int64_t)(blockIdx.x - t.block_base[e]) * (16 * WG_MULTI_RG) + j;
+    float s[WG_MULTI_RG];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) r += red[k][tid];
-        t.out[e][i] = r;
+    for (int g = 0; g < WG_MULTI_RG; ++g) s[g] = 0.0f;
+    if (i0 - j + 16 * WG_MULTI_RG <= n) {                  // uniform: every output of the workgroup exists -- plain loads,
+        for (int k = q; k < S; k += 16) {                  // eight in flight per lane
+            const float *row = part + (size_t)k * n + i0;
+            float v[WG_MULTI_RG];
+#pragma unroll
+            for (int g = 0; g < WG_MULTI_RG; ++g) v[g] = row[16 * g];
+#pragma unroll
+            for (int g = 0; g < WG_MULTI_RG; ++g) s[g] += v[g];
+        }
+    } else {                                               // the entry's last workgroup
+        for (int k = q; k < S; k += 16) {
+            const float *row = part + (size_t)k * n;
+#pragma unroll
+            for (int g = 0; g < WG_MULTI_RG; ++g) {
+                const int64_t i = i0 + 16 * g;
+                if (i < n) s[g] += row[i];
+            }
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < WG_MULTI_RG; ++g) red[q][16 * g + j] = s[g];
+    __syncthreads();
+    if (tid < 16 * WG_MULTI_RG) {
+        const int64_t i = (int64_t)(blockIdx.x - t.block_base[e]) * (16 * WG_MULTI_RG) + tid;
+        if (i < n) {
+            float r = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) r += red[k][tid];
+            t.out[e][i] = r;
+        }
     }
 }
 }  // namespace grafp
@@ -942,7 +973,7 @@ extern "C" int grafp_wgrad_reduce_multi(const void *const *parts, const int *n_s
             t.S[e] = n_slices[e0 + e];
             t.n[e] = (int)n_out[e0 + e];
             t.block_base[e] = blocks;
-            blocks += (int)((n_out[e0 + e] + 15) / 16);
+            blocks += (int)((n_out[e0 + e] + 16 * WG_MULTI_RG - 1) / (16 * WG_MULTI_RG));
         }
         t.block_base[t.count] = blocks;
         for (int e = t.count; e < WG_MULTI; ++e) {
