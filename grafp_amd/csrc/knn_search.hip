@@ -23,8 +23,12 @@
 // Roofline: one pass streams n*(512+4) bytes; 2*128 flops per (row, query).  HBM-bound up to ~50
 // queries per pass, f32-matrix-bound (157.3 TFLOP/s) beyond.  See DESIGN.md "search_scan_kernel".
 // The default entry (grafp_knn_search_l2_pre, second half of this file) runs the same pipeline on a bf16 copy of the
-// database with a rigorous rounding margin and rescoring in exact f32: same bits out, 2-5x faster; from 768 queries
-// on its scan runs in two parts with the bound tightened in between.
+// database with a rigorous rounding margin and rescoring in exact f32: same bits out, 2-8x faster.  Its launches
+// (round 4): search_bound_bf16_kernel (pre-pass, raw group maxima, no atomics) -> search_thr_pre_kernel (query norms,
+// empty lists, bound) -> search_scan_bf16_kernel (LDS-DMA ring, bf16 MFMA, one compare per 32 x 32 block; from 768
+// queries on in two parts with search_select_exact_kernel<true> tightening the bound in between; from 1024 queries two
+// query sets per wave) -> search_select_exact_kernel<false> (histogram bound, exact f32 distances of the ~100 rows
+// under it, rank by counting).
 #include <math.h>
 
 #include <type_traits>
@@ -506,16 +510,21 @@ __device__ __forceinline__ void fma16_pk(const float (&hv)[16], float k, const f
 
 // ABL (measurement builds, tools/search_abl.py): bit 0 drops the MFMAs, bit 1 the per-block callback, bit 2 the DMA issue
 // after the prologue, bit 3 the fragment reads -- what the loop costs without each of its parts.
-template <int QW, int NQS, int ABL = 0, typename F, typename G>
+// prepare() runs once, right behind the DMA issue of the first two tiles: the caller loads and converts its query operand
+// there, under the ring fill instead of in front of it (the two latencies added up in every workgroup's prologue).
+template <int QW, int NQS, int ABL = 0, typename P, typename F, typename G>
 __device__ __forceinline__ void stream_tiles_bf16(const unsigned short *__restrict__ dbh, const float *__restrict__ dd,
                                                   int64_t row_begin, int64_t row_end, unsigned char *ring,
-                                                  const bf16x8 (&bq)[NQS][8], F &&on_block, G &&on_tile) {
+                                                  bf16x8 (&bq)[NQS][8], P &&prepare, F &&on_block, G &&on_tile) {
     constexpr int RW = 4 / QW;
     static_assert(SB_TR % (32 * RW) == 0 && SB_TR == 64, "one dword DMA covers the 64 norms of a tile");
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int rw = wave / QW;
     const int ntiles = row_end > row_begin ? (int)((row_end - row_begin + SB_TR - 1) / SB_TR) : 0;
-    if (ntiles == 0) return;
+    if (ntiles == 0) {
+        prepare();
+        return;
+    }
     const int nrows = (int)(row_end - row_begin);
     const unsigned lds0 = (unsigned)(uintptr_t)(gm_lptr)ring;
     const unsigned char *rows = reinterpret_cast<const unsigned char *>(dbh) + row_begin * 256;
@@ -558,6 +567,7 @@ __device__ __forceinline__ void stream_tiles_bf16(const unsigned short *__restri
     };
 #pragma unroll
     for (int t0 = 0; t0 < SB_NS - 1; ++t0) issue(t0 < ntiles ? t0 : ntiles - 1, t0);
+    prepare();
     const unsigned char *frag[8];                     // fragment s2 of block 0 in stage 0, this lane
 #pragma unroll
     for (int s2 = 0; s2 < 8; ++s2) frag[s2] = ring + l31 * 256 + (((2 * s2 + half) ^ (l31 & 15)) << 4);
@@ -626,8 +636,10 @@ __device__ __forceinline__ void stream_tiles_bf16(const unsigned short *__restri
             for (int r = 0; r < 16; ++r) hv[r] = hv4[r >> 2][r & 3];
 #pragma unroll
             for (int j = 0; j < NQS; ++j) {
-                if (ABL & 2) { if (acc[j][0] == 12345.678f && hv[3] == acc[j][5]) on_block(t, RB, j, acc[j], hv); }
-                else on_block(t, RB, j, acc[j], hv);
+                // (last argument: the lane's 16 norms where they stand in LDS -- norm of row mfma_row(r, half) at [8 (r >> 2) + (r & 3)])
+                const float *nb = reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(nrm0) + NOFF);
+                if (ABL & 2) { if (acc[j][0] == 12345.678f && hv[3] == acc[j][5]) on_block(t, RB, j, acc[j], hv, nb); }
+                else on_block(t, RB, j, acc[j], hv, nb);
             }
         };
         // (Also measured and dropped for the two-query-set form: the reads of both blocks in front of the first chain,
@@ -669,14 +681,15 @@ __global__ __launch_bounds__(256, NQS == 2 ? SB_WGS_NQS2 : 3) void search_bound_
 #pragma unroll
     for (int j = 0; j < NQS; ++j) {
         qi[j] = ((qgroup * QW + qw) * NQS + j) * 32 + l31;
-        load_queries_bf16(q, qi[j], qi[j] < nq, half, bq[j]);
         bestm[j] = -INFINITY;
     }
     // d~ + SLACK (qq + dd) = qk - 2 (<q^,x^> - dd kplus / 2): the lane keeps the MAXIMUM of the bracket (one fma per
     // element, maxima three at a time); rows past the end carry NaN and are ignored by fmaxf
     const float nhk = -0.5f * kplus;
-    stream_tiles_bf16<QW, NQS, ABL>(dbh, dd, row_begin, row_end, ring, bq,
-                               [&](int, int, int j, const f32x16 &acc, const float (&hv)[16]) {
+    stream_tiles_bf16<QW, NQS, ABL>(dbh, dd, row_begin, row_end, ring, bq, [&]() {
+#pragma unroll
+        for (int j = 0; j < NQS; ++j) load_queries_bf16(q, qi[j], qi[j] < nq, half, bq[j]);
+    }, [&](int, int, int j, const f32x16 &acc, const float (&hv)[16], const float *) {
         float e[16];
         fma16_pk(hv, nhk, acc, e);
 #pragma unroll
@@ -695,17 +708,18 @@ __global__ __launch_bounds__(256, NQS == 2 ? SB_WGS_NQS2 : 3) void search_bound_
 // The queues are WAVE-PRIVATE: the fill count is a wave-uniform scalar, a hit's slot is count + (hit lanes below this
 // one) from the ballot -- no LDS atomic (its returning round trip was most of the ~650 cycles a block with a hit
 // cost, and every second block holds one), no workgroup barrier around a drain, no shared state at all.
-constexpr int HB_CAP = 96;        // entries per wave: 4 x 96 x 9 B = 3.4 KB; with the 49 KB ring three workgroups fit a CU
+constexpr int HB_CAP = 72;        // entries per wave: 4 x 72 x 13 B = 3.7 KB; with the 49 KB ring three workgroups fit a CU
 
 template <int QW, int NQS>
 __global__ __launch_bounds__(256, NQS == 2 ? SB_WGS_NQS2 : 3) void search_scan_bf16_kernel(
     const unsigned short *__restrict__ dbh, const float *__restrict__ dd, int64_t row0, int64_t n,
     const float *__restrict__ q, const float *__restrict__ qq, int nq, int64_t rows_per_split,
-    const float *__restrict__ thr, int *__restrict__ cnt, int *__restrict__ cand_i, float *__restrict__ cand_e) {
+    const float *__restrict__ thr, int *__restrict__ cnt, int *__restrict__ cand_i, float2 *__restrict__ cand_e) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned char *ring = reinterpret_cast<unsigned char *>(smem);
     __shared__ int hb_row[4][HB_CAP];
     __shared__ float hb_e[4][HB_CAP];
+    __shared__ float hb_d[4][HB_CAP];
     __shared__ unsigned char hb_q[4][HB_CAP];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int qw = wave % QW;
@@ -718,15 +732,10 @@ __global__ __launch_bounds__(256, NQS == 2 ? SB_WGS_NQS2 : 3) void search_scan_b
     const float kminus = 1.0f - SB_SLACK;
     bf16x8 bq[NQS][8];
     float a_q[NQS];
-#pragma unroll
-    for (int j = 0; j < NQS; ++j) {
-        const int qi = qbase + (qw * NQS + j) * 32 + l31;
-        load_queries_bf16(q, qi, qi < nq, half, bq[j]);
-        a_q[j] = qi < nq ? 0.5f * (qq[qi] * kminus - thr[qi]) : INFINITY;
-    }
     const int sub = split & (SR_NSUB - 1);
     int *my_row = hb_row[wave];
     float *my_e = hb_e[wave];
+    float *my_d = hb_d[wave];
     unsigned char *my_q = hb_q[wave];
     int fill = 0;                                             // wave-uniform
     auto drain = [&]() {                                      // this wave's queue -> sub-list `sub` of the queries' lists
@@ -736,13 +745,15 @@ __global__ __launch_bounds__(256, NQS == 2 ? SB_WGS_NQS2 : 3) void search_scan_b
             const int pos = atomicAdd(&cnt[qg * SR_NSUB + sub], 1);
             if (pos < SR_SUBCAP) {                            // beyond: the select kernel sees the count and rescans
                 cand_i[(size_t)qg * SR_CAP + sub * SR_SUBCAP + pos] = my_row[e];
-                cand_e[(size_t)qg * SR_CAP + sub * SR_SUBCAP + pos] = my_e[e];   // E = <q^,x^> - dd kminus / 2
+                // E = <q^,x^> - dd kminus / 2 (bounds d later) and the row's norm (the select kernel's upper bound needs it:
+                // carried along, the select kernel has no gather between its candidate load and its histogram)
+                cand_e[(size_t)qg * SR_CAP + sub * SR_SUBCAP + pos] = make_float2(my_e[e], my_d[e]);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         fill = 0;
     };
-    auto push = [&](bool hit, int row, float ev, int ql) {    // wave-level call
+    auto push = [&](bool hit, int row, float ev, float ddv, int ql) {    // wave-level call
         const unsigned long long mask = __ballot(hit);
         const int add = __popcll(mask);
         if (fill + add > HB_CAP) drain();                     // uniform
@@ -751,6 +762,7 @@ __global__ __launch_bounds__(256, NQS == 2 ? SB_WGS_NQS2 : 3) void search_scan_b
         if (hit) {
             my_row[slot] = row;
             my_e[slot] = ev;
+            my_d[slot] = ddv;
             my_q[slot] = (unsigned char)ql;
         }
         fill += add;
@@ -759,8 +771,14 @@ __global__ __launch_bounds__(256, NQS == 2 ? SB_WGS_NQS2 : 3) void search_scan_b
     // keep iff <q^,x^> - H_row >= A_q.  Common case: 16 fmas, their maximum three at a time (NaN past the end of the
     // slice drops out of fmaxf), ONE compare and one branch per block -- no per-element lane masks, whose 16 dependent
     // scalar ORs behind 16 VALU compares cost as much as the MFMA chain itself.
-    stream_tiles_bf16<QW, NQS>(dbh, dd, row_begin, row_end, ring, bq,
-                               [&](int t, int rb, int j, const f32x16 &acc, const float (&hv)[16]) {
+    stream_tiles_bf16<QW, NQS>(dbh, dd, row_begin, row_end, ring, bq, [&]() {
+#pragma unroll
+        for (int j = 0; j < NQS; ++j) {
+            const int qi = qbase + (qw * NQS + j) * 32 + l31;
+            load_queries_bf16(q, qi, qi < nq, half, bq[j]);
+            a_q[j] = qi < nq ? 0.5f * (qq[qi] * kminus - thr[qi]) : INFINITY;
+        }
+    }, [&](int t, int rb, int j, const f32x16 &acc, const float (&hv)[16], const float *nb) {
         float e[16];
         fma16_pk(hv, -hs, acc, e);
         float m = fmaxf(e[0], e[1]);
@@ -778,12 +796,13 @@ __global__ __launch_bounds__(256, NQS == 2 ? SB_WGS_NQS2 : 3) void search_scan_b
             const int ql = (qw * NQS + j) * 32 + l31;                 // < 256: fits the queue's byte
             const bool single = (bits & (bits - 1)) == 0;
             const int r0 = bits ? __builtin_ctz(bits) : 0;            // row mfma_row(r, half) of the block
-            push(bits != 0 && single, slab0 + (r0 & 3) + 8 * (r0 >> 2), m, ql);
+            const int off0 = (r0 & 3) + 8 * (r0 >> 2);
+            push(bits != 0 && single, slab0 + off0, m, nb[off0], ql);  // (the norm: one LDS read at the lane's own index)
             if (__ballot(!single) != 0) {                             // several hits in one lane's 16 rows: rare
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const bool h = !single && ((bits >> r) & 1);
-                    if (__ballot(h) != 0) push(h, slab0 + (r & 3) + 8 * (r >> 2), e[r], ql);
+                    if (__ballot(h) != 0) push(h, slab0 + (r & 3) + 8 * (r >> 2), e[r], hv[r], ql);
                 }
             }
         }
@@ -810,7 +829,7 @@ __global__ __launch_bounds__(256, 4) void search_select_exact_kernel(const float
                                                                   int64_t id_base, float *__restrict__ thr,
                                                                   const int *__restrict__ cnt,
                                                                   const int *__restrict__ cand_i,
-                                                                  const float *__restrict__ cand_e,
+                                                                  const float2 *__restrict__ cand_e,
                                                                   float *__restrict__ out_d,
                                                                   int64_t *__restrict__ out_i) {
     __shared__ float pend_d[4][WT_PEND];
@@ -825,15 +844,19 @@ __global__ __launch_bounds__(256, 4) void search_select_exact_kernel(const float
     if (tid < SR_D) sq[tid] = q[(size_t)qi * SR_D + tid];
     __shared__ int s_off[SR_NSUB + 1];
     const float myqq = qq[qi];
-    if (tid == 0) {                                        // sub-list fills -> offsets of a flat candidate index
-        int acc_n = 0, over = 0;
-        for (int s2 = 0; s2 < SR_NSUB; ++s2) {
-            const int cs = cnt[qi * SR_NSUB + s2];
-            over |= cs > SR_SUBCAP;
-            s_off[s2] = acc_n;
-            acc_n += cs < SR_SUBCAP ? cs : SR_SUBCAP;
+    if (wave == 0) {                                       // sub-list fills -> offsets of a flat candidate index
+        const int cs = lane < SR_NSUB ? cnt[qi * SR_NSUB + lane] : 0;      // (one load per lane, a 16-lane prefix sum)
+        const bool over = cs > SR_SUBCAP;
+        const int v = over ? SR_SUBCAP : cs;
+        int inc = v;
+#pragma unroll
+        for (int j = 1; j < SR_NSUB; j <<= 1) {
+            const int o = __shfl_up(inc, j);
+            if (lane >= j) inc += o;
         }
-        s_off[SR_NSUB] = over ? -1 : acc_n;
+        const bool any_over = __ballot(over) != 0;
+        if (lane < SR_NSUB) s_off[lane] = inc - v;
+        if (lane == SR_NSUB - 1) s_off[SR_NSUB] = any_over ? -1 : inc;
     }
     __syncthreads();
     const int c = s_off[SR_NSUB];
@@ -889,15 +912,16 @@ __global__ __launch_bounds__(256, 4) void search_select_exact_kernel(const float
         for (int u = 0; u < SF_PER; ++u) {                 // every load of a kind in flight at once; the rounds past the
             row[u] = 0;                                    // end of the list (u * 256 >= c: uniform) load nothing
             ev[u] = 0.0f;
+            ddv[u] = 0.0f;
             if (u * 256 < c) {
                 const int e = u * 256 + tid;
                 const size_t sl = (size_t)qi * SR_CAP + slot_of(e < c ? e : c - 1);
                 row[u] = cand_i[sl];
-                ev[u] = cand_e[sl];
+                const float2 ed = cand_e[sl];
+                ev[u] = ed.x;
+                ddv[u] = ed.y;                             // the row's norm rides with the candidate: no gather here
             }
         }
-#pragma unroll
-        for (int u = 0; u < SF_PER; ++u) ddv[u] = u * 256 < c ? dd[row[u]] : 0.0f;
         float mn = INFINITY, mx = -INFINITY;
 #pragma unroll
         for (int u = 0; u < SF_PER; ++u) {
@@ -1014,7 +1038,7 @@ __global__ __launch_bounds__(256, 4) void search_select_exact_kernel(const float
                 const int e = e0 + u * 256 + tid;
                 const size_t sl = (size_t)qi * SR_CAP + slot_of(e < c ? e : c - 1);
                 row[u] = cand_i[sl];
-                ev[u] = cand_e[sl];
+                ev[u] = cand_e[sl].x;
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) ddv[u] = dd[row[u]];
@@ -1055,7 +1079,7 @@ __global__ __launch_bounds__(256, 4) void search_select_exact_kernel(const float
                 const int e = e0 + u * 256 + tid;
                 const size_t sl = (size_t)qi * SR_CAP + slot_of(e < c ? e : c - 1);
                 row[u] = cand_i[sl];
-                ev[u] = cand_e[sl];
+                ev[u] = cand_e[sl].x;
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
@@ -1336,7 +1360,7 @@ extern "C" size_t grafp_knn_search_pre_workspace(int64_t n, int nq, int d, int k
     const PrePlan p = pre_plan(n, nq);
     return align256((size_t)nq * sizeof(float)) * 2 + align256((size_t)nq * SR_NSUB * sizeof(int)) +
            align256((size_t)nq * p.ngroups * sizeof(float)) + align256((size_t)nq * SR_CAP * sizeof(int)) +
-           align256((size_t)nq * SR_CAP * sizeof(float));
+           align256((size_t)nq * SR_CAP * sizeof(float2));
 }
 
 extern "C" int grafp_knn_search_l2_pre(const float *db, const void *db_bf16, const float *db_sqnorm, int64_t n,
@@ -1360,7 +1384,7 @@ extern "C" int grafp_knn_search_l2_pre(const float *db, const void *db_bf16, con
     const int64_t b_rows = pl.b_rows, b_rps = pl.b_rps;
     int splits;
     int64_t rps;
-    int64_t want = (nqs == 2 ? 256 * SB_WGS_NQS2 : 768) / qgroups;
+    int64_t want = GRAFP_TUNE_INT("GRAFP_SEARCH_WANT", nqs == 2 ? 256 * SB_WGS_NQS2 : 768) / qgroups;
     if (want < 1) want = 1;
     // Large batches scan in two parts.  The pre-pass bound (k-th smallest of 64 group minima over n/16 rows) lets a few
     // hundred rows per query through; the first n/4 rows are scanned with it, the k-th smallest UPPER bound among their
@@ -1384,7 +1408,7 @@ extern "C" int grafp_knn_search_l2_pre(const float *db, const void *db_bf16, con
     int *cnt = (int *)w;                    w += align256((size_t)nq * SR_NSUB * sizeof(int));
     float *gmax = (float *)w;               w += align256((size_t)nq * pl.ngroups * sizeof(float));
     int *cand_i = (int *)w;                 w += align256((size_t)nq * SR_CAP * sizeof(int));
-    float *cand_e = (float *)w;
+    float2 *cand_e = (float2 *)w;
     const size_t lds = (size_t)SB_NS * SB_STAGE;
     const dim3 grid_b(b_splits, qgroups), grid_a(a_splits, qgroups), grid(splits, qgroups);
     const unsigned short *dbh = (const unsigned short *)db_bf16;
@@ -1399,7 +1423,7 @@ extern "C" int grafp_knn_search_l2_pre(const float *db, const void *db_bf16, con
                            cnt, cand_i, cand_e);                                                                    \
         hipLaunchKernelGGL(search_select_exact_kernel<true>, dim3(nq), dim3(256), 0, s, db, db_sqnorm, n, q,        \
                            (const float *)qq, nq, k, id_base, thr, (const int *)cnt, (const int *)cand_i,           \
-                           (const float *)cand_e, out_dist, out_ids);                                               \
+                           (const float2 *)cand_e, out_dist, out_ids);                                               \
     }                                                                                                               \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(search_scan_bf16_kernel<QW, NQS>), grid, dim3(256), lds, s, dbh, db_sqnorm,  \
                        n_first, n, q, (const float *)qq, nq, rps, (const float *)thr, cnt, cand_i, cand_e)
@@ -1410,7 +1434,7 @@ extern "C" int grafp_knn_search_l2_pre(const float *db, const void *db_bf16, con
     GRAFP_CHECK_LAUNCH("search_bound_bf16_kernel / search_scan_bf16_kernel");
     hipLaunchKernelGGL(search_select_exact_kernel<false>, dim3(nq), dim3(256), 0, s, db, db_sqnorm, n, q,
                        (const float *)qq, nq, k, id_base, thr, (const int *)cnt, (const int *)cand_i,
-                       (const float *)cand_e, out_dist, out_ids);
+                       (const float2 *)cand_e, out_dist, out_ids);
     GRAFP_CHECK_LAUNCH("search_select_exact_kernel");
     return GRAFP_OK;
 }
