@@ -1123,6 +1123,35 @@ def test_ivfpq_index_vs_oracle_and_exact(dev):
     assert idx.rows().shape == (n, d) and idx.ntotal == n
 
 
+@pytest.mark.parametrize("d,M,nlist,n", [(64, 64, 8, 1500), (32, 8, 5, 900), (128, 16, 3, 100), (16, 16, 70, 400)])
+def test_ivfpq_other_shapes_vs_c_oracle(dev, d, M, nlist, n):
+    """Sub-space widths 1 / 4 / 8 (the table and scan templates), M not a multiple of 16 (byte-wise code reads), fewer
+    training rows than codewords (repeated seeds, empty clusters keep their centroid), more lists than a wave has lanes:
+    quantisers, codes, probes and search results bit-equal to oracle/csrc/ivfpq.c."""
+    from grafp_amd.ivfpq import IVFPQIndex, kmeans_init_rows
+    from oracle import native
+    rng = np.random.RandomState(d + M)
+    x = rng.randn(n, d).astype(np.float32)
+    idx = IVFPQIndex(d, nlist=nlist, M=M, niter=3)
+    idx.train(x)
+    cent = native.kmeans(x, 1, nlist, kmeans_init_rows(n, nlist, idx.seed).numpy(), 3)[0]
+    a = native.pq_assign(x, 1, cent[None])[:, 0]
+    books = native.kmeans(x, M, 256, kmeans_init_rows(n, 256, idx.seed + 2).numpy(), 3, base=cent, base_idx=a)
+    assert np.array_equal(idx.centroids.cpu().numpy(), cent) and np.array_equal(idx.codebooks.cpu().numpy(), books)
+    idx.add(x)
+    codes = native.pq_assign(x, M, books, base=cent, base_idx=a).astype(np.uint8)
+    assert np.array_equal(torch.cat(idx._codes).cpu().numpy(), codes)
+    nprobe = min(nlist, 4)
+    idx.nprobe = nprobe
+    q = (x[:23] + 0.02 * rng.randn(23, d)).astype(np.float32)
+    D, I = idx.search(q, 9)
+    order = np.argsort(a, kind="stable")
+    start = np.r_[0, np.cumsum(np.bincount(a, minlength=nlist))]
+    probe = native.ivfpq_probe(q, cent, nprobe)
+    Dc, Ic = native.ivfpq_search(q, cent, books, codes[order], start, order, probe, 9)
+    assert np.array_equal(I, Ic) and np.array_equal(D, Dc)
+
+
 def test_ivfpq_dense_scan_agrees_with_the_fused_search(dev):
     """grafp_ivfpq_scan_f32 (every estimate of the probed lists out, the round-1 form) followed by a host-side selection
     gives the fused kernel's results: the two share the table and the order of the sub-space sum."""
