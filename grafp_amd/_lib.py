@@ -30,7 +30,8 @@ SIGNATURES = {
     "grafp_logmel_f32": (_I, [_P, _L, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "grafp_unfold_segments_f32": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "grafp_peak_extract_fwd_f32": (_I, [_P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
-    "grafp_peak_extract_bwd_f32": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "grafp_peak_extract_bwd_f32": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "grafp_peak_extract_bwd_workspace": (_Z, [_I, _I, _I, _I]),
     "grafp_knn_graph_workspace": (_Z, [_I, _I, _I]),
     "grafp_knn_normalize_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
     "grafp_knn_topk_f32": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),

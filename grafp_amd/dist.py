@@ -96,6 +96,10 @@ class GradSync:
             raise ValueError("no trainable parameters")
         dev, total = self.params[0].device, sum(p.numel() for p in self.params)
         self.world = world_size(group)
+        # collectives are issued whenever there is something to reduce -- and also on a ONE-rank process group when the
+        # caller forces the flat layout (the one-GPU tests of the data-parallel graph step: the RCCL all-reduce of every
+        # bucket then really runs between the replayed backward graphs, on the shared memory pool, as it does at N > 1)
+        self._reduce = self.world > 1 or (force_flat and dist.is_available() and dist.is_initialized())
         self.flat = None
         if self.world == 1 and not force_flat:
             # nothing to reduce: let autograd ASSIGN fresh gradients (zero() drops them) instead of launching one
@@ -213,7 +217,7 @@ class GradSync:
     def _launch(self, b):
         self._pack(b)
         lo, hi = self.bounds[b]
-        if self.world > 1:
+        if self._reduce:
             self._handles.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group,
                                                  async_op=True))
         self._fired[b] = True
@@ -261,7 +265,7 @@ class GradSync:
         """Launch (do not wait for) the all-reduce of the given buckets' slices of the flat buffer: the replay side of
         begin_capture(), called right after the graph that packed them was enqueued.  RCCL orders the collective behind
         everything enqueued on the current stream so far and runs it on its own stream, under whatever is enqueued next."""
-        if self.world > 1:
+        if self._reduce:
             for b in buckets:
                 lo, hi = self.bounds[b]
                 self._handles.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group,
@@ -304,7 +308,7 @@ class GradSync:
         view of the reduced buffer.  No autograd involvement: the eager piece between two replayed graphs."""
         if self.flat is None:
             return
-        if self.world > 1:
+        if self._reduce:
             hs = [dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
                   for lo, hi in self.bounds]
             for h in hs:

@@ -266,12 +266,15 @@ class _PeakExtract(torch.autograd.Function):
         spec, out = ctx.saved_tensors
         B, H, W, F, KH, KW, stride_h = ctx.geom
         g = _f32c(grad_out)
-        dw = torch.zeros((F, 3, KH, KW), dtype=torch.float32, device=spec.device)
-        db = torch.zeros((F,), dtype=torch.float32, device=spec.device)
+        dw = torch.empty((F, 3, KH, KW), dtype=torch.float32, device=spec.device)
+        db = torch.empty((F,), dtype=torch.float32, device=spec.device)
         t_ramp, f_ramp = _ramps(spec.device, H, W)
+        nbytes = lib.grafp_peak_extract_bwd_workspace(B, F, KH, KW)
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=spec.device)      # per-workgroup partial sums
         with _timed("peak_extract_bwd", (B,)):
             check(lib.grafp_peak_extract_bwd_f32(_p(spec), B, H, W, F, KH, KW, stride_h, _p(t_ramp), _p(f_ramp),
-                                                 _p(out), _p(g), _p(dw), _p(db), _stream()), "peak_extract_bwd")
+                                                 _p(out), _p(g), _p(dw), _p(db), _p(ws), nbytes, _stream()),
+                  "peak_extract_bwd")
         return None, dw, db, None
 
 
@@ -769,6 +772,39 @@ def gemm_supported(R, K, groups, M, views=1):
     return bool(lib.grafp_conv1x1_gemm_supported(int(R), int(K), int(groups), int(M), int(views)))
 
 
+_XL_CHECKED = set()
+
+
+def _xl_selfcheck(device):
+    """Once per process and device, at the first product: the four-wave tile (gemm_xl.h) keeps its accumulators in AGPRs it
+    NAMES in asm text.  The build checks the generated code for that contract (Makefile -> tools/check_kernel_regs.py);
+    this checks the RESULT: one product the plan sends to that tile, against the same product through the eight-wave tile
+    (the identity-affine epilogue form runs on GemmL with the same grid).  A mismatch raises -- there is no fallback."""
+    key = (device.type, device.index)
+    if key in _XL_CHECKED or torch.cuda.is_current_stream_capturing():
+        return
+    _XL_CHECKED.add(key)
+    R, K, M = 256, 512, 4096
+    info = (ctypes.c_int * 16)()
+    lib.grafp_conv1x1_gemm_plan(R, K, 1, M, 1, info)
+    g = torch.Generator(device="cpu").manual_seed(0)
+    w = (torch.randn(R, K, generator=g) / K ** 0.5).to(device, torch.bfloat16)
+    x = torch.randn(K, M, generator=g).to(device, torch.bfloat16)
+    tab = torch.tensor([1.0, 0.0], device=device).repeat(R, 1, 1).contiguous()            # (R, views = 1, 2): identity
+    y, z = torch.empty((R, M), dtype=torch.bfloat16, device=device), torch.empty((R, M), dtype=torch.bfloat16, device=device)
+    check(lib.grafp_conv1x1_gemm_bf16(_p(w), _p(x), R, K, 1, M, 1, None, 0, 0.0, _p(y), None, _stream()), "conv1x1_gemm")
+    check(lib.grafp_conv1x1_gemm_affine_bf16(_p(w), _p(x), R, K, 1, M, 1, _p(tab), 0, 0.0, _p(z), _stream()),
+          "conv1x1_gemm_affine")
+    yf, zf = y.float(), z.float()
+    # (the two tiles may add the K chunks in another association: equal up to one bf16 rounding step on a few elements)
+    wrong = bool(((yf - zf).abs() > zf.abs() * 2.0 ** -7 + float(zf.abs().max()) * 2.0 ** -15).any())
+    if wrong or not bool(torch.isfinite(yf).all()) or float((yf != zf).float().mean()) > 5e-3:
+        bad = float((yf - zf).abs().max())
+        raise RuntimeError(f"libgrafp_hip: the four-wave GEMM tile disagrees with the eight-wave tile on a {R}x{K}x{M} product "
+                           f"(max |diff| {bad}): this build broke the register contract of gemm_xl.h -- rebuild with the "
+                           "pinned toolchain (`make -C grafp_amd/csrc` runs tools/check_kernel_regs.py)")
+
+
 def conv1x1_gemm(w, x, groups=1, views=1, pro_tab=None, pro_act=ACT_NONE, pro_slope=0.0, stats=False):
     """y = W f(x): w (R, K/groups) bf16, x (K, M) bf16 rows -> y (R, M) bf16 [, partial statistics (R, views, P, 3) f32].
     pro_tab (K, views, 2) f32: f(x) = act(x * scale + shift) applied to the operand tile on the fly (the BatchNorm +
@@ -776,6 +812,7 @@ def conv1x1_gemm(w, x, groups=1, views=1, pro_tab=None, pro_act=ACT_NONE, pro_sl
     _require_gpu(w, x)
     if w.dtype != torch.bfloat16 or x.dtype != torch.bfloat16:
         raise TypeError("conv1x1_gemm: bf16 operands")
+    _xl_selfcheck(x.device)
     w, x = w.contiguous(), x.contiguous()
     R, K, M = w.shape[0], x.shape[0], x.shape[1]
     if w.shape[1] * groups != K:

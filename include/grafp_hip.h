@@ -72,14 +72,17 @@ int grafp_unfold_segments_f32(const float *spec, int n_mels, int n_frames, int s
  * [T-ramp, F-ramp, spec] stack, Conv2d(3 -> F, (KH,KW), stride (sh,1), pad (KH/2,KW/2)) + ReLU, flatten.
  *   spec (B,H,W)  weight (F,3,KH,KW)  bias (F)  out (B,F,Ho*W), Ho = (H + 2*(KH/2) - KH)/sh + 1
  *   t_ramp (W) = linspace(0,1,W), f_ramp (H) = linspace(0,1,H)   (peak_extractor.py:36-42), KH, KW odd
- * Backward (spec carries no gradient, train.py:66-67): dweight/dbias are ACCUMULATED into (the caller
- * zeroes them); `out` is the forward result (ReLU mask). */
+ * Backward (spec carries no gradient, train.py:66-67): dweight (F,3,KH,KW) / dbias (F) are WRITTEN (not accumulated
+ * into); `out` is the forward result (ReLU mask).  Bit-reproducible: per-workgroup partial sums in the workspace
+ * (grafp_peak_extract_bwd_workspace bytes), added in workgroup order by a second launch -- no float atomics. */
 int grafp_peak_extract_fwd_f32(const float *spec, int B, int H, int W, const float *weight, const float *bias,
                                int F, int KH, int KW, int stride_h, const float *t_ramp, const float *f_ramp,
                                float *out, grafp_stream_t stream);
 int grafp_peak_extract_bwd_f32(const float *spec, int B, int H, int W, int F, int KH, int KW, int stride_h,
                                const float *t_ramp, const float *f_ramp, const float *out, const float *grad_out,
-                               float *dweight, float *dbias, grafp_stream_t stream);
+                               float *dweight, float *dbias, void *workspace, size_t workspace_bytes,
+                               grafp_stream_t stream);
+size_t grafp_peak_extract_bwd_workspace(int B, int F, int KH, int KW);
 
 /* ---- K3-K5: dynamic k-NN graph ---------------------------------------------------------------
  * Replaces DenseDilatedKnnGraph.forward (encoder/gcn_lib/torch_edge.py:270-284, y=None, dilation 1):

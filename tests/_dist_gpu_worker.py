@@ -86,6 +86,15 @@ def graph_mode(out, B, rccl_one_rank=False, overlap=True, timeline=False):
                 for k, v in sv.items():
                     st[k].copy_(v)
 
+    # count the collectives a replayed step really issues (at one rank reduce_buckets() used to issue none)
+    calls = {"all_reduce": 0}
+    orig_all_reduce = torch.distributed.all_reduce
+
+    def counted_all_reduce(*a, **k):
+        calls["all_reduce"] += 1
+        return orig_all_reduce(*a, **k)
+    torch.distributed.all_reduce = counted_all_reduce
+
     res = []
     for seed in (51, 52):
         y_i, y_j = synthetic_batch(B, seed, device)
@@ -94,12 +103,14 @@ def graph_mode(out, B, rccl_one_rank=False, overlap=True, timeline=False):
         p_e = torch.cat([p.detach().flatten() for p in model.parameters()]).clone()
         restore(snap)
         marks.append([])
+        calls["all_reduce"] = 0
         loss_g = float(tr.step_graph(y_i[sl], y_j[sl]))
+        n_allreduce = calls["all_reduce"]
         p_g = torch.cat([p.detach().flatten() for p in model.parameters()]).clone()
         p_0 = torch.cat([v.flatten() for v in snap[0]])
         res.append({"loss_e": loss_e, "loss_g": loss_g, "d_e": float((p_e - p_0).norm()),
                     "d_diff": float((p_g - p_e).norm()), "p_sum": float(p_g.double().sum()), "n_graphs": n_parts + 2,
-                    "bucket_numel": [hi - lo for lo, hi in tr.sync.bounds]})
+                    "n_allreduce": n_allreduce, "bucket_numel": [hi - lo for lo, hi in tr.sync.bounds]})
         if timeline:
             torch.cuda.synchronize()
             end = [e for tag, e in marks[-1] if tag == "end"][0]

@@ -11,6 +11,8 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+    config.addinivalue_line("markers", "statistical: scores briefly trained models (hit rates, free-running drift); "
+                                       "collected LAST so that `-x` never hides a parity test behind it")
 
 
 @pytest.fixture(scope="session")
@@ -18,8 +20,22 @@ def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
 
 
+# Order of a GPU run: kernel parity -> matrix products -> model / training step -> headline sizes -> data parallel ->
+# bf16 bars -> the statistical tests.  Under `-x` a failure then hides only what depends on what failed (one
+# hit-rate assertion, collected first by file name, hid 324 parity tests).
+_FILE_ORDER = ("test_gpu_kernels.py", "test_gpu_gemm.py", "test_gpu_model.py", "test_gpu_repro.py",
+               "test_gpu_headline.py", "test_gpu_dist.py", "test_gpu_bf16_backward.py", "test_gpu_bf16.py")
+
+
+def _rank(item):
+    name = os.path.basename(str(item.fspath))
+    file_rank = _FILE_ORDER.index(name) if name in _FILE_ORDER else -1        # CPU files keep their place in front
+    return (1 if item.get_closest_marker("statistical") is not None else 0, file_rank)
+
+
 def pytest_collection_modifyitems(config, items):
     config._grafp_gpu_selected = any(it.get_closest_marker("gpu") is not None for it in items)
+    items.sort(key=_rank)              # stable: the order inside a file is the order of definition
 
 
 @pytest.fixture(scope="session", autouse=True)

@@ -166,6 +166,9 @@ def test_step_graph_data_parallel_over_rccl_one_rank(tmp_path, mode):
     for step in torch.load(f"{out}.0.pt", weights_only=False):
         assert abs(step["loss_g"] - step["loss_e"]) <= 2e-3 * max(1.0, abs(step["loss_e"])), step
         assert step["d_e"] > 0 and step["d_diff"] < 0.05 * step["d_e"], step
+        # the replayed step really issued one RCCL all-reduce per gradient bucket (a one-rank group reduces too when the
+        # flat layout is forced: GradSync._reduce)
+        assert step["n_allreduce"] == len(step["bucket_numel"]) >= 4, step
 
 
 def test_bucket_all_reduces_are_released_before_backward_ends(tmp_path):
@@ -180,6 +183,7 @@ def test_bucket_all_reduces_are_released_before_backward_ends(tmp_path):
         assert abs(step["loss_g"] - step["loss_e"]) <= 2e-3 * max(1.0, abs(step["loss_e"])), step
         tl = step["ms_before_backward_end"]
         sizes = step["bucket_numel"]
+        assert step["n_allreduce"] == len(sizes), step                    # RCCL all-reduces interleaved with the graphs
         print("graphs per step:", step["n_graphs"], "bucket sizes:", sizes, "markers (buckets, ms before backward's end):", tl)
         assert len(tl) == len(sizes) and [b for b, _ in tl] == [[i] for i in range(len(sizes))]      # in completion order
         assert sizes[-1] <= (1 << 20) < max(sizes)                                      # the tail bucket is the small one

@@ -387,6 +387,34 @@ def test_peak_extract_forward_backward(dev):
         w.grad = None; bias.grad = None
 
 
+@pytest.mark.parametrize("B,F,K,W", [(700, 8, 7, 32), (1300, 8, 7, 32), (37, 4, 5, 16), (600, 4, 5, 16)])
+def test_peak_extract_backward_many_clips_bit_reproducible(dev, B, F, K, W):
+    """More clips than workgroups (512): every workgroup accumulates several clips before its row of partial sums is
+    written, and the second launch adds the rows in workgroup order -- the weight gradient is a fixed f32 expression, so
+    two calls give the SAME bits (it ended in float atomics until round 5: /root/reference/peak_extractor.py:22-30 is the
+    conv whose gradient this is).  Shapes: the model's (8 filters, 7x7, 32 frames: the register-blocked kernel) and
+    another one (the generic kernel)."""
+    from grafp_amd import ops
+    from oracle import model as om
+    spec = t(40.0 * hash_uniform(f"gpu:peak.many.{B}.{W}", (B, 64, W)) - 30.0)
+    w = t(0.1 * hash_normalish(f"gpu:peak.many.w{F}", (F, 3, K, K))).requires_grad_(True)
+    bias = t(0.05 * hash_normalish(f"gpu:peak.many.b{F}", (F,))).requires_grad_(True)
+    want = om.peak_extract({"peak_extractor.convs.0.weight": w, "peak_extractor.convs.0.bias": bias}, spec)
+    g = t(hash_normalish(f"gpu:peak.many.g.{B}.{F}", tuple(want.shape)))
+    want.backward(g)
+    grads = []
+    for _ in range(2):
+        wg = w.detach().to(dev).requires_grad_(True); bg = bias.detach().to(dev).requires_grad_(True)
+        got = ops.peak_extract(spec.to(dev), wg, bg, 2)
+        got.backward(g.to(dev))
+        grads.append((wg.grad.clone(), bg.grad.clone()))
+    np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().numpy(), rtol=1e-4, atol=1e-5)
+    scale = float(w.grad.abs().max())
+    np.testing.assert_allclose(grads[0][0].cpu().numpy(), w.grad.numpy(), rtol=1e-3, atol=2e-5 * scale)
+    np.testing.assert_allclose(grads[0][1].cpu().numpy(), bias.grad.numpy(), rtol=1e-3, atol=2e-5 * float(bias.grad.abs().max()))
+    assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])
+
+
 def test_peak_extract_reference_golden(dev):
     from _hashfill import fill_state_dict
     from grafp_amd import ops

@@ -10,7 +10,10 @@ would give silently wrong weight gradients, so `make check` (and __graft_entry__
 compile wgrad.hip to assembly and verify, for every instantiation:
   * the kernel descriptor allocates 256 VGPRs (so v224-v255 exist), no AGPRs, no scratch, no spills;
   * outside the `;;#ASMSTART ... ;;#ASMEND` blocks no instruction mentions v224 ... v255 (alone or inside a range).
-Usage: check_kernel_regs.py [--hipcc PATH]      (exit status 0 = contract holds)."""
+Usage: check_kernel_regs.py [--hipcc PATH] [--asm-wgrad FILE --asm-gemm FILE] [--measure]   (exit status 0 = contract holds).
+`make -C grafp_amd/csrc` runs it on the assembly of the very flags the objects were built with (the library is not linked
+when it fails); without --asm-* it compiles the two sources itself.  Toolchain the contract was last verified on: the
+hipcc of ROCm 7.2.0 (`hipcc --version`: AMD clang 20) -- any other compiler is checked the same way, not trusted."""
 import argparse
 import os
 import re
@@ -115,14 +118,19 @@ def check_gemm_xl(asm):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--hipcc", default=os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"))
+    ap.add_argument("--asm-wgrad", default=None, help="assembly of wgrad.hip (device only) instead of compiling it here")
+    ap.add_argument("--asm-gemm", default=None, help="assembly of gemm.hip")
+    ap.add_argument("--measure", action="store_true", help="compile with -DGRAFP_MEASURE (the measurement library)")
     args = ap.parse_args()
+    flags = FLAGS + (["-DGRAFP_MEASURE"] if args.measure else [])
     with tempfile.TemporaryDirectory() as tmp:
-        out = os.path.join(tmp, "wgrad.s")
-        res = subprocess.run([args.hipcc] + FLAGS + [os.path.join(CSRC, "wgrad.hip"), "-o", out],
-                             stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-        if res.returncode != 0:
-            print(res.stdout)
-            return 2
+        out = args.asm_wgrad or os.path.join(tmp, "wgrad.s")
+        if not args.asm_wgrad:
+            res = subprocess.run([args.hipcc] + flags + [os.path.join(CSRC, "wgrad.hip"), "-o", out],
+                                 stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            if res.returncode != 0:
+                print(res.stdout)
+                return 2
         asm = open(out).read()
     kernels, errors = check(asm)
     for e in errors:
@@ -130,12 +138,13 @@ def main():
     if not errors:
         print(f"wgrad_gr_kernel register contract holds for {kernels} instantiations")
     with tempfile.TemporaryDirectory() as tmp:
-        out = os.path.join(tmp, "gemm.s")
-        res = subprocess.run([args.hipcc] + FLAGS + [os.path.join(CSRC, "gemm.hip"), "-o", out],
-                             stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-        if res.returncode != 0:
-            print(res.stdout)
-            return 2
+        out = args.asm_gemm or os.path.join(tmp, "gemm.s")
+        if not args.asm_gemm:
+            res = subprocess.run([args.hipcc] + flags + [os.path.join(CSRC, "gemm.hip"), "-o", out],
+                                 stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            if res.returncode != 0:
+                print(res.stdout)
+                return 2
         gemm_asm = open(out).read()
         gk, gerrors = check_gemm_splat(gemm_asm)
         xk, xerrors = check_gemm_xl(gemm_asm)
