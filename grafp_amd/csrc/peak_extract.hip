@@ -252,19 +252,82 @@ __global__ __launch_bounds__(PK_THREADS) void peak_bwd8_kernel(const float *__re
 #pragma unroll
         for (int kx = 0; kx < K; ++kx) acc[f][kx] = f32x2{0.0f, 0.0f};
     }
+    // the zero border of the three planes is written once: the per-clip fill only touches the interior
+    for (int i = tid; i < 3 * HP * WP; i += PK_THREADS) img[i] = 0.0f;
+    const int nv = H * W / 4;                      // float4 pieces of a clip (W = 32: 8 per row)
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
-        __syncthreads();
-        build_image(img, scratch, spec + (size_t)b * H * W, H, W, ph, pw, WP, t_ramp, f_ramp, tid);
+        // every global read of the clip goes out FIRST, 16 bytes per lane: the spectrogram (<= 2 pieces per thread at
+        // H = 64) and, per position quad, the 8 filters' outputs and gradients (16 loads in flight per thread)
+        const f32x4 *sp4 = reinterpret_cast<const f32x4 *>(spec + (size_t)b * H * W);
         const float *ob = out + (size_t)b * F * nPos, *gb = gout + (size_t)b * F * nPos;
-        for (int i = tid; i < 2 * nPos; i += PK_THREADS) {
-            const int fq = i / nPos, p = i - fq * nPos;
-            f32x4 v;
+        f32x4 sv[2];
+        float lo = INFINITY, hi = -INFINITY;
+        if (nv <= 2 * PK_THREADS) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int i = tid + j * PK_THREADS;
+                sv[j] = i < nv ? sp4[i] : f32x4{INFINITY, INFINITY, INFINITY, INFINITY};
+            }
+        }
+        __syncthreads();                           // the previous clip's products are done with img / sgT
+        for (int q = tid; q < nPos / 4; q += PK_THREADS) {
+            f32x4 o4[F], g4[F];
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                o4[f] = *reinterpret_cast<const f32x4 *>(ob + (size_t)f * nPos + 4 * q);
+                g4[f] = *reinterpret_cast<const f32x4 *>(gb + (size_t)f * nPos + 4 * q);
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const size_t o = (size_t)(fq * 4 + e) * nPos + p;
-                v[e] = ob[o] > 0.0f ? gb[o] : 0.0f;
+                f32x4 a, c;
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    a[f] = o4[f][e] > 0.0f ? g4[f][e] : 0.0f;
+                    c[f] = o4[4 + f][e] > 0.0f ? g4[4 + f][e] : 0.0f;
+                }
+                f32x4 *dst = reinterpret_cast<f32x4 *>(sgT + (size_t)(4 * q + e) * F);
+                dst[0] = a;
+                dst[1] = c;
             }
-            *reinterpret_cast<f32x4 *>(sgT + (size_t)p * F + fq * 4) = v;
+        }
+        if (nv <= 2 * PK_THREADS) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                if (tid + j * PK_THREADS < nv)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        lo = fminf(lo, sv[j][e]);
+                        hi = fmaxf(hi, sv[j][e]);
+                    }
+        } else {
+            for (int i = tid; i < nv; i += PK_THREADS) {
+                const f32x4 v = sp4[i];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    lo = fminf(lo, v[e]);
+                    hi = fmaxf(hi, v[e]);
+                }
+            }
+        }
+        lo = block_reduce(lo, false, scratch, tid);
+        hi = block_reduce(hi, true, scratch, tid);
+        const float range = hi - lo;
+        auto fill = [&](int i, const f32x4 &v) {
+            const int y = i / (W / 4), x = (i - y * (W / 4)) * 4;
+            const int o = (y + ph) * WP + x + pw;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                img[o + e] = t_ramp[x + e];
+                img[HP * WP + o + e] = f_ramp[y];
+                img[2 * HP * WP + o + e] = __fdiv_rn(v[e] - lo, range);
+            }
+        };
+        if (nv <= 2 * PK_THREADS) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                if (tid + j * PK_THREADS < nv) fill(tid + j * PK_THREADS, sv[j]);
+        } else {
+            for (int i = tid; i < nv; i += PK_THREADS) fill(i, sp4[i]);
         }
         __syncthreads();
         if (active) {

@@ -408,10 +408,18 @@ def test_peak_extract_backward_many_clips_bit_reproducible(dev, B, F, K, W):
         got = ops.peak_extract(spec.to(dev), wg, bg, 2)
         got.backward(g.to(dev))
         grads.append((wg.grad.clone(), bg.grad.clone()))
-    np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().numpy(), rtol=1e-4, atol=1e-5)
+    got_c = got.detach().cpu()
+    np.testing.assert_allclose(got_c.numpy(), want.detach().numpy(), rtol=1e-4, atol=1e-5)
+    # An output within rounding of zero can have its ReLU decided the other way by the two forward passes (a handful out of
+    # B * F * 1024 outputs); such a position moves all 3 * K * K taps of ITS filter by O(1).  Filters with a flipped mask are
+    # left out of the weight comparison (and there must be few of them); every other filter is compared at f32 accuracy.
+    flipped = ((got_c > 0) != (want.detach() > 0)).reshape(B, F, -1).any(dim=2).any(dim=0)
+    assert int(((got_c > 0) != (want.detach() > 0)).sum()) <= 8 and int(flipped.sum()) <= F // 2, flipped
+    keep = (~flipped).numpy()
     scale = float(w.grad.abs().max())
-    np.testing.assert_allclose(grads[0][0].cpu().numpy(), w.grad.numpy(), rtol=1e-3, atol=2e-5 * scale)
-    np.testing.assert_allclose(grads[0][1].cpu().numpy(), bias.grad.numpy(), rtol=1e-3, atol=2e-5 * float(bias.grad.abs().max()))
+    np.testing.assert_allclose(grads[0][0].cpu().numpy()[keep], w.grad.numpy()[keep], rtol=1e-3, atol=2e-5 * scale)
+    np.testing.assert_allclose(grads[0][1].cpu().numpy()[keep], bias.grad.numpy()[keep], rtol=1e-3,
+                               atol=2e-5 * float(bias.grad.abs().max()))
     assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])
 
 
