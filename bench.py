@@ -633,6 +633,46 @@ def main():
                 except Exception as exc:      # noqa: BLE001 -- report, do not fail the bench line
                     c3["hip_graph_error"] = f"{type(exc).__name__}: {exc}"[:200]
             del t3
+            if not args.no_graph and not dist.is_initialized():
+                # The same 128-pair step in its DATA-PARALLEL form on a ONE-RANK RCCL group (the most a one-GPU box can run):
+                # forward graph -> RCCL all-gather -> one backward graph per gradient bucket with that bucket's RCCL all-reduce
+                # launched behind it -> Adam graph.  Beside it the two collectives alone (the all-gather of the stacked
+                # embeddings and the bucketed all-reduce of the 18.4 M f32 gradients), so that
+                # "graph step + collectives <= budget" can be read off this line.  At one rank RCCL moves no bytes over xGMI:
+                # these are launch + local-copy costs, the floor of what N = 8 adds.
+                try:
+                    import socket
+                    with socket.socket() as sk:
+                        sk.bind(("127.0.0.1", 0))
+                        port = sk.getsockname()[1]
+                    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                            device_id=device)
+                    t4 = Trainer(dict(cfg, bsz_train=B3), model, device, amp_dtype=amp, data_parallel_graphs=True)
+                    t4.step_graph(x3_i, x3_j)
+                    dt, _ = timed_steps(lambda: t4.step_graph(x3_i, x3_j), args.steps, barrier)
+                    c3["dp_graphs_rccl_one_rank_ms_per_step"] = round(1e3 * dt / args.steps, 3)
+                    c3["dp_graphs"] = len(t4._graph[1][1]) + 2
+                    mine = torch.zeros((2, B3, 128), device=device)
+                    gathered = torch.empty_like(mine)
+                    flat, bounds = t4.sync.flat, t4.sync.bounds
+
+                    def collectives_once():
+                        dist.all_gather_into_tensor(gathered, mine)
+                        hs = [dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True) for lo, hi in bounds]
+                        for h in hs:
+                            h.wait()
+                    for _ in range(5):
+                        collectives_once()
+                    dt, _ = timed_steps(collectives_once, 50, barrier)
+                    c3["collectives_alone_rccl_one_rank_ms"] = round(1e3 * dt / 50, 3)
+                    c3["gradient_bucket_bytes"] = [4 * (hi - lo) for lo, hi in bounds]
+                    t4.sync.close()
+                    del t4
+                except Exception as exc:      # noqa: BLE001 -- report, do not fail the bench line
+                    c3["dp_graphs_error"] = f"{type(exc).__name__}: {exc}"[:200]
+                finally:
+                    if dist.is_initialized():
+                        dist.destroy_process_group()
             line["config3_per_gpu_128"] = c3
             # measured parity figures of THIS model and build (numbers, not prose): the free-running distance of the bf16
             # mode from the f32 mode on 256 clip-views (eval mode, random-init weights) -- see tests/test_gpu_bf16.py for
