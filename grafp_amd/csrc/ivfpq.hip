@@ -18,7 +18,9 @@
 //                         once -- a thread owns a code and adds M table entries (one ds_read_b32 each: the bank is set by
 //                         the code byte, random) -- and the estimates go straight into the wave's running top-k (topk.h):
 //                         no (query x probed codes) scratch, no host round trip, ids out;
-//   ivfpq_adc_kernel      the round-1 form of the scan (dense estimates out), kept for k > 32.
+//   ivfpq_adc_kernel      the round-1 form of the scan (dense estimates out; grafp_ivfpq_scan_f32): a caller that wants
+//                         more than GRAFP_SEARCH_MAX_K = 32 results per query selects from it itself (IVFPQIndex.search
+//                         serves k <= 32, what eval.py:122,269 asks for: k_probe = 20).
 // Bound of a search: codes bytes from L2/HBM (M bytes per candidate) + M LDS reads per candidate.
 #include "common.h"
 #include "topk.h"
@@ -77,42 +79,54 @@ __global__ __launch_bounds__(256) void ivfpq_adc_kernel(const float *__restrict_
 // ---- nearest centroid per (row, sub-space) -------------------------------------------------------------------------
 // x (n, D) f32, G sub-spaces of d = D / G dims; optional residual: r = x[row] - base[base_idx[row]] (one rounding), then
 // dist_j = fmaf chain over c of (r_c - cent[g][j][c])^2 -- the same two roundings per term as the search's table.
-// Grid (row blocks, G); the sub-space's k x d centroids sit in LDS, every thread owns a row and reads them as broadcasts.
+// Grid (row blocks, G); the sub-space's centroids pass through LDS (all k x d of them when they fit 64 KB, otherwise kb at
+// a time: IndexIVFPQ with 512 or 1024 lists at d = 128), every thread owns a row and reads them as broadcasts.
 template <int DCAP>
 __global__ __launch_bounds__(256) void pq_assign_kernel(const float *__restrict__ x, int64_t n, int D, int G,
                                                         const float *__restrict__ base,
                                                         const int32_t *__restrict__ base_idx,
-                                                        const float *__restrict__ cent, int k,
+                                                        const float *__restrict__ cent, int k, int kb,
                                                         int32_t *__restrict__ out, uint8_t *__restrict__ out_u8) {
-    extern __shared__ __attribute__((aligned(16))) float sc[];             // k x d
+    extern __shared__ __attribute__((aligned(16))) float sc[];             // kb x d: one tile of the centroids at a time
     const int d = D / G, g = blockIdx.y, tid = threadIdx.x;
     const float *cg = cent + (size_t)g * k * d;
-    for (int i = tid; i < k * d; i += 256) sc[i] = cg[i];
-    __syncthreads();
     const int64_t row = (int64_t)blockIdx.x * 256 + tid;
-    if (row >= n) return;
+    const bool live = row < n;
     float r[DCAP];
-    const float *xr = x + row * D + (size_t)g * d;
-    const float *br = base ? base + (size_t)base_idx[row] * D + (size_t)g * d : nullptr;
-#pragma unroll
-    for (int c = 0; c < DCAP; ++c)
-        if (c < d) r[c] = br ? xr[c] - br[c] : xr[c];
-    float best = INFINITY;
-    int bj = 0;
-    for (int j = 0; j < k; ++j) {
-        const float *cj = sc + j * d;
-        float acc = 0.0f;
+    if (live) {
+        const float *xr = x + row * D + (size_t)g * d;
+        const float *br = base ? base + (size_t)base_idx[row] * D + (size_t)g * d : nullptr;
 #pragma unroll
         for (int c = 0; c < DCAP; ++c)
-            if (c < d) {
-                const float diff = r[c] - cj[c];
-                acc = __builtin_fmaf(diff, diff, acc);
+            if (c < d) r[c] = br ? xr[c] - br[c] : xr[c];
+    }
+    float best = INFINITY;
+    int bj = 0;
+    // any k: the centroids pass through LDS kb at a time, in id order -- the running (best, id) sees them in the same
+    // order as one resident table would (strict <: lowest id on ties), so the result does not depend on kb
+    for (int j0 = 0; j0 < k; j0 += kb) {
+        const int kt = (k - j0) < kb ? (k - j0) : kb;
+        __syncthreads();                                                   // the previous tile has been read by everybody
+        for (int i = tid; i < kt * d; i += 256) sc[i] = cg[(size_t)j0 * d + i];
+        __syncthreads();
+        if (live) {
+            for (int j = 0; j < kt; ++j) {
+                const float *cj = sc + j * d;
+                float acc = 0.0f;
+#pragma unroll
+                for (int c = 0; c < DCAP; ++c)
+                    if (c < d) {
+                        const float diff = r[c] - cj[c];
+                        acc = __builtin_fmaf(diff, diff, acc);
+                    }
+                if (acc < best) {                  // strict: lowest id on ties
+                    best = acc;
+                    bj = j0 + j;
+                }
             }
-        if (acc < best) {                      // strict: lowest id on ties
-            best = acc;
-            bj = j;
         }
     }
+    if (!live) return;
     if (out) out[row * G + g] = bj;
     if (out_u8) out_u8[row * G + g] = (uint8_t)bj;
 }
@@ -345,15 +359,17 @@ extern "C" int grafp_pq_assign_f32(const float *x, int64_t n, int D, int G, cons
     GRAFP_REQUIRE(G <= 65535, "pq_assign: G=%d sub-spaces", G);
     const int d = D / G;
     GRAFP_REQUIRE(d <= 128, "pq_assign: %d dims per sub-space (<= 128)", d);
-    const size_t lds = (size_t)k * d * sizeof(float);
-    GRAFP_REQUIRE(lds <= 150 * 1024, "pq_assign: k x d = %d x %d centroids need %zu bytes of LDS", k, d, lds);
+    // centroids per LDS tile: all of them up to 64 KB (two workgroups per CU), otherwise 64 KB worth
+    int kb = (64 * 1024) / (int)(d * sizeof(float));
+    if (kb > k) kb = k;
+    const size_t lds = (size_t)kb * d * sizeof(float);
     if (n == 0) return GRAFP_OK;
     const dim3 grid((unsigned)((n + 255) / 256), G);
     hipStream_t s = (hipStream_t)stream;
 #define PQA_LAUNCH(DC)                                                                                                   \
     do {                                                                                                                 \
         (void)hipFuncSetAttribute((const void *)pq_assign_kernel<DC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((pq_assign_kernel<DC>), grid, dim3(256), lds, s, x, n, D, G, base, base_idx, cent, k, out, out_u8); \
+        hipLaunchKernelGGL((pq_assign_kernel<DC>), grid, dim3(256), lds, s, x, n, D, G, base, base_idx, cent, k, kb, out, out_u8); \
     } while (0)
     if (d <= 2) PQA_LAUNCH(2);
     else if (d <= 8) PQA_LAUNCH(8);

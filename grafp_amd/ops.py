@@ -1020,6 +1020,16 @@ def _wgrad_bf16(g, x, cout, cin, groups, M, views=1, pro_tab=None, pro_act=ACT_N
 conv1x1_wgrad = _wgrad_bf16
 
 
+def _may_defer(w):
+    """A weight gradient may leave backward() with its split-K partial sums still unreduced (defer_wgrad_reduce) only if
+    nothing can READ it before the flush: the weight is a leaf whose .grad is None (AccumulateGrad then takes the tensor
+    over as it is -- with an existing .grad it would ADD the unreduced memory into it: gradient accumulation without
+    zero()) and it carries no tensor hook (a hook receives the gradient inside backward).  Post-accumulate hooks are
+    GradSync's, which flushes before it packs a bucket.  Everything else reduces immediately: slower, never wrong."""
+    return (w is not None and w.grad is None and not getattr(w, "_backward_hooks", None)
+            and not torch.is_grad_enabled())            # create_graph = True keeps grad mode on inside backward
+
+
 class _ConvBnAct(torch.autograd.Function):
     """z = act(BatchNorm(W x + bias)) + residual on bf16 (C, M) rows, the bf16 training path of every
     [Conv2d(1x1) -> BatchNorm2d -> activation -> shortcut] chain: ONE hand-written GEMM whose epilogue also yields the
@@ -1038,6 +1048,7 @@ class _ConvBnAct(torch.autograd.Function):
             pro = (defer.tab, int(defer.act), float(defer.slope))
         ctx.pro = pro
         ctx.w_leaf = bool(w.is_leaf)                         # its gradient goes straight to AccumulateGrad (never read here)
+        ctx.w_param = w if w.is_leaf else None               # (looked at again in backward: see _may_defer)
         ctx.token, ctx.token_role = token, token_role        # 1: first layer of the block (consumes), 2: last (provides)
         ctx.w_t, ctx.w_aug = w_t, w_aug                      # prepared with the forward operand (lowp_weights), or None
         # shared prepared buffers in use: remember which preparation this forward pass saw
@@ -1108,9 +1119,10 @@ class _ConvBnAct(torch.autograd.Function):
         dw = None
         if ctx.needs_input_grad[1]:
             if ctx.pro is not None:                        # x is the producer's raw output: the same transform on load
-                dw = _wgrad_bf16(dy, x, R, K, cg, M, views, ctx.pro[0], ctx.pro[1], ctx.pro[2], may_defer=ctx.w_leaf).reshape(wfull)
+                dw = _wgrad_bf16(dy, x, R, K, cg, M, views, ctx.pro[0], ctx.pro[1], ctx.pro[2],
+                                 may_defer=_may_defer(ctx.w_param)).reshape(wfull)
             else:
-                dw = _wgrad_bf16(dy, x, R, K, cg, M, may_defer=ctx.w_leaf).reshape(wfull)
+                dw = _wgrad_bf16(dy, x, R, K, cg, M, may_defer=_may_defer(ctx.w_param)).reshape(wfull)
         dres = dz if has_res else None
         if has_res and tok is not None and ctx.token_role == 2 and tok.grad is None:
             tok.grad, dres = dz, None                      # the first layer's backward adds it (see above)

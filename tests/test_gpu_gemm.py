@@ -375,6 +375,40 @@ def test_deferred_weight_gradient_reductions_are_bit_identical():
     assert torch.equal(b, want[2])
 
 
+def test_deferred_reduction_only_when_nothing_can_read_the_gradient_first():
+    """under ops.defer_wgrad_reduce() a layer's dW leaves backward() unreduced only if autograd will ASSIGN it to a
+    leaf weight's empty .grad.  A second backward pass without zeroing in between (gradient accumulation: AccumulateGrad
+    ADDS into the existing .grad) and a tensor hook on the weight (it receives the gradient inside backward) must both see
+    reduced values: those layers reduce immediately.  The layer is conv_bn_act on bf16 rows, as the encoder calls it."""
+    from grafp_amd import ops
+    R, K, M = 128, 64, 8192
+    x = _rand((K, M), 61, 1.0, 0.2)
+    gamma, beta = torch.ones(R, device=DEV), torch.zeros(R, device=DEV)
+    up = _rand((R, M), 62).float()
+
+    def backward(w, hook=None):
+        rm, rv = torch.zeros(R, device=DEV), torch.ones(R, device=DEV)
+        if hook is not None:
+            w.register_hook(hook)
+        z = ops.conv_bn_act(x, w, gamma, beta, rm, rv, True, act=ops.ACT_RELU)
+        with ops.defer_wgrad_reduce():
+            queued_inside = None
+            (z.float() * up).sum().backward()
+            queued_inside = len(ops._WGRAD_PENDING)
+        return queued_inside
+
+    w0 = (0.2 * torch.randn(R, K, generator=torch.Generator().manual_seed(63))).to(DEV)
+    w = w0.clone().requires_grad_(True)
+    assert backward(w) == 1                                   # the plain case IS deferred (one queued reduction)
+    once = w.grad.clone()
+    assert backward(w) == 0                                   # .grad exists: reduced immediately, then accumulated
+    assert torch.equal(w.grad, once + once)
+    seen = []
+    w2 = w0.clone().requires_grad_(True)
+    assert backward(w2, hook=lambda g: seen.append(g.clone())) == 0
+    assert torch.equal(seen[0], once) and torch.equal(w2.grad, once)
+
+
 @pytest.mark.parametrize("R,K,M", [(64, 64, 8192), (256, 64, 16384), (64, 256, 131072), (1024, 256, 4096), (512, 2048, 1024),
                                    (128, 96, 128 * 37), (2048, 512, 2560)])
 def test_split_bf16_product_of_the_f32_mode(R, K, M):

@@ -1159,11 +1159,13 @@ def test_ivfpq_index_vs_oracle_and_exact(dev):
     assert idx.rows().shape == (n, d) and idx.ntotal == n
 
 
-@pytest.mark.parametrize("d,M,nlist,n", [(64, 64, 8, 1500), (32, 8, 5, 900), (128, 16, 3, 100), (16, 16, 70, 400)])
+@pytest.mark.parametrize("d,M,nlist,n", [(64, 64, 8, 1500), (32, 8, 5, 900), (128, 16, 3, 100), (16, 16, 70, 400),
+                                         (128, 64, 512, 3000)])
 def test_ivfpq_other_shapes_vs_c_oracle(dev, d, M, nlist, n):
     """Sub-space widths 1 / 4 / 8 (the table and scan templates), M not a multiple of 16 (byte-wise code reads), fewer
-    training rows than codewords (repeated seeds, empty clusters keep their centroid), more lists than a wave has lanes:
-    quantisers, codes, probes and search results bit-equal to oracle/csrc/ivfpq.c."""
+    training rows than codewords (repeated seeds, empty clusters keep their centroid), more lists than a wave has lanes,
+    and 512 lists at d = 128 (eval.py's n_centroids argument: the coarse centroids pass through LDS in tiles, 256 KB do not
+    fit at once): quantisers, codes, probes and search results bit-equal to oracle/csrc/ivfpq.c."""
     from grafp_amd.ivfpq import IVFPQIndex, kmeans_init_rows
     from oracle import native
     rng = np.random.RandomState(d + M)
