@@ -386,8 +386,13 @@ __global__ __launch_bounds__(256) void knn_norms_kernel(const unsigned short *__
     for (int u = 0; u < VE; ++u) {
         sq[o + u] = q[u];
         den_out[o + u] = den[u];
-        cs[o + u] = make_float2(-2.0f * __frcp_rn(den[u]), q[u]);
     }
+    // the candidate table, PAIR-interleaved: nodes 2p, 2p + 1 -> (cj_2p, cj_2p+1, sq_2p, sq_2p+1), so that the scan reads
+    // two candidates' factors as two aligned register pairs (one v_pk_fma_f32 per pair and term; knn_topk_raw_kernel)
+    f32x4 *cs4 = reinterpret_cast<f32x4 *>(cs) + (o >> 1);                 // o = b * N + n0 is a multiple of VE (even)
+#pragma unroll
+    for (int u = 0; u < VE; u += 2)
+        cs4[u >> 1] = f32x4{-2.0f * __frcp_rn(den[u]), -2.0f * __frcp_rn(den[u + 1]), q[u], q[u + 1]};
 }
 
 template <int K, typename I>
@@ -467,11 +472,33 @@ __global__ __launch_bounds__(256, 2) void knn_topk_raw_kernel(const unsigned sho
     best.init();
     bool bad = false;
 
-    auto insert = [&](const f32x16 (&a)[4], int e, int tb, unsigned lane_bits) {
-        const int loc_c = (e >> 4) * 32 + ((e & 15) & 3) + 8 * ((e & 15) >> 2);
-        const float2 t = sCS[tb + loc_c + 4 * half];
-        const float d = __builtin_fmaf(a[e >> 4][e & 15], t.x, __builtin_fmaf(t.y, iq, dqi));
-        best.push((__float_as_uint(d) & key_mask) | lane_bits | (unsigned)loc_c);
+    // four candidates at once (accumulator registers e0 .. e0 + 3 of one MFMA tile = candidates loc_c .. loc_c + 3): their
+    // table entries are two 16-byte broadcast reads [cj0 cj1 sq0 sq1][cj2 cj3 sq2 sq3] (pair-interleaved by pass 1), and
+    // d'' = fma(G, cj, fma(sq, den_q, (sq_q + 2^-10) den_q)) runs as v_pk_fma_f32 on aligned register pairs -- two FMAs per
+    // instruction, the same IEEE result per element as the scalar form (the scan is bound by exactly these VALU instructions)
+    const gm_f32x2 iq2 = {iq, iq}, dqi2 = {dqi, dqi};
+    unsigned kmv = key_mask;
+    asm volatile("" : "+v"(kmv));
+    auto insert4 = [&](const f32x16 (&a)[4], int e0, int tb, unsigned lane_bits) {
+        const int tt = e0 >> 4, r0 = e0 & 15;
+        const int loc_c = tt * 32 + 8 * (r0 >> 2);
+        const f32x4 *tp = reinterpret_cast<const f32x4 *>(sCS + tb + loc_c + 4 * half);
+        const f32x4 t01 = tp[0], t23 = tp[1];
+        const gm_f32x2 d01 = __builtin_elementwise_fma(gm_f32x2{a[tt][r0], a[tt][r0 + 1]}, gm_f32x2{t01[0], t01[1]},
+                                                    __builtin_elementwise_fma(gm_f32x2{t01[2], t01[3]}, iq2, dqi2));
+        const gm_f32x2 d23 = __builtin_elementwise_fma(gm_f32x2{a[tt][r0 + 2], a[tt][r0 + 3]}, gm_f32x2{t23[0], t23[1]},
+                                                    __builtin_elementwise_fma(gm_f32x2{t23[2], t23[3]}, iq2, dqi2));
+        // key = distance bits under key_mask, candidate index in the freed mantissa bits: ONE v_and_or_b32 with the mask in
+        // a VGPR and the wave-uniform index in an SGPR (mask and index both in SGPRs do not fit one VOP3: v_and + v_or)
+        const unsigned c0 = lane_bits | (unsigned)loc_c;
+        best.push((__float_as_uint(d01[0]) & kmv) | c0);
+        best.push((__float_as_uint(d01[1]) & kmv) | (c0 + 1));
+        best.push((__float_as_uint(d23[0]) & kmv) | (c0 + 2));
+        best.push((__float_as_uint(d23[1]) & kmv) | (c0 + 3));
+    };
+    // cj of candidate c of the table block at tb (pair-interleaved layout)
+    auto cj_of = [&](int tb, int c) -> float {
+        return reinterpret_cast<const float *>(sCS + tb)[4 * (c >> 1) + (c & 1)];
     };
 
 #pragma unroll
@@ -503,11 +530,11 @@ __global__ __launch_bounds__(256, 2) void knn_topk_raw_kernel(const unsigned sho
                     // in batches of 8: hipcc otherwise hoists all 32 table reads (64 registers) over the inserts and spills
 #pragma unroll
                     for (int e8 = 0; e8 < 32; e8 += 8) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) insert(prev, ks * 32 + e8 + e, tb_prev, bits_prev);
+                        insert4(prev, ks * 32 + e8, tb_prev, bits_prev);
+                        insert4(prev, ks * 32 + e8 + 4, tb_prev, bits_prev);
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    bad = bad || fabsf(sCS[tb_prev + ks * 64 + lane].x) < KR_TINY;
+                    bad = bad || fabsf(cj_of(tb_prev, ks * 64 + lane)) < KR_TINY;
                 }
             }
         }
@@ -523,11 +550,11 @@ __global__ __launch_bounds__(256, 2) void knn_topk_raw_kernel(const unsigned sho
         const unsigned bits_last = (unsigned)((nblk - 1) * KS_TR);
 #pragma unroll
         for (int e8 = 0; e8 < 64; e8 += 8) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) insert(prev, e8 + e, tb_last, bits_last);
+            insert4(prev, e8, tb_last, bits_last);
+            insert4(prev, e8 + 4, tb_last, bits_last);
             __builtin_amdgcn_sched_barrier(0);
         }
-        bad = bad || fabsf(sCS[tb_last + lane].x) < KR_TINY || fabsf(sCS[tb_last + 64 + lane].x) < KR_TINY;
+        bad = bad || fabsf(cj_of(tb_last, lane)) < KR_TINY || fabsf(cj_of(tb_last, 64 + lane)) < KR_TINY;
     }
     const bool clip_bad = __any(bad ? 1 : 0) != 0;
     // index bit 2 (which half-wave's rows) is the same for every candidate a lane saw: set once, here
