@@ -165,9 +165,22 @@ def summarise_kernels(timed, esize=4):
                        peak=PEAK_F32_MATRIX_TFLOPS, tflops=round(fl / (tot * 1e-3) / 1e12, 3),
                        note="exact-f32 MFMA; launch/latency-bound at these sizes")
         elif name == "logmel":
+            # SURVEY 8d prices K1 at 72 192 B and 1.64 M (FFT: 5 n log2 n per 1024-point frame) + 2.10 M (mel: 513 x 64
+            # multiply-adds per frame) flops per clip-view: at 8 TB/s and 157 TFLOP/s the ARITHMETIC is the higher ceiling
+            # (24 ns against 9 ns per clip-view), so the fraction of the HBM peak alone undersells the kernel:
+            # two_ceiling_frac = max(bytes / HBM peak, flops / f32 peak) / measured
             by = sum(B * (4.0 * T + 4.0 * 64 * (1 + T // 512)) for _, _, (B, T) in ev)
-        elif name == "peak_extract_fwd":
-            by = sum(B * (8192.0 + 32768.0) for _, _, (B,) in ev)
+            fl = sum(B * (1 + T // 512) * (5.0 * 1024 * 10 + 2.0 * 513 * 64) for _, _, (B, T) in ev)
+            row["fp32_tflops"] = round(fl / (tot * 1e-3) / 1e12, 2)
+            row["two_ceiling_frac"] = round(max(by / (PEAK_HBM_GBS * 1e9), fl / (PEAK_F32_MATRIX_TFLOPS * 1e12)) / (tot * 1e-3), 4)
+        elif name in ("peak_extract_fwd", "peak_extract_bwd"):
+            # 3 x 7 x 7 taps x 8 filters x 1024 positions multiply-adds per clip-view either way (2.41 MFLOP); forward moves
+            # 8 192 + 32 768 B, backward reads the clip, the output and its gradient (73 728 B) and writes 1 184 sums
+            per = 8192.0 + 32768.0 if name == "peak_extract_fwd" else 8192.0 + 2 * 32768.0
+            by = sum(B * per for _, _, (B,) in ev)
+            fl = sum(B * 2.0 * 147 * 8 * 1024 for _, _, (B,) in ev)
+            row["fp32_tflops"] = round(fl / (tot * 1e-3) / 1e12, 2)
+            row["two_ceiling_frac"] = round(max(by / (PEAK_HBM_GBS * 1e9), fl / (PEAK_F32_MATRIX_TFLOPS * 1e12)) / (tot * 1e-3), 4)
         if by is not None:
             row["bytes"] = by
             if "achieved" not in row:
