@@ -108,6 +108,8 @@ __device__ __forceinline__ unsigned long long ks_key64(float d, int i) {
     return ((unsigned long long)u << 32) | (unsigned)i;
 }
 
+template <bool V> struct KsBool { static constexpr bool value = V; };
+
 // K smallest keys, ascending, + the smallest key that left (or never entered) the list
 template <int K>
 struct KeyList {
@@ -463,11 +465,7 @@ __global__ __launch_bounds__(256, 2) void knn_topk_raw_kernel(const unsigned sho
         return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     };
 
-    f32x16 acc[4], prev[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { acc[t][r] = 0.0f; prev[t][r] = 0.0f; }
+    f32x16 acc[4];
     KeyList<K + 1> best;
     best.init();
     bool bad = false;
@@ -504,10 +502,17 @@ __global__ __launch_bounds__(256, 2) void knn_topk_raw_kernel(const unsigned sho
 #pragma unroll
     for (int c = 0; c < D; ++c)
         if (c < T) dma_chunk(c);
+    // One candidate block: its products accumulate in `acc` -- the first k-step starts from a zero C OPERAND, no register
+    // clears -- and when its last chunk is done the 64 finished values of a lane become keys straight out of the
+    // accumulators.  (Until round 5 the finished block was first copied to a second register set and its keys were built
+    // "in the MFMA shadow" of the next block: VALU and MFMA instructions of one SIMD do not overlap (tools/microbench/
+    // mfma_valu_bench), so the shadow bought nothing, and the 128 v_mov per block of "prev = acc; acc = 0" were a fifth of
+    // the kernel's VALU instructions at 64 channels.)
     for (int blk = 0; blk < nblk; ++blk) {
-        const int tb_prev = ((blk + KR_NT - 1) % KR_NT) * KS_TR;
-        const unsigned bits_prev = (unsigned)((blk - 1) * KS_TR);       // wave-uniform: (bits | loc_c) stays in SGPRs
-        for (int ch = 0; ch < nch; ++ch) {
+        const int tb = (blk % KR_NT) * KS_TR;
+        const unsigned bits = (unsigned)(blk * KS_TR);                  // wave-uniform: (bits | loc_c) stays in SGPRs
+        auto chunk = [&](int ch, auto first_c) __attribute__((always_inline)) {
+            constexpr bool FIRST = decltype(first_c)::value;
             const int t = blk * nch + ch;
             {   // chunk t landed (this wave's pieces; wave 0's table pieces only make its wait stricter), then everybody's
                 const int newer = T - 1 - t;
@@ -524,37 +529,25 @@ __global__ __launch_bounds__(256, 2) void knn_topk_raw_kernel(const unsigned sho
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt) {
                     const gm_bf16x8 af = frag(st, foff[tt] + ks * 16 * 256);
-                    acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, qf, acc[tt], 0, 0, 0);
-                }
-                if (ch == 0 && blk > 0) {
-                    // in batches of 8: hipcc otherwise hoists all 32 table reads (64 registers) over the inserts and spills
-#pragma unroll
-                    for (int e8 = 0; e8 < 32; e8 += 8) {
-                        insert4(prev, ks * 32 + e8, tb_prev, bits_prev);
-                        insert4(prev, ks * 32 + e8 + 4, tb_prev, bits_prev);
-                        __builtin_amdgcn_sched_barrier(0);
+                    if (FIRST && ks == 0) {
+                        const f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+                        acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, qf, zero, 0, 0, 0);
+                    } else {
+                        acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, qf, acc[tt], 0, 0, 0);
                     }
-                    bad = bad || fabsf(cj_of(tb_prev, ks * 64 + lane)) < KR_TINY;
                 }
             }
-        }
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {
-            prev[tt] = acc[tt];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[tt][r] = 0.0f;
-        }
-    }
-    {
-        const int tb_last = ((nblk - 1) % KR_NT) * KS_TR;
-        const unsigned bits_last = (unsigned)((nblk - 1) * KS_TR);
+        };
+        chunk(0, KsBool<true>{});
+        for (int ch = 1; ch < nch; ++ch) chunk(ch, KsBool<false>{});
+        // in batches of 8: hipcc otherwise hoists all 32 table reads (64 registers) over the inserts and spills
 #pragma unroll
         for (int e8 = 0; e8 < 64; e8 += 8) {
-            insert4(prev, e8, tb_last, bits_last);
-            insert4(prev, e8 + 4, tb_last, bits_last);
+            insert4(acc, e8, tb, bits);
+            insert4(acc, e8 + 4, tb, bits);
             __builtin_amdgcn_sched_barrier(0);
         }
-        bad = bad || fabsf(cj_of(tb_last, lane)) < KR_TINY || fabsf(cj_of(tb_last, 64 + lane)) < KR_TINY;
+        bad = bad || fabsf(cj_of(tb, lane)) < KR_TINY || fabsf(cj_of(tb, 64 + lane)) < KR_TINY;
     }
     const bool clip_bad = __any(bad ? 1 : 0) != 0;
     // index bit 2 (which half-wave's rows) is the same for every candidate a lane saw: set once, here
