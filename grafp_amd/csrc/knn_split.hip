@@ -601,7 +601,7 @@ __global__ __launch_bounds__(256) void knn_exact_clip_kernel(const T *__restrict
                                                              I *__restrict__ idx, int C, int N, int chc,
                                                              const int *__restrict__ counters,
                                                              int *__restrict__ n_uncertified,
-                                                             const int *__restrict__ extra) {
+                                                             const int *__restrict__ extra, int stop) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm_x[];
     if (n_uncertified && blockIdx.x == 0 && threadIdx.x == 0) *n_uncertified = counters[0];   // diagnostics (last pass)
     T *sX = reinterpret_cast<T *>(sm_x);                                       // [2][chc][W] feature chunks (W columns)
@@ -623,46 +623,62 @@ __global__ __launch_bounds__(256) void knn_exact_clip_kernel(const T *__restrict
     __syncthreads();
     const int n = s_n, nl = s_nl;
     if (n == 0 && nl == 0) return;
+    if (stop == 1) return;                                     // measurement builds only (tools/knn_prof.sh): after the flag scan
     const T *xb = x + (size_t)b * sb;
     const float *denb = den + (size_t)b * N, *sqb = sq + (size_t)b * N;
-    // ---- LIGHT queries of this clip (pass 3a, formerly a kernel of its own over a global list): exact distances to the
-    // k + 1 listed candidates only, c-ordered fmaf chains on x / den, ranked by (distance, index); 8 lanes per query (lane
-    // s < k + 1 takes candidate s).  Done here, clip by clip, instead of a kernel of its own over a global list of rows: one
-    // launch and the list's atomics less, the same 100 us per call for both exact passes (load-latency bound: two
-    // workgroups per CU by registers, a few queries each; neither deeper unrolling nor the per-clip grouping moved it).
-    for (int base = 0; base < nl; base += 32) {
-        const int e = base + (tid >> 3), sub = lane & 7;
-        const bool active = e < nl && sub <= K;
-        unsigned long long key = ~0ull;
-        int q = 0, j = 0;
-        if (active) {
-            q = s_list[N - 1 - e];
+    // ---- LIGHT queries of this clip (pass 3a): exact distances to the k + 1 listed candidates only, the oracle's c-ordered
+    // fmaf chain on x / den, ranked by (distance, index).  One query per WAVE at a time: all 64 lanes first fetch the k + 2
+    // feature columns involved (the query's and its candidates': (k + 2) C / 64 independent 2-byte loads per lane, all in
+    // flight together), divide by the column's norm and park the quotients in LDS; then lane s runs candidate s's chain out
+    // of LDS.  (Until round 5 eight lanes per query walked the channels with their own dependent global loads, 8 channels
+    // at a time: C / 8 load latencies in a row per query -- 50 of the kernel's 100 us at 256 channels, and the whole of its
+    // 47 us at 256 clip-views.)  The quotients and the chain are the same IEEE operations in the same order.
+    {
+        float *sL = reinterpret_cast<float *>(sm_x) + (size_t)wave * (K + 2) * C;      // [K + 2][C]: the staging area is idle
+        for (int e = wave; e < nl; e += 4) {                                           // wave-uniform
+            const int q = s_list[N - 1 - e];
             const size_t row = (size_t)b * N + q;
-            j = sub < K ? (int)idx[row * K + sub] : extra[row];
-            const float dq = denb[q], dj = denb[j];
-            float g = 0.0f;
-            for (int c = 0; c < C; c += 8) {                   // C % 32 == 0 (32 channels of loads in flight change nothing)
-                float vq[8], vj[8];
+            int col[K + 2];
+            col[0] = q;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    vq[u] = ks_ld(xb + (size_t)(c + u) * sc + q);
-                    vj[u] = ks_ld(xb + (size_t)(c + u) * sc + j);
-                }
+            for (int t = 0; t < K; ++t) col[1 + t] = (int)idx[row * K + t];
+            col[K + 1] = extra[row];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) g = __builtin_fmaf(__fdiv_rn(vj[u], dj), __fdiv_rn(vq[u], dq), g);
+            for (int v = 0; v < K + 2; ++v) {
+                const float dv = denb[col[v]];
+                for (int c = lane; c < C; c += 64) sL[v * C + c] = __fdiv_rn(ks_ld(xb + (size_t)c * sc + col[v]), dv);
             }
-            const float d = __builtin_fmaf(-2.0f, g, sqb[q]) + sqb[j];        // (sq_i + (-2 g)) + sq_j
-            key = ks_key64(d, j);
-        }
-        int rank = 0;                                          // inside the 8-lane group (keys are distinct: the indices are)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            unsigned long long key = ~0ull;
+            int j = 0;
+            if (lane <= K) {
+                j = col[1];
 #pragma unroll
-        for (int t = 0; t <= K; ++t) {
-            const unsigned long long other = __shfl(key, (lane & ~7) + t);
-            rank += other < key ? 1 : 0;
+                for (int t = 1; t <= K; ++t) j = lane == t ? col[1 + t] : j;
+                const f32x4 *vq4 = reinterpret_cast<const f32x4 *>(sL);
+                const f32x4 *vj4 = reinterpret_cast<const f32x4 *>(sL + (size_t)(1 + lane) * C);
+                float g = 0.0f;
+                for (int c4 = 0; c4 < C / 4; ++c4) {                                    // C % 32 == 0
+                    const f32x4 a = vj4[c4], bq = vq4[c4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) g = __builtin_fmaf(a[u], bq[u], g);
+                }
+                const float d = __builtin_fmaf(-2.0f, g, sqb[q]) + sqb[j];            // (sq_i + (-2 g)) + sq_j
+                key = ks_key64(d, j);
+            }
+            int rank = 0;                                          // among lanes 0 .. K (keys are distinct: the indices are)
+#pragma unroll
+            for (int t = 0; t <= K; ++t) {
+                const unsigned long long other = __shfl(key, t);
+                rank += other < key ? 1 : 0;
+            }
+            if (lane <= K && rank < K) idx[row * K + rank] = (I)j;
+            __builtin_amdgcn_wave_barrier();                       // the chains are done with sL before the next query's quotients land
         }
-        if (active && rank < K) idx[((size_t)b * N + q) * K + rank] = (I)j;
     }
-    if (n == 0) return;
+    if (n == 0 || stop == 2) return;                           // (stop == 2: measurement builds, after the light queries)
     const int W = N < 256 * KX_NU ? N : 256 * KX_NU;          // columns per range (N % 128 == 0)
     constexpr int VE = 16 / (int)sizeof(T);                    // elements per 16-byte vector
     const int vrow = W / VE, nvec = chc * vrow;                // vectors per row / per chunk
@@ -831,7 +847,7 @@ template <int K, typename I, typename T> static void ks_launch_exact(const KsArg
     (void)hipFuncSetAttribute((const void *)knn_exact_clip_kernel<K, I, T>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds_x);
     hipLaunchKernelGGL((knn_exact_clip_kernel<K, I, T>), dim3(a.B), dim3(256), lds_x, s, (const T *)a.x, a.sb, a.sc, a.den,
-                       a.sq, a.flag, (I *)a.idx, a.C, a.N, chc, a.count, a.n_unc, a.extra);
+                       a.sq, a.flag, (I *)a.idx, a.C, a.N, chc, a.count, a.n_unc, a.extra, GRAFP_TUNE_INT("GRAFP_KX_STOP", 0));
 }
 template <int K, typename I> static void ks_launch(const KsArgs &a, hipStream_t s) {
     const int tiles = a.N / KS_TQ, nblocks = a.B * tiles;
