@@ -59,9 +59,16 @@ template <> struct BnIO<unsigned short> {
         }
     }
     __device__ static void store(unsigned short *p, const float (&v)[8]) {
+        // v_cvt_pk_bf16_f32 (round to nearest even, the conversion the GEMM epilogues use): one instruction per PAIR instead
+        // of the six of the integer form per value -- a seventh of this file's backward kernel's vector instructions
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        typedef __bf16 b2 __attribute__((ext_vector_type(2)));
         unsigned w[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) w[i] = (unsigned)f2bf(v[2 * i]) | ((unsigned)f2bf(v[2 * i + 1]) << 16);
+        for (int i = 0; i < 4; ++i) {
+            const f2 pr = {v[2 * i], v[2 * i + 1]};
+            w[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(pr, b2));
+        }
         typedef unsigned u4 __attribute__((ext_vector_type(4)));
         const u4 t = {w[0], w[1], w[2], w[3]};
         __builtin_nontemporal_store(t, reinterpret_cast<u4 *>(p));
@@ -622,6 +629,13 @@ __global__ __launch_bounds__(THREADS) void bn_bwd1_kernel(const T *__restrict__ 
     T *orow = dx + (size_t)c * M;
     const float pb = pre_bias ? pre_bias[c] : 0.0f;
     const float mean = save_mean[c * G + grp], invstd = save_invstd[c * G + grp], ga = gamma[c], be = beta[c];
+    // The kernel is partly bound by its vector instructions (27 per element against ~50 lane-operations per element that
+    // 5 TB/s leave a CU), so the per-element arithmetic is folded into the fewest fused operations:
+    //   xhat = fma(x, invstd, (pb - mean) invstd);  pre-activation = fma(x, gamma invstd, beta + (pb - mean) gamma invstd)
+    //   -- the very expression the forward pass thresholds, so the ReLU decision is the forward one by construction;
+    //   masked gradient = pre > 0 ? dz : dz * neg   (neg: 1 without activation, 0 for ReLU, the slope for LeakyReLU)
+    const float xh0 = (pb - mean) * invstd, zg = ga * invstd, zoff = be + (pb - mean) * zg;
+    const float neg = act == 0 ? 1.0f : (act == 1 ? 0.0f : slope);
     const int64_t gend = (int64_t)(grp + 1) * Mg;
     const int64_t lo = (int64_t)grp * Mg + (int64_t)sl * CHUNK;
     const int64_t hi = (lo + CHUNK < gend) ? lo + CHUNK : gend;
@@ -644,8 +658,8 @@ __global__ __launch_bounds__(THREADS) void bn_bwd1_kernel(const T *__restrict__ 
             BnIO<T>::unpack(rd[it], d);
 #pragma unroll
             for (int i = 0; i < W; ++i) {
-                const float xh = ((v[i] + pb) - mean) * invstd;
-                const float dy = d[i] * act_grad(__builtin_fmaf(xh, ga, be), act, slope);
+                const float xh = __builtin_fmaf(v[i], invstd, xh0);
+                const float dy = __builtin_fmaf(v[i], zg, zoff) > 0.0f ? d[i] : d[i] * neg;
                 sd += dy;
                 sdx = __builtin_fmaf(dy, xh, sdx);
             }
@@ -672,8 +686,8 @@ __global__ __launch_bounds__(THREADS) void bn_bwd1_kernel(const T *__restrict__ 
                     BnIO<T>::load(grow + m, d);
 #pragma unroll
                     for (int e = 0; e < W; ++e) {
-                        const float xh = ((v[e] + pb) - mean2) * invstd2;
-                        const float dy = d[e] * act_grad(__builtin_fmaf(xh, ga, be), act, slope);
+                        const float xh = __builtin_fmaf(v[e], invstd2, (pb - mean2) * invstd2);
+                        const float dy = __builtin_fmaf(v[e], ga * invstd2, be + (pb - mean2) * (ga * invstd2)) > 0.0f ? d[e] : d[e] * neg;
                         sd2 += dy;
                         sdx2 = __builtin_fmaf(dy, xh, sdx2);
                     }
@@ -708,6 +722,7 @@ __global__ __launch_bounds__(THREADS) void bn_bwd1_kernel(const T *__restrict__ 
     }
     const float k = ga * invstd;
     const float m1 = sd / (float)Mg, m2 = sdx / (float)Mg;
+    const float km1 = -(k * m1), km2 = -(k * m2);               // dx = k dy - k m1 - k m2 xh: two fmaf per element
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
         const int64_t m = lo + ((int64_t)it * THREADS + tid) * W;
@@ -717,9 +732,9 @@ __global__ __launch_bounds__(THREADS) void bn_bwd1_kernel(const T *__restrict__ 
             BnIO<T>::unpack(rd[it], d);
 #pragma unroll
             for (int i = 0; i < W; ++i) {
-                const float xh = ((v[i] + pb) - mean) * invstd;
-                const float dy = d[i] * act_grad(__builtin_fmaf(xh, ga, be), act, slope);
-                v[i] = k * ((dy - m1) - xh * m2);
+                const float xh = __builtin_fmaf(v[i], invstd, xh0);
+                const float dy = __builtin_fmaf(v[i], zg, zoff) > 0.0f ? d[i] : d[i] * neg;
+                v[i] = __builtin_fmaf(xh, km2, __builtin_fmaf(dy, k, km1));
             }
             BnIO<T>::store(orow + m, v);
         }
