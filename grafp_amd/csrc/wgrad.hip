@@ -649,6 +649,11 @@ static WgDmaPlan wgrad_dma_plan(int cout_g, int cin_g, int groups, int64_t M, in
         if (groups == 1 && outs > 128 * 128 && outs <= 256 * 256 && opbytes >= 250e6) p.cfg = 10;
         if (groups > 1 && cout_g == 128 && cin_g == 128 && opbytes >= 750e6) p.cfg = 10;
     }
+    // ... and at SMALL batches (operands under 200 MB: 128 pairs per GPU, BASELINE config 3's per-rank shape) for the 2^17 ...
+    // 2^19-output layers with >= 256 rows on both sides (stage 2 fc2 / FFN, stage 3 fc1), which the first rule leaves on
+    // the 64 x 64 tile: tools/wgrad_sweep.sh at 256 clip-views (profiles/r05_wgrad_sweep_256.txt): 65 -> 55 us (FFN),
+    // 39 -> 35 (stage 3 fc1), 37 -> 34.5 (stage 2 fc2); the 2^19+ outputs stay where they are (128 x 128: best there).
+    if (p256 && !pro && groups == 1 && lo >= 256 && outs >= (1 << 17) && outs < (1 << 19) && opbytes < 200e6) p.cfg = 10;
     const int forced = wg_tile(tile);
     if (forced >= 0 && forced != 9 && !(pro && (forced == 6 || forced == 7))) p.cfg = forced;
     if (p.cfg == 8 && (M / views) % 128 != 0) p.cfg = 0;          // T128 / S128 need whole 128-column chunks
