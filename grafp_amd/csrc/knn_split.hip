@@ -730,20 +730,34 @@ __global__ __launch_bounds__(256) void knn_exact_clip_kernel(const T *__restrict
             for (int ck = 0; ck < nchunk; ++ck) {
                 const T *buf = sX + (size_t)(ck & 1) * (KX_CHUNK / sizeof(T));
                 if (ck + 1 < nchunk) dma(ck + 1);
-                for (int cc = 0; cc < chc; ++cc) {
-                    const int c = ck * chc + cc;
-                    float a[QG];
+                // four channels per step: their LDS reads and IEEE divisions are independent of each other (only the fmaf
+                // chains are ordered), so issuing them together hides three of every four read + division latencies -- with
+                // one channel per step the pass was a chain of C such latencies (36 us per clip, the kernel's critical path)
+                auto channels = [&](int cc0, auto nc_c) __attribute__((always_inline)) {
+                    constexpr int NC = decltype(nc_c)::value;
+                    float v[NC][KX_NU];
 #pragma unroll
-                    for (int qi = 0; qi < QG; ++qi) a[qi] = sQ[qi * C + c];
+                    for (int k2 = 0; k2 < NC; ++k2)
 #pragma unroll
-                    for (int u = 0; u < KX_NU; ++u) {
-                        if (tid + 256 * u < W) {
-                            const float v = __fdiv_rn(ks_ld(buf + (size_t)cc * W + tid + 256 * u), dj[u]);
+                        for (int u = 0; u < KX_NU; ++u)
+                            v[k2][u] = (tid + 256 * u < W)
+                                           ? __fdiv_rn(ks_ld(buf + (size_t)(cc0 + k2) * W + tid + 256 * u), dj[u]) : 0.0f;
 #pragma unroll
-                            for (int qi = 0; qi < QG; ++qi) g[u][qi] = __builtin_fmaf(v, a[qi], g[u][qi]);
-                        }
+                    for (int k2 = 0; k2 < NC; ++k2) {
+                        const int c = ck * chc + cc0 + k2;
+                        float a[QG];
+#pragma unroll
+                        for (int qi = 0; qi < QG; ++qi) a[qi] = sQ[qi * C + c];
+#pragma unroll
+                        for (int u = 0; u < KX_NU; ++u)
+                            if (tid + 256 * u < W)
+#pragma unroll
+                                for (int qi = 0; qi < QG; ++qi) g[u][qi] = __builtin_fmaf(v[k2][u], a[qi], g[u][qi]);
                     }
-                }
+                };
+                int cc = 0;
+                for (; cc + 4 <= chc; cc += 4) channels(cc, KsInt<4>{});
+                for (; cc < chc; ++cc) channels(cc, KsInt<1>{});
                 gm_wait_vm<0>();
                 __syncthreads();                               // next chunk landed; this buffer may be overwritten
             }
