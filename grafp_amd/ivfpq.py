@@ -24,7 +24,7 @@ _vp = ctypes.c_void_p
 
 
 def _stream():
-    return _vp(torch.cuda.current_stream().cuda_stream)
+    return _vp(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
 
 
 def _ptr(t):

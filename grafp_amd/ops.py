@@ -30,8 +30,14 @@ def _p(t):
     return _vp(t.data_ptr()) if t is not None else None
 
 
+# the raw handle of torch's current stream, straight from the C bindings: torch.cuda.current_stream() builds a Stream
+# object and validates the device on every call (~10 us; 160 launches of a 128-pair step made that 1.6 ms of host time
+# per pass -- the eager step is host-bound at that size: tools/host_profile.py)
+_raw_stream, _cur_device = torch._C._cuda_getCurrentRawStream, torch._C._cuda_getDevice
+
+
 def _stream():
-    return _vp(torch.cuda.current_stream().cuda_stream)
+    return _vp(_raw_stream(_cur_device()))
 
 
 def _f32c(t):
@@ -441,7 +447,7 @@ def _bn_sync(device, C, M):
     kernels (None)."""
     if switches.bn_two_pass:
         return None
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    key = (device, _raw_stream(device.index if device.index is not None else _cur_device()))
     buf = _BN_SYNC.get(key)
     need = int(lib.grafp_bn_sync_bytes(C, M))
     if buf is None or buf.numel() * 8 < need:
@@ -741,6 +747,7 @@ class lowp_weights:
         if stale:
             self._build(dtype, dev)
             self._src_ptrs = [c.weight.data_ptr() for c in self.convs]
+            self._published = False
         self.generation += 1
         with torch.no_grad():
             if self._table is not None:
@@ -748,7 +755,11 @@ class lowp_weights:
                                                 _stream()), "weights_prepare")
             if self._slow:
                 torch._foreach_copy_(self._slow_bufs, [c.weight for c in self._slow])
-        self._publish()
+        # the prepared buffers are refreshed IN PLACE: the modules' attributes only change when the buffers were rebuilt
+        # (or cleared) -- re-assigning 4 x 61 module attributes on every forward pass was 0.6 ms of host time per step
+        if not getattr(self, "_published", False):
+            self._publish()
+            self._published = True
 
     def _publish(self):
         for c in self.convs:
@@ -763,6 +774,7 @@ class lowp_weights:
         for c in self.convs:
             c._w_lowp = c._w_t = c._w_aug = None
             c._lowp_owner = None
+        self._published = False
 
 
 # ------------------------------------------------------------------------------------------------
