@@ -846,6 +846,23 @@ def main():
             line["cpu_baseline"] = cpu_baseline(cfg, args.cpu_baseline_seconds)
         if sharded is not None:
             line["retrieval_sharded"] = sharded
+        # LAST key of the line (the driver keeps only the final ~2 000 characters of stdout): every kernel family as
+        # [average launch in us, fraction of its roofline] and the handful of step figures the verdict's gates name
+        def pick(obj, *path):
+            for k in path:
+                obj = obj.get(k) if isinstance(obj, dict) else None
+            return obj
+        line["kernels_digest"] = {
+            "kernels_avg_us_frac": {k: [v.get("avg_us"), v.get("frac")] for k, v in kernels.items()},
+            "ms_1024": line["ms_per_step"], "bytes_per_step_gb": round(step_bytes / 1e9, 1),
+            "ms_256": pick(line, "config2_batch256", "ms_per_step"),
+            "ms_256_graph": pick(line, "config2_batch256", "hip_graph", "ms_per_step"),
+            "ms_128": pick(line, "config3_per_gpu_128", "ms_per_step"),
+            "ms_128_graph": pick(line, "config3_per_gpu_128", "hip_graph_ms_per_step"),
+            "ms_128_dp_graphs_rccl1": pick(line, "config3_per_gpu_128", "dp_graphs_rccl_one_rank_ms_per_step"),
+            "retrieval_frac_nq1_nq41_nq4096": [pick(line, "retrieval", "roofline", n, "frac") for n in ("nq1", "nq41", "nq4096")],
+            "retrieval_ms_nq4096": pick(line, "retrieval", "ms_per_batch_nq4096"),
+        }
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -594,6 +594,12 @@ constexpr int KX_QG = 16;        // uncertified queries per pass over the clip's
 constexpr int KX_NU = 2;         // candidates per thread and pass (256 threads: column ranges of 512 nodes)
 constexpr int KX_CHUNK = 16384;  // bytes of one staged feature chunk (double buffered)
 
+// bytes of LDS in front of the (N)-entry query list of knn_exact_clip_kernel: max of [2 chunks | KX_QG x C floats] (heavy
+// pass) and [4 waves x (K + 2) x C floats] (light pass); the same expression sizes the launch (ks_launch_exact)
+__host__ __device__ constexpr size_t kx_front_bytes(int K, int C) {
+    const size_t heavy = (size_t)2 * KX_CHUNK + (size_t)KX_QG * C * 4, light = (size_t)4 * (K + 2) * C * 4;
+    return heavy > light ? heavy : light;
+}
 template <int K, typename I, typename T>
 __global__ __launch_bounds__(256) void knn_exact_clip_kernel(const T *__restrict__ x, int64_t sb, int64_t sc,
                                                              const float *__restrict__ den, const float *__restrict__ sq,
@@ -606,7 +612,9 @@ __global__ __launch_bounds__(256) void knn_exact_clip_kernel(const T *__restrict
     if (n_uncertified && blockIdx.x == 0 && threadIdx.x == 0) *n_uncertified = counters[0];   // diagnostics (last pass)
     T *sX = reinterpret_cast<T *>(sm_x);                                       // [2][chc][W] feature chunks (W columns)
     float *sQ = reinterpret_cast<float *>(sm_x + 2 * KX_CHUNK);                 // [KX_QG][C]
-    int *s_list = reinterpret_cast<int *>(sQ + KX_QG * C);                      // [N]
+    // the query lists sit behind BOTH uses of the staging area in front of them: the chunk ring + query group of the heavy
+    // pass, and the light pass's per-wave (K + 2) x C quotient blocks (sL below), whichever is larger (kx_front_bytes)
+    int *s_list = reinterpret_cast<int *>(sm_x + kx_front_bytes(K, C));          // [N]
     __shared__ int s_n;
     __shared__ unsigned long long s_red[4];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
@@ -834,7 +842,7 @@ static float ks_margin(int C) {
 static float ks_margin_raw(int C) { return 2.0f * (1.7881393e-7f * (float)C + 3.6e-7f) + 2e-6f; }
 static bool ks_supported(int C, int N, int k) {
     return C > 0 && C % KS_KC == 0 && N >= KS_TR && N % KS_TR == 0 && N <= 4096 && k >= 1 && k <= 4 && k <= N &&
-           ks_margin(C) < 0.9f * KS_SHIFT;
+           ks_margin(C) < 0.9f * KS_SHIFT && kx_front_bytes(k, C) + (size_t)N * 4 <= 160 * 1024;   // (exact pass's LDS)
 }
 static size_t ks_align(size_t v) { return (v + 255) & ~(size_t)255; }
 
@@ -857,7 +865,7 @@ template <int K, typename I, typename T> static void ks_launch_exact(const KsArg
     const int wcols = a.N < 256 * KX_NU ? a.N : 256 * KX_NU;
     int chc = 32;
     while (chc > 1 && (size_t)chc * wcols * sizeof(T) > KX_CHUNK) chc >>= 1;
-    const size_t lds_x = (size_t)2 * KX_CHUNK + (size_t)KX_QG * a.C * 4 + (size_t)a.N * 4;
+    const size_t lds_x = kx_front_bytes(K, a.C) + (size_t)a.N * 4;
     (void)hipFuncSetAttribute((const void *)knn_exact_clip_kernel<K, I, T>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds_x);
     hipLaunchKernelGGL((knn_exact_clip_kernel<K, I, T>), dim3(a.B), dim3(256), lds_x, s, (const T *)a.x, a.sb, a.sc, a.den,

@@ -341,12 +341,13 @@ def shard_range(n, rank, world):
 class ShardedFlatL2Index:
     """Row-sharded exact search: every rank holds rows shard_range(n, rank, world) of the database.
     search(q, k): local top-k (ids offset by the shard start) -> all-gather of (nq, k) dist+ids -> merge.
-    `local_index_factory(id_base)` and `merge_fn(part_d, part_i)` default to the HIP implementations."""
+    `local_index_factory(id_base)`, `merge_fn(part_d, part_i)` and `rerank_fn` (signature of ops.seq_rerank) default to
+    the HIP implementations; the gloo tests inject the oracle's, as for the loss."""
 
-    def __init__(self, d=128, group=None, local_index_factory=None, merge_fn=None, halo=63):
+    def __init__(self, d=128, group=None, local_index_factory=None, merge_fn=None, halo=63, rerank_fn=None):
         self.d, self.group = d, group
         self.rank, self.world = rank_of(group), world_size(group)
-        self._factory, self._merge = local_index_factory, merge_fn
+        self._factory, self._merge, self._rerank = local_index_factory, merge_fn, rerank_fn
         self.local = None
         self.ntotal = 0
         self.halo = int(halo)          # rows of the NEXT shard kept after the own rows: sequences stay local (rerank)
@@ -385,7 +386,9 @@ class ShardedFlatL2Index:
         row it owns (its rows + halo make those sequences local), then one all-gather of the (n_items, top) lists
         and a merge by (score descending, id ascending).  q_rows / topk_ids are the replicated query segments and the
         merged GLOBAL search results; returns (ids, scores) like ops.seq_rerank."""
-        from . import ops
+        if self._rerank is None:
+            from . import ops
+            self._rerank = ops.seq_rerank
         dev = self.local.device
         rows = self.local.rows()
         if self._halo_rows is not None and len(self._halo_rows):
@@ -400,9 +403,9 @@ class ShardedFlatL2Index:
         known = not torch.is_tensor(item_len) and not torch.is_tensor(item_row)
         if known and (int(np.max(np.asarray(item_row) + np.asarray(item_len))) > len(q_rows) or int(np.min(item_row)) < 0):
             raise ValueError("seq_rerank: an item reaches outside q_rows")
-        ids, sc = ops.seq_rerank(rows, as_t(q_rows, torch.float32), as_t(topk_ids, torch.int64),
-                                 as_t(item_row, torch.int64), item_len_t, top=top,
-                                 shard=(self.lo, self.ntotal, self.lo, self.hi), max_len=max_len if known else None)
+        ids, sc = self._rerank(rows, as_t(q_rows, torch.float32), as_t(topk_ids, torch.int64),
+                               as_t(item_row, torch.int64), item_len_t, top=top,
+                               shard=(self.lo, self.ntotal, self.lo, self.hi), max_len=max_len if known else None)
         if self.world == 1:
             return ids, sc
         n_items = ids.shape[0]

@@ -147,18 +147,48 @@ class IVFPQIndex:
         qt = torch.as_tensor(np.ascontiguousarray(q) if as_numpy else q).to(self.device, torch.float32).reshape(-1, self.d)
         qt = qt.contiguous()
         nq = qt.shape[0]
-        if not 1 <= k <= 32:
-            raise ValueError("IVFPQIndex.search: 1 <= k <= 32 (GRAFP_SEARCH_MAX_K), as for the exact index")
+        k = int(k)
+        if k < 1:
+            raise ValueError("IVFPQIndex.search: k >= 1")
         D = torch.full((nq, k), float("inf"), device=self.device)
         I = torch.full((nq, k), -1, dtype=torch.int64, device=self.device)
         if self.ntotal and nq:
-            codes, ids, start, _counts = self._materialise()
+            codes, ids, start, counts = self._materialise()
             nprobe = max(1, min(int(self.nprobe), self.nlist))
             probe = torch.empty((nq, nprobe), dtype=torch.int32, device=self.device)
             stream = _stream()
             check(lib.grafp_ivfpq_probe_f32(_ptr(qt), nq, self.d, _ptr(self.centroids), self.nlist, nprobe, _ptr(probe),
                                             stream), "ivfpq_probe")
-            check(lib.grafp_ivfpq_search_f32(_ptr(qt), nq, self.d, _ptr(self.centroids), self.nlist, _ptr(self.codebooks),
-                                             self.M, _ptr(codes), _ptr(start), _ptr(ids), _ptr(probe), nprobe, k, _ptr(D),
-                                             _ptr(I), stream), "ivfpq_search")
+            if k <= 32:                                   # GRAFP_SEARCH_MAX_K: the running top-k lives in registers
+                check(lib.grafp_ivfpq_search_f32(_ptr(qt), nq, self.d, _ptr(self.centroids), self.nlist,
+                                                 _ptr(self.codebooks), self.M, _ptr(codes), _ptr(start), _ptr(ids),
+                                                 _ptr(probe), nprobe, k, _ptr(D), _ptr(I), stream), "ivfpq_search")
+            else:
+                self._search_dense(qt, k, probe, nprobe, codes, ids, start, counts, D, I, stream)
         return (D.cpu().numpy(), I.cpu().numpy()) if as_numpy else (D, I)
+
+    def _search_dense(self, qt, k, probe, nprobe, codes, ids, start, counts, D, I, stream, rows_per_pass=1024):
+        """k beyond the fused kernel's register list (the reference's k_probe is a free argument, eval.py:177): every
+        estimate of the probed lists through grafp_ivfpq_scan_f32 -- the same table and sub-space order as the fused
+        search, so the same floats -- then the k best by (distance, id) with two stable sorts.  Queries in passes that
+        bound the (rows x probed codes) scratch."""
+        nq = qt.shape[0]
+        for lo in range(0, nq, rows_per_pass):
+            qb, pb = qt[lo:lo + rows_per_pass], probe[lo:lo + rows_per_pass].contiguous()
+            lens = counts[pb.long()]
+            ostart = (torch.cumsum(lens, 1) - lens).contiguous()
+            stride = max(1, int(lens.sum(1).max().item()))
+            dist = torch.full((qb.shape[0], stride), float("inf"), device=self.device)
+            pos = torch.full((qb.shape[0], stride), -1, dtype=torch.int32, device=self.device)
+            check(lib.grafp_ivfpq_scan_f32(_ptr(qb), qb.shape[0], self.d, _ptr(self.centroids), self.nlist,
+                                           _ptr(self.codebooks), self.M, _ptr(codes), _ptr(start), _ptr(pb), nprobe,
+                                           _ptr(ostart), stride, _ptr(dist), _ptr(pos), stream), "ivfpq_scan")
+            have = pos >= 0
+            cid = torch.where(have, ids[pos.clamp_min(0).long()], torch.full_like(pos, -1, dtype=torch.int64))
+            key = torch.where(have, cid, torch.full_like(cid, torch.iinfo(torch.int64).max))
+            o1 = torch.argsort(key, dim=1, stable=True)                                # id ascending ...
+            d1, i1 = torch.gather(dist, 1, o1), torch.gather(cid, 1, o1)
+            o2 = torch.argsort(d1, dim=1, stable=True)[:, :k]                          # ... then distance, stable
+            kk = o2.shape[1]
+            D[lo:lo + qb.shape[0], :kk] = torch.gather(d1, 1, o2)
+            I[lo:lo + qb.shape[0], :kk] = torch.gather(i1, 1, o2)

@@ -795,26 +795,47 @@ def _xl_selfcheck(device):
     key = (device.type, device.index)
     if key in _XL_CHECKED or torch.cuda.is_current_stream_capturing():
         return
-    _XL_CHECKED.add(key)
     R, K, M = 256, 512, 4096
     info = (ctypes.c_int * 16)()
     lib.grafp_conv1x1_gemm_plan(R, K, 1, M, 1, info)
+    if info[0] != 5:                                   # GM_CFG_XL (gemm.hip): the plan rules moved, the check would be vacuous
+        raise RuntimeError(f"libgrafp_hip: the self-check product {R}x{K}x{M} is planned on tile configuration {info[0]}, not "
+                           "on the four-wave tile (5): update ops._xl_selfcheck together with gemm_plan")
     g = torch.Generator(device="cpu").manual_seed(0)
     w = (torch.randn(R, K, generator=g) / K ** 0.5).to(device, torch.bfloat16)
     x = torch.randn(K, M, generator=g).to(device, torch.bfloat16)
     tab = torch.tensor([1.0, 0.0], device=device).repeat(R, 1, 1).contiguous()            # (R, views = 1, 2): identity
     y, z = torch.empty((R, M), dtype=torch.bfloat16, device=device), torch.empty((R, M), dtype=torch.bfloat16, device=device)
+    ys = torch.empty((R, M), dtype=torch.bfloat16, device=device)
+    P = lib.grafp_conv1x1_gemm_partials(R, K, 1, M, 1)
+    part = torch.empty((R, 1, max(P, 1), 3), dtype=torch.float32, device=device)
     check(lib.grafp_conv1x1_gemm_bf16(_p(w), _p(x), R, K, 1, M, 1, None, 0, 0.0, _p(y), None, _stream()), "conv1x1_gemm")
+    check(lib.grafp_conv1x1_gemm_bf16(_p(w), _p(x), R, K, 1, M, 1, None, 0, 0.0, _p(ys), _p(part), _stream()),
+          "conv1x1_gemm")                                                                   # the <STATS> form of training
     check(lib.grafp_conv1x1_gemm_affine_bf16(_p(w), _p(x), R, K, 1, M, 1, _p(tab), 0, 0.0, _p(z), _stream()),
           "conv1x1_gemm_affine")
-    yf, zf = y.float(), z.float()
-    # (the two tiles may add the K chunks in another association: equal up to one bf16 rounding step on a few elements)
-    wrong = bool(((yf - zf).abs() > zf.abs() * 2.0 ** -7 + float(zf.abs().max()) * 2.0 ** -15).any())
-    if wrong or not bool(torch.isfinite(yf).all()) or float((yf != zf).float().mean()) > 5e-3:
-        bad = float((yf - zf).abs().max())
+    ones, zeros = torch.ones(R, device=device), torch.zeros(R, device=device)
+    # batch statistics out of the partial sums (training-mode finalize on scratch running statistics)
+    mean, invstd, _ = bn_finalize(part, R, K, 1, M, 1, ones, zeros, None, zeros.clone(), ones.clone(), True, 0.1, 1e-5)
+    zf = z.float()
+    zd = z.double()
+    want_mean, want_var = zd.mean(1), zd.var(1, unbiased=False)
+    what = None
+    for name, yf in (("product", y.float()), ("product with statistics", ys.float())):
+        # (the two tiles may add the K chunks in another association: equal up to one bf16 rounding step on a few elements)
+        wrong = bool(((yf - zf).abs() > zf.abs() * 2.0 ** -7 + float(zf.abs().max()) * 2.0 ** -15).any())
+        if wrong or not bool(torch.isfinite(yf).all()) or float((yf != zf).float().mean()) > 5e-3:
+            what = f"{name}: max |diff| {float((yf - zf).abs().max())}"
+    if what is None:
+        sd = want_var.sqrt()
+        if not bool(((mean[:, 0].double() - want_mean).abs() <= 1e-3 * sd + 1e-6).all()) or \
+                not bool(((invstd[:, 0].double() * (want_var + 1e-5).sqrt() - 1.0).abs() <= 2e-3).all()):
+            what = "statistics epilogue: batch mean / variance of the rounded outputs"
+    if what is not None:
         raise RuntimeError(f"libgrafp_hip: the four-wave GEMM tile disagrees with the eight-wave tile on a {R}x{K}x{M} product "
-                           f"(max |diff| {bad}): this build broke the register contract of gemm_xl.h -- rebuild with the "
+                           f"({what}): this build broke the register contract of gemm_xl.h -- rebuild with the "
                            "pinned toolchain (`make -C grafp_amd/csrc` runs tools/check_kernel_regs.py)")
+    _XL_CHECKED.add(key)                               # only a check that PASSED is remembered: a caught error re-raises
 
 
 def conv1x1_gemm(w, x, groups=1, views=1, pro_tab=None, pro_act=ACT_NONE, pro_slope=0.0, stats=False):
@@ -975,6 +996,7 @@ def flush_wgrad_reduce():
     ends and by whoever reads a gradient before that (dist.GradSync packs a bucket while backward is still running)."""
     global _WGRAD_PENDING
     q = _WGRAD_PENDING
+    _WGRAD_DEFERRED_IDS.clear()
     if not q:
         return
     _WGRAD_PENDING = []
@@ -1002,6 +1024,7 @@ def defer_wgrad_reduce():
         flush_wgrad_reduce()
     finally:
         _WGRAD_PENDING = None
+        _WGRAD_DEFERRED_IDS.clear()
 
 
 def _wgrad_bf16(g, x, cout, cin, groups, M, views=1, pro_tab=None, pro_act=ACT_NONE, pro_slope=0.0, tile=-1, may_defer=True):
@@ -1032,14 +1055,31 @@ def _wgrad_bf16(g, x, cout, cin, groups, M, views=1, pro_tab=None, pro_act=ACT_N
 conv1x1_wgrad = _wgrad_bf16
 
 
+_WGRAD_DEFERRED_IDS = set()  # weights whose gradient is queued unreduced in the running defer_wgrad_reduce() block
+
+
 def _may_defer(w):
     """A weight gradient may leave backward() with its split-K partial sums still unreduced (defer_wgrad_reduce) only if
     nothing can READ it before the flush: the weight is a leaf whose .grad is None (AccumulateGrad then takes the tensor
     over as it is -- with an existing .grad it would ADD the unreduced memory into it: gradient accumulation without
-    zero()) and it carries no tensor hook (a hook receives the gradient inside backward).  Post-accumulate hooks are
-    GradSync's, which flushes before it packs a bucket.  Everything else reduces immediately: slower, never wrong."""
-    return (w is not None and w.grad is None and not getattr(w, "_backward_hooks", None)
-            and not torch.is_grad_enabled())            # create_graph = True keeps grad mode on inside backward
+    zero()), it carries no tensor hook (a hook receives the gradient inside backward), every post-accumulate hook on it is
+    GradSync's (which flushes before it packs a bucket; anybody else's would read unreduced memory), and it is the FIRST
+    use of this weight in the pass (a weight shared by two layers gets its two gradients summed by autograd in front of
+    AccumulateGrad: the second one -- and with it the first, flushed -- must be reduced by then).  Everything else reduces
+    immediately: slower, never wrong."""
+    if w is None or w.grad is not None or getattr(w, "_backward_hooks", None) or torch.is_grad_enabled():
+        return False                                    # (create_graph = True keeps grad mode on inside backward)
+    hooks = getattr(w, "_post_accumulate_grad_hooks", None)
+    if hooks:
+        from .dist import GradSync
+        if not all(isinstance(getattr(h, "__self__", None), GradSync) for h in hooks.values()):
+            return False
+    if id(w) in _WGRAD_DEFERRED_IDS:
+        flush_wgrad_reduce()                            # the first use's partial sums: reduced before autograd adds the two
+        return False
+    if _WGRAD_PENDING is not None:
+        _WGRAD_DEFERRED_IDS.add(id(w))
+    return True
 
 
 class _ConvBnAct(torch.autograd.Function):

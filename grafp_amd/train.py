@@ -49,6 +49,9 @@ class Trainer:
         self._lr = torch.tensor(float(lr0), dtype=torch.float32, device=device) if on_gpu else None
         self.opt = torch.optim.Adam(model.parameters(), lr=self._lr if on_gpu else lr0, fused=on_gpu, capturable=on_gpu)
         self._graph = None                     # (hipGraph, static x_i, static x_j, static loss) once captured
+        # modules whose forward depends on .training (BatchNorm statistics, dropout): the short list step() looks at
+        self._mode_sensitive = [m for m in model.modules()
+                                if isinstance(m, (torch.nn.modules.batchnorm._BatchNorm, torch.nn.modules.dropout._DropoutNd))]
         self.sched = torch.optim.lr_scheduler.CosineAnnealingLR(self.opt, T_max=cfg["T_max"], eta_min=cfg["min_lr"])
         self.sync = gdist.GradSync(model.parameters(), group=group, n_buckets=n_buckets,
                                    force_flat=self._dp_graphs and self.world == 1)
@@ -62,7 +65,9 @@ class Trainer:
         """x_i, x_j: (B_local, T) waveforms already on the device.  Returns this rank's share of the loss
         (a 0-d device tensor; the shares sum to the global mean loss)."""
         self._rebind_lr()                      # a util.load_ckp(optimizer=trainer.opt) in between swapped the lr object
-        if not self.model.training:            # (Module.train() walks and re-assigns ~340 modules: 1.7 ms of host time per call)
+        # (Module.train() walks and re-assigns ~340 modules: 1.7 ms of host time per call -- only when something IS in eval
+        #  mode: the root, or one of the mode-sensitive modules under it, e.g. after model.encoder.eval() for fingerprinting)
+        if not self.model.training or not all(m.training for m in self._mode_sensitive):
             self.model.train()
         self.sync.zero()
         with torch.no_grad():

@@ -1,5 +1,7 @@
-"""World-size-2 gloo tests (CPU) of the data-parallel plumbing.  The compute step is injected (the oracle),
-because the product's kernels have no CPU path: what is under test is the collective logic of grafp_amd.dist."""
+"""World-size-2 and world-size-8 gloo tests (CPU) of the data-parallel plumbing.  The compute step is injected (the
+oracle), because the product's kernels have no CPU path: what is under test is the collective logic of grafp_amd.dist.
+World 8 is the layout of BASELINE config 3 / config 5 (/root/reference/train.py:69-71,165-168: eight replicas, global
+negatives; eval.py:285: candidate sequences across shard boundaries)."""
 import os
 import socket
 
@@ -42,9 +44,10 @@ def _worker(rank, world, port, out):
     r, w, dev = gdist.init_from_env(backend="gloo")
     assert (r, w, dev.type) == (rank, world, "cpu")
     torch.manual_seed(0)
+    torch.set_num_threads(1)
     res = {}
     # ---- global-negative NT-Xent: shares add up, local gradients are slices of the global gradient
-    B, D = 12, 32
+    B, D = (12 if world <= 4 else 3 * world), 32          # equal shares per rank (world 8: 24 pairs, 3 per rank)
     zi = torch.nn.functional.normalize(torch.from_numpy(hash_normalish("dist:zi", (B, D))), dim=1)
     zj = torch.nn.functional.normalize(torch.from_numpy(hash_normalish("dist:zj", (B, D))), dim=1)
     lo, hi = rank * B // world, (rank + 1) * B // world
@@ -148,6 +151,82 @@ def _worker(rank, world, port, out):
     res["search_local_ok"] = bool(np.array_equal(np.asarray(I2), wi) and np.array_equal(np.asarray(D2), wd))
     res["shard_rows"] = gdist.shard_range(1001, rank, world)
     res["search_ok"] = bool(np.array_equal(np.asarray(I), wi) and np.array_equal(np.asarray(D), wd))
+    # ---- the buckets follow the gradients' ARRIVAL order (rank 0's, broadcast) at this world size too: a module
+    #      registered last and applied first ends up in the last bucket on every rank, and the sums stay right
+    torch.manual_seed(7)
+    body = [torch.nn.Linear(16, 16) for _ in range(4)]
+    head, first = torch.nn.Linear(16, 16), torch.nn.Linear(16, 16)
+    mods = body + [head, first]
+    for m in mods:                                      # replicas start equal (seeded), as after a broadcast
+        for q_ in m.parameters():
+            dist.broadcast(q_.data, src=0)
+    prm = [q_ for m in mods for q_ in m.parameters()]
+
+    def fwd(ms, x):
+        x = ms[5](x)
+        for m in ms[:4]:
+            x = x + torch.relu(m(x))
+        return ms[4](x).square().sum()
+    sync3 = gdist.GradSync(prm, n_buckets=3, tail_numel=0)
+    twin = copy.deepcopy(torch.nn.ModuleList(mods))
+    ok, was_first = True, sync3._bucket_of[id(first.weight)]
+    for it in range(3):
+        sync3.zero()
+        x = torch.from_numpy(hash_normalish(f"dist:relay{rank}.{it}", (4, 16)))
+        fwd(mods, x).backward()
+        twin.zero_grad(); fwd(list(twin), x).backward()
+        sync3.finish()
+        for q_, t_ in zip(prm, twin.parameters()):
+            want = t_.grad.clone(); dist.all_reduce(want)
+            mag = t_.grad.abs(); dist.all_reduce(mag)             # gloo's ring adds the ranks' terms in another order
+            ok &= bool(((q_.grad - want).abs() <= 2e-6 * mag + 1e-12).all())         # per slice: a few ulps of sum |g_r|
+    layout = torch.tensor([sync3._bucket_of[id(q_)] for q_ in prm])
+    lay0 = layout.clone(); dist.broadcast(lay0, src=0)
+    res["relayout_ok"] = bool(ok and sync3._relaid and was_first == 0 and torch.equal(layout, lay0)
+                              and sync3._bucket_of[id(first.weight)] == len(sync3.bounds) - 1
+                              and sync3._bucket_of[id(head.weight)] == 0)
+    # ---- sharded sequence rerank (eval.py:272-290 over shard_range + halo): planted runs, one straddling EVERY shard
+    #      boundary; per-shard top lists merged == the unsharded rerank, ids and scores bit for bit
+    def oracle_rerank(rows, q_rows, topk_ids, item_row, item_len, top=10, shard=None, max_len=None):
+        row_base, n_total, id_lo, id_hi = shard
+        rows_np, ids_out, sc_out = rows.numpy(), [], []
+        assert row_base + len(rows_np) <= n_total
+        for r0, ql in zip(item_row.tolist(), item_len.tolist()):
+            tk = topk_ids[r0:r0 + ql].clone()
+            start = tk - torch.arange(ql)[:, None]
+            tk = torch.where((tk >= 0) & (start >= id_lo) & (start < id_hi), tk - row_base, torch.full_like(tk, -1))
+            own = start[(tk >= 0) & (start >= id_lo) & (start < id_hi)]
+            assert own.numel() == 0 or id_hi == n_total or int(own.max()) + ql <= row_base + len(rows_np)   # halo suffices
+            oi, os_ = native.seq_rerank(rows_np, q_rows[r0:r0 + ql].numpy(), tk.numpy(), [0], [ql], top=top)
+            ids_out.append(np.where(oi >= 0, oi + row_base, -1)); sc_out.append(os_)
+        return torch.from_numpy(np.concatenate(ids_out)), torch.from_numpy(np.concatenate(sc_out))
+
+    class OracleRows(OracleIndex):
+        device = torch.device("cpu")
+        def rows(self): return torch.from_numpy(self.x)
+    per = (len(db) + world - 1) // world
+    starts = sorted({3} | {min(len(db) - 11, b * per - 4) for b in range(1, world)} | {len(db) - 6})
+    qs = np.concatenate([np.concatenate([db[s0:s0 + 11], np.zeros((max(0, s0 + 11 - len(db)), 128), np.float32)])[:11]
+                         for s0 in starts]).astype(np.float32)
+    qs = qs + 0.05 * hash_normalish("dist:qs", qs.shape)
+    idx3 = gdist.ShardedFlatL2Index(128, local_index_factory=OracleRows, merge_fn=merge, halo=10,
+                                    rerank_fn=oracle_rerank)
+    idx3.add_global(db)
+    _, Iq = idx3.search(qs, 10)
+    item_row = np.repeat(np.arange(len(starts)) * 11, 3)
+    item_len = np.tile(np.array([1, 5, 11], np.int32), len(starts))
+    rid, rsc = idx3.rerank(qs, Iq, item_row, item_len, top=10)
+    _, wIq = native.flat_search_l2(db, qs, 10)
+    wid, wsc = native.seq_rerank(db, qs, wIq, item_row, item_len, top=10)
+    res["rerank_ok"] = bool(np.array_equal(rid.numpy(), wid) and np.array_equal(rsc.numpy(), wsc)
+                            and np.array_equal(np.asarray(Iq), wIq)
+                            and np.array_equal(wid[2::3, 0], np.asarray(starts)))       # the planted 11-runs found
+    try:
+        idx3.halo = 9                                   # 11-segment items need 10 halo rows
+        idx3.rerank(qs, Iq, item_row, item_len, top=10)
+        res["rerank_halo_guard"] = world == 1
+    except ValueError:
+        res["rerank_halo_guard"] = True
     out[rank] = res
     dist.barrier()
     dist.destroy_process_group()
@@ -162,8 +241,28 @@ def test_world_size_2_gloo():
     assert set(res) == {0, 1}
     for rank, r in res.items():
         assert r["loss_ok"] and r["grad_ok"] and r["gradsync_0"] and r["gradsync_1"] and r["search_ok"] and r["search_local_ok"] and \
-            r["gradsync_after_failed_backward"] and r["gradsync_partial_step"], (rank, r)
+            r["gradsync_after_failed_backward"] and r["gradsync_partial_step"] and r["relayout_ok"] and r["rerank_ok"] and \
+            r["rerank_halo_guard"], (rank, r)
     assert res[0]["shard_rows"] == (0, 501) and res[1]["shard_rows"] == (501, 1001)
+
+
+def test_world_size_8_gloo():
+    """The 8-rank layout of BASELINE configs 3 and 5, once, on gloo: rank-major all-gather of the stacked (z_i, z_j) and
+    row_begin = rank * B_loc (shares add up, local gradients are slices of the global gradient); the flat-buffer SUM
+    with buckets fired from hooks; the arrival-order re-layout broadcast from rank 0; 8-way shard_range + merge ==
+    unsharded search; sequence rerank with a planted run across every one of the 7 shard boundaries
+    (/root/reference/train.py:69-71,165-168; eval.py:269-290)."""
+    world, port = 8, _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+        res = dict(out)
+    assert set(res) == set(range(8))
+    for rank, r in res.items():
+        assert all(r[k] for k in ("loss_ok", "grad_ok", "gradsync_0", "gradsync_1", "search_ok", "search_local_ok",
+                                  "gradsync_after_failed_backward", "gradsync_partial_step", "relayout_ok", "rerank_ok",
+                                  "rerank_halo_guard")), (rank, {k: v for k, v in r.items() if v is not True})
+    assert [res[r]["shard_rows"] for r in range(8)] == [(126 * r, min(1001, 126 * (r + 1))) for r in range(8)]
 
 
 def test_single_process_paths():

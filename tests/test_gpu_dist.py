@@ -101,16 +101,16 @@ def test_two_ranks_match_one_process(tmp_path):
     assert (wid[:, 0].cpu().reshape(4, 3) == starts[:, None]).all()          # planted runs found, across the boundary
 
 
-def test_two_ranks_at_128_pairs_per_rank(tmp_path):
-    """The per-GPU shape of BASELINE config 3 (128 pairs per rank) on two ranks: global-negative loss shares, summed
-    gradients and their norm against ONE process pushing the two shards through the model one after the other."""
+def _ranks_against_one_process(tmp_path, world, B, tag):
+    """`world` ranks on cuda:0 over gloo, B // world pairs each, against ONE process pushing the shards through the model
+    one after the other (per-replica BatchNorm statistics, as under the reference's DataParallel, train.py:165-168) with
+    the loss over the concatenated batch (train.py:69-71)."""
     from grafp_amd.simclr.ntxent import ntxent_loss
     from grafp_amd.train import Trainer, build_model, synthetic_batch
     from grafp_amd.util import load_config
-    B = 256
-    out = str(tmp_path / "w2big")
-    _launch(2, out, B)
-    got = [torch.load(f"{out}.{r}.pt", weights_only=False) for r in range(2)]
+    out = str(tmp_path / tag)
+    _launch(world, out, B)
+    got = [torch.load(f"{out}.{r}.pt", weights_only=False) for r in range(world)]
     device = torch.device("cuda:0")
     cfg = load_config()
     cfg["bsz_train"] = B
@@ -119,25 +119,61 @@ def test_two_ranks_at_128_pairs_per_rank(tmp_path):
     trainer = Trainer(cfg, model, device, amp_dtype=None)
     x_i, x_j = synthetic_batch(B, 7, device)
     model.train()
+    per = B // world
     zs_i, zs_j = [], []
-    for lo in (0, B // 2):
+    for r in range(world):
         with torch.no_grad():
-            X_i, X_j = trainer.augment(x_i[lo:lo + B // 2], x_j[lo:lo + B // 2])
+            X_i, X_j = trainer.augment(x_i[r * per:(r + 1) * per], x_j[r * per:(r + 1) * per])
         _, _, z_i, z_j = model(X_i, X_j)
         zs_i.append(z_i); zs_j.append(z_j)
     loss = ntxent_loss(torch.cat(zs_i), torch.cat(zs_j), cfg)
     loss.backward()
-    for r in range(2):
-        assert torch.allclose(got[r]["z_i"], zs_i[r].detach().cpu(), rtol=0, atol=1e-6)
+    for r in range(world):
+        assert got[r]["z_i"].shape == (per, zs_i[r].shape[1])
+        assert torch.allclose(got[r]["z_i"], zs_i[r].detach().cpu(), rtol=0, atol=1e-6), r
     loss_v = float(loss.detach())
-    assert abs(got[0]["loss_share"] + got[1]["loss_share"] - loss_v) <= 1e-5 * max(1.0, abs(loss_v))
+    assert abs(sum(g["loss_share"] for g in got) - loss_v) <= 1e-5 * max(1.0, abs(loss_v))
     params = dict(model.named_parameters())
     for name, g in got[0]["grads"].items():
         want = params[name].grad.detach().float().cpu()
         assert (g - want).norm() / want.norm().clamp_min(1e-12) < 2e-4, name
-        assert torch.equal(g, got[1]["grads"][name])
+        for r in range(1, world):
+            assert torch.equal(g, got[r]["grads"][name]), (name, r)    # every rank holds the same reduced gradient
     want_norm = torch.sqrt(sum((p.grad.float() ** 2).sum() for p in model.parameters() if p.grad is not None)).item()
-    assert abs(got[0]["grad_norm"] - want_norm) <= 2e-4 * want_norm
+    for r in range(world):
+        assert abs(got[r]["grad_norm"] - want_norm) <= 2e-4 * want_norm
+    return got, device
+
+
+def test_two_ranks_at_128_pairs_per_rank(tmp_path):
+    """The per-GPU shape of BASELINE config 3 (128 pairs per rank) on two ranks: global-negative loss shares, summed
+    gradients and their norm against ONE process pushing the two shards through the model one after the other."""
+    _ranks_against_one_process(tmp_path, 2, 256, "w2big")
+
+
+def test_eight_ranks_at_128_pairs_per_rank(tmp_path):
+    """BASELINE config 3 exactly -- global batch 1024 on EIGHT ranks of 128 pairs -- with all eight processes on cuda:0
+    over gloo (288 GB holds eight replicas; RCCL needs eight devices, everything around the collectives is the production
+    code): the rank-major all-gather of 8 x (2, 128, 128) embeddings, row_begin = rank * 128 against 2046 global
+    negatives per row, the SUM of eight flat gradient buffers in arrival-order buckets, and 8-way shard_range + merge +
+    halo rerank on the retrieval side (/root/reference/train.py:69-71,165-168; eval.py:269-290)."""
+    from grafp_amd import ops
+    got, device = _ranks_against_one_process(tmp_path, 8, 1024, "w8")
+    gen = torch.Generator().manual_seed(3)
+    db = torch.nn.functional.normalize(torch.randn(5000, 128, generator=gen), dim=1)
+    q = torch.nn.functional.normalize(db[::97][:20] + 0.05 * torch.randn(20, 128, generator=gen), dim=1)
+    dbd = db.to(device)
+    D, I = ops.search_l2(dbd, ops.row_sqnorm(dbd), q.to(device), 10)
+    starts = torch.tensor([40, 2495, 3100, 4989])                       # 2495..2505 straddles the shard boundary at 2500
+    qs = torch.cat([db[s0:s0 + 11] for s0 in starts.tolist()])
+    qs = torch.nn.functional.normalize(qs + 0.05 * torch.randn(qs.shape, generator=gen), dim=1).to(device)
+    _, Iq = ops.search_l2(dbd, ops.row_sqnorm(dbd), qs, 10)
+    item_row = (torch.arange(4).repeat_interleave(3) * 11).to(device)
+    item_len = torch.tensor([1, 5, 11] * 4, dtype=torch.int32, device=device)
+    wid, wsc = ops.seq_rerank(dbd, qs, Iq, item_row, item_len, top=10)
+    for r in range(8):
+        assert torch.equal(got[r]["I"], I.cpu()) and torch.equal(got[r]["D"], D.cpu()), r
+        assert torch.equal(got[r]["rid"], wid.cpu()) and torch.equal(got[r]["rsc"], wsc.cpu()), r
 
 
 def test_step_graph_data_parallel(tmp_path):

@@ -407,6 +407,27 @@ def test_deferred_reduction_only_when_nothing_can_read_the_gradient_first():
     w2 = w0.clone().requires_grad_(True)
     assert backward(w2, hook=lambda g: seen.append(g.clone())) == 0
     assert torch.equal(seen[0], once) and torch.equal(w2.grad, once)
+    # a post-accumulate hook that is not GradSync's reads .grad inside backward -> reduced immediately
+    seen_post = []
+    w3 = w0.clone().requires_grad_(True)
+    w3.register_post_accumulate_grad_hook(lambda p: seen_post.append(p.grad.clone()))
+    assert backward(w3) == 0
+    assert torch.equal(seen_post[0], once) and torch.equal(w3.grad, once)
+    # ... and ONE weight used by two layers of the same pass: autograd adds the two gradients in front of AccumulateGrad,
+    # so the second use reduces at once and flushes the first
+    w4 = w0.clone().requires_grad_(True)
+    rm, rv = torch.zeros(R, device=DEV), torch.ones(R, device=DEV)
+    x2 = _rand((K, M), 64, 1.0, 0.2)
+    za = ops.conv_bn_act(x, w4, gamma, beta, rm.clone(), rv.clone(), True, act=ops.ACT_RELU)
+    zb = ops.conv_bn_act(x2, w4, gamma, beta, rm.clone(), rv.clone(), True, act=ops.ACT_RELU)
+    with ops.defer_wgrad_reduce():
+        ((za.float() + zb.float()) * up).sum().backward()
+        assert len(ops._WGRAD_PENDING) == 0
+    w5 = w0.clone().requires_grad_(True)
+    zb5 = ops.conv_bn_act(x2, w5, gamma, beta, rm.clone(), rv.clone(), True, act=ops.ACT_RELU)
+    (zb5.float() * up).sum().backward()
+    assert torch.allclose(w4.grad, once + w5.grad, rtol=1e-6, atol=1e-6 * float(once.abs().max()))
+    assert not ops._WGRAD_DEFERRED_IDS
 
 
 @pytest.mark.parametrize("R,K,M", [(64, 64, 8192), (256, 64, 16384), (64, 256, 131072), (1024, 256, 4096), (512, 2048, 1024),

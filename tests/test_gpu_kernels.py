@@ -1143,8 +1143,18 @@ def test_ivfpq_index_vs_oracle_and_exact(dev):
     few.nprobe = 4
     Df, If = few.search(x[:2], 10)
     assert (If[:, 3:] == -1).all() and np.isinf(Df[:, 3:]).all() and sorted(If[0, :3]) == [0, 1, 2]
-    with pytest.raises(ValueError):                                                      # k <= 32, as for the exact index
-        idx.search(q, 33)
+    # k beyond the fused kernel's register list (the reference's k_probe is a free argument, eval.py:177): the dense scan
+    # + selection route returns the C oracle's lists too, and its first 20 columns are the fused kernel's
+    D50, I50 = idx.search(q, 50)
+    Dc50, Ic50 = native.ivfpq_search(q, cent, books, codes_g[order], start, order, probe_o, 50)
+    assert np.array_equal(I50, Ic50) and np.array_equal(D50, Dc50)
+    assert np.array_equal(I50[:, :20], I) and np.array_equal(D50[:, :20], D)
+    Df40, If40 = few.search(x[:2], 40)                                                   # fewer candidates than k, dense route
+    assert (If40[:, 3:] == -1).all() and np.isinf(Df40[:, 3:]).all() and np.array_equal(If40[:, :3], If[:, :3])
+    Dd40, Id40 = dup.search(x[:3], 35)                                                   # ties: lowest id first there too
+    assert np.array_equal(Id40[:, :32], Id) and np.array_equal(Dd40[:, :32], Dd) and (Id40[:, 35 - 1] >= -1).all()
+    with pytest.raises(ValueError):
+        idx.search(q, 0)
     # torch tensors in, tensors out
     Dt, It = idx.search(torch.from_numpy(q[:3]).to(dev), 4)
     assert Dt.is_cuda and torch.equal(It.cpu(), torch.from_numpy(I[:3, :4]))
