@@ -34,7 +34,7 @@ template <> struct BnIO<float> {
     __device__ static void store(float *p, const float (&v)[4]) {
         typedef float f4 __attribute__((ext_vector_type(4)));
         const f4 t = {v[0], v[1], v[2], v[3]};
-        __builtin_nontemporal_store(t, reinterpret_cast<f4 *>(p));
+        GRAFP_ST_NT(t, reinterpret_cast<f4 *>(p));
     }
     using Raw = float4;
     __device__ static void unpack(const float4 &t, float (&v)[4]) { v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
@@ -71,7 +71,7 @@ template <> struct BnIO<unsigned short> {
         }
         typedef unsigned u4 __attribute__((ext_vector_type(4)));
         const u4 t = {w[0], w[1], w[2], w[3]};
-        __builtin_nontemporal_store(t, reinterpret_cast<u4 *>(p));
+        GRAFP_ST_NT(t, reinterpret_cast<u4 *>(p));
     }
     using Raw = uint4;
     __device__ static void unpack(const uint4 &t, float (&v)[8]) {

@@ -32,6 +32,15 @@ __device__ __forceinline__ int mfma_row(int reg, int half) { return (reg & 3) + 
 
 }  // namespace grafp
 
+// Streaming (non-temporal) store of a result row piece: the consumer is a later launch and the producers' working set
+// should keep the caches.  GRAFP_PLAIN_STORES (an experiment build: make measure XFLAGS=-DGRAFP_PLAIN_STORES) turns every
+// one of them into a plain store for the A/B of tools/step_ab.py at Infinity-Cache-resident tensor sizes.
+#ifdef GRAFP_PLAIN_STORES
+#define GRAFP_ST_NT(v, p) (*(p) = (v))
+#else
+#define GRAFP_ST_NT(v, p) __builtin_nontemporal_store(v, p)
+#endif
+
 #define GRAFP_REQUIRE(cond, ...)              \
     do {                                      \
         if (!(cond)) {                        \

@@ -413,7 +413,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::NW == 4 ? 2 : 1) void conv1x1_ge
                             for (int rg = 0; rg < 4; ++rg) {
                                 const f32x4 v = {acc[mi][ri][4 * rg + 0], acc[mi][ri][4 * rg + 1], acc[mi][ri][4 * rg + 2],
                                                  acc[mi][ri][4 * rg + 3]};
-                                __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(y32 + mi * 32 + 8 * rg + 4 * half));
+                                GRAFP_ST_NT(v, reinterpret_cast<f32x4 *>(y32 + mi * 32 + 8 * rg + 4 * half));
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) acc[mi][ri][4 * rg + e] = 0.0f;
                             }
@@ -492,7 +492,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::NW == 4 ? 2 : 1) void conv1x1_ge
                             const int r = r0 + wr * 32 * RT + ri * 32 + h * OR + row;
                             const gm_u32x4 vv = {v.x, v.y, v.z, v.w};
                             // streaming (nt) stores of Y: -10 ... 15 % on the family against plain stores
-                            __builtin_nontemporal_store(vv, reinterpret_cast<gm_u32x4 *>(Y + (size_t)r * M + mcol + p16 * 8));
+                            GRAFP_ST_NT(vv, reinterpret_cast<gm_u32x4 *>(Y + (size_t)r * M + mcol + p16 * 8));
                         }
                     }
                 }
@@ -726,7 +726,7 @@ __global__ __launch_bounds__(256) void bn_affine_bf16_kernel(const unsigned shor
         }
         typedef unsigned u4 __attribute__((ext_vector_type(4)));
         const u4 t = {o[0], o[1], o[2], o[3]};
-        __builtin_nontemporal_store(t, reinterpret_cast<u4 *>(dst));
+        GRAFP_ST_NT(t, reinterpret_cast<u4 *>(dst));
     };
     while (full) {
 #pragma unroll

@@ -272,7 +272,7 @@ __global__ __launch_bounds__(GemmXL::THREADS, 1) void conv1x1_gemm_xl_kernel(
     auto slice_store = [&](int slot, int it, char *ub) __attribute__((always_inline)) {
         const gm_u32x4 vv = sv[slot & 1];
         if (!(ABL & 2) || (vv[0] == 0x12345678u && it == 7))
-            __builtin_nontemporal_store(vv, reinterpret_cast<gm_u32x4 *>(ub + y_lane));
+            GRAFP_ST_NT(vv, reinterpret_cast<gm_u32x4 *>(ub + y_lane));
     };
     const int64_t y_rowstep = 8 * M;                         // bytes between the row groups of two consecutive stores
 

@@ -62,12 +62,12 @@ __device__ __forceinline__ unsigned mr_pack(float lo, float hi) {
 __device__ __forceinline__ void mr_st4(float *p, const float (&v)[4]) {
     typedef float f4 __attribute__((ext_vector_type(4)));
     const f4 t = {v[0], v[1], v[2], v[3]};
-    __builtin_nontemporal_store(t, reinterpret_cast<f4 *>(p));
+    GRAFP_ST_NT(t, reinterpret_cast<f4 *>(p));
 }
 __device__ __forceinline__ void mr_st4(unsigned short *p, const float (&v)[4]) {
     typedef unsigned u2 __attribute__((ext_vector_type(2)));
     const u2 t = {mr_pack(v[0], v[1]), mr_pack(v[2], v[3])};
-    __builtin_nontemporal_store(t, reinterpret_cast<u2 *>(p));
+    GRAFP_ST_NT(t, reinterpret_cast<u2 *>(p));
 }
 
 // The backward scatter accumulates in 64-bit FIXED POINT with integer LDS atomics (ds_add_f32 runs at 0.33 lane-ops per
