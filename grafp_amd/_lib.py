@@ -92,6 +92,7 @@ SIGNATURES = {
     "grafp_conv1x1_wgrad_tile_bf16": (_I, [_P, _P, _I, _I, _I, _L, _I, _P, _I, _F, _I, _P, _P, _Z, _P]),
     "grafp_conv1x1_wgrad_partials_bf16": (_I, [_P, _P, _I, _I, _I, _L, _I, _P, _I, _F, _I, _P, _Z, _P, _P]),
     "grafp_wgrad_reduce_multi": (_I, [_P, _P, _P, _P, _I, _P]),
+    "grafp_adam_multi_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _c.c_double, _c.c_double, _c.c_double, _c.c_double, _P]),
     "grafp_conv1x1_wgrad_f32_workspace": (_Z, [_I, _I, _I, _L]),
     "grafp_conv1x1_wgrad_f32": (_I, [_P, _P, _I, _I, _I, _L, _P, _P, _Z, _P]),
     "grafp_ntxent_workspace": (_Z, [_I]),

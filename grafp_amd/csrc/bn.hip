@@ -15,6 +15,7 @@
 
 #include <type_traits>
 
+#define GRAFP_STORE_FAMILY 1        // (common.h: GRAFP_ST_NT experiment builds)
 #include "common.h"
 #include "tuning.h"
 
@@ -31,10 +32,11 @@ template <> struct BnIO<float> {
     }
     // outputs are streamed with the non-temporal hint: a plain-store copy of a 67-268 MB tensor runs at 3.7-4.9 TB/s
     // on MI355X, the same copy with `nt` stores at 6.2-6.7 TB/s (tools/microbench/copy_bench.hip)
-    __device__ static void store(float *p, const float (&v)[4]) {
+    __device__ static void store(float *p, const float (&v)[4], bool plain = false) {
         typedef float f4 __attribute__((ext_vector_type(4)));
         const f4 t = {v[0], v[1], v[2], v[3]};
-        GRAFP_ST_NT(t, reinterpret_cast<f4 *>(p));
+        if (plain) store16_hint(p, __builtin_bit_cast(st_u32x4, t), true);      // (wave-uniform: see bn_plain_stores)
+        else GRAFP_ST_NT(t, reinterpret_cast<f4 *>(p));
     }
     using Raw = float4;
     __device__ static void unpack(const float4 &t, float (&v)[4]) { v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
@@ -58,7 +60,7 @@ template <> struct BnIO<unsigned short> {
             v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
         }
     }
-    __device__ static void store(unsigned short *p, const float (&v)[8]) {
+    __device__ static void store(unsigned short *p, const float (&v)[8], bool plain = false) {
         // v_cvt_pk_bf16_f32 (round to nearest even, the conversion the GEMM epilogues use): one instruction per PAIR instead
         // of the six of the integer form per value -- a seventh of this file's backward kernel's vector instructions
         typedef float f2 __attribute__((ext_vector_type(2)));
@@ -71,7 +73,8 @@ template <> struct BnIO<unsigned short> {
         }
         typedef unsigned u4 __attribute__((ext_vector_type(4)));
         const u4 t = {w[0], w[1], w[2], w[3]};
-        GRAFP_ST_NT(t, reinterpret_cast<u4 *>(p));
+        if (plain) store16_hint(p, __builtin_bit_cast(st_u32x4, t), true);
+        else GRAFP_ST_NT(t, reinterpret_cast<u4 *>(p));
     }
     using Raw = uint4;
     __device__ static void unpack(const uint4 &t, float (&v)[8]) {
@@ -85,6 +88,18 @@ template <> struct BnIO<unsigned short> {
     __device__ static float ld1(const unsigned short *p) { return __uint_as_float(((unsigned)*p) << 16); }
     __device__ static void st1(unsigned short *p, float v) { *p = f2bf(v); }
 };
+
+// dY of the BatchNorm backward is read twice by the two launches that follow it (data gradient and weight gradient of
+// the convolution in front).  A tensor that fits the 256 MB Infinity Cache with room for the other operand is written
+// with PLAIN stores (it stays cached for its two readers); larger ones keep the streaming hint, which wins there by
+// sparing the producers' working set.  Same-box A/B of the whole step (tools/step_lib_ab.py, profiles/r06_c_*, r06_d_*):
+// plain stores in this file -1.15 % at 128 pairs, -1.05 % at 256, +0.45 % at 512, +1.2 % at 1024; the threshold between
+// them from tools/step_env_graph_ab.py (profiles/r06_e_bn_plain_threshold.txt: tensors up to 70 / 140 / 280 MB / all
+// plain: 128 pairs -0.8 / -0.7 / -0.8 / -0.8 %, 256 pairs -0.8 / -1.2 / -0.6 / -0.7 %, 512 pairs +0.2 / -0.1 / +0.8 /
+// +1.1 %): 140 MB.  A pure function of the tensor size.
+static int bn_plain_stores(size_t bytes) {
+    return bytes <= ((size_t)GRAFP_TUNE_INT("GRAFP_BN_BWD_PLAIN_MAX_MB", 140) << 20) ? 1 : 0;
+}
 
 template <int THREADS = 256>
 __device__ __forceinline__ float2 block_sum2(float a, float b, float2 *scratch, int tid) {
@@ -618,7 +633,8 @@ __global__ __launch_bounds__(THREADS) void bn_bwd1_kernel(const T *__restrict__ 
                                                              float slope,
                                                              int *__restrict__ sync, T *__restrict__ dx,
                                                              float *__restrict__ dgamma, float *__restrict__ dbeta,
-                                                             float *__restrict__ dpre_bias, int spin_limit) {
+                                                             float *__restrict__ dpre_bias, int spin_limit,
+                                                             int plain_stores) {
     constexpr int W = BnIO<T>::W, CHUNK = THREADS * ITEMS * W;
     __shared__ float2 scratch[THREADS / 64];
     __shared__ float2 sp[BN1_MAX_S];
@@ -736,7 +752,7 @@ __global__ __launch_bounds__(THREADS) void bn_bwd1_kernel(const T *__restrict__ 
                 const float dy = __builtin_fmaf(v[i], zg, zoff) > 0.0f ? d[i] : d[i] * neg;
                 v[i] = __builtin_fmaf(xh, km2, __builtin_fmaf(dy, k, km1));
             }
-            BnIO<T>::store(orow + m, v);
+            BnIO<T>::store(orow + m, v, plain_stores != 0);
         }
     }
     if (tid == 0) bn1_rearm(checkout, S, counter, slots_row);
@@ -888,6 +904,7 @@ extern "C" int grafp_bn_bwd_1pass(const void *x, const void *dz, int dtype, int 
         // operands fenced across the wait -- bn_opaque -- this variant needs 122 VGPRs, 4 workgroups per CU)
         int items = BN1_ITEMS_BWD;
         int Sg = ok ? bn1_plan(Mg, G, f32 ? 4 : 8, items) : 0;
+        const int plain = bn_plain_stores((size_t)C * (size_t)M * (f32 ? 4 : 2));
         const int items8_from = GRAFP_TUNE_INT("GRAFP_BN_BWD_ITEMS8_FROM", 16);
         if (ok && !f32 && (Sg == 0 || Sg * G > items8_from)) {
             items = 2 * BN1_ITEMS_BWD;
@@ -905,7 +922,7 @@ extern "C" int grafp_bn_bwd_1pass(const void *x, const void *dz, int dtype, int 
                 hipLaunchKernelGGL((bn_bwd1_kernel<unsigned short, 2 * BN1_ITEMS_BWD, 512>), grid2, dim3(512), 0, s,
                                    (const unsigned short *)x, (const unsigned short *)dz, M, Mg, Sg2, G, pre_bias, gamma,
                                    beta, save_mean, save_invstd, act, slope, (int *)sync, (unsigned short *)dx,
-                                   dgamma, dbeta, dpre_bias, spin);
+                                   dgamma, dbeta, dpre_bias, spin, plain);
                 GRAFP_CHECK_LAUNCH("bn_bwd1_kernel");
                 return GRAFP_OK;
             }
@@ -915,17 +932,17 @@ extern "C" int grafp_bn_bwd_1pass(const void *x, const void *dz, int dtype, int 
             if (f32)
                 hipLaunchKernelGGL((bn_bwd1_kernel<float, BN1_ITEMS_BWD>), grid, dim3(BN1_THREADS), 0, s, (const float *)x,
                                    (const float *)dz, M, Mg, Sg, G, pre_bias, gamma, beta, save_mean, save_invstd, act,
-                                   slope, (int *)sync, (float *)dx, dgamma, dbeta, dpre_bias, spin);
+                                   slope, (int *)sync, (float *)dx, dgamma, dbeta, dpre_bias, spin, plain);
             else if (items == BN1_ITEMS_BWD)
                 hipLaunchKernelGGL((bn_bwd1_kernel<unsigned short, BN1_ITEMS_BWD>), grid, dim3(BN1_THREADS), 0, s,
                                    (const unsigned short *)x, (const unsigned short *)dz, M, Mg, Sg, G, pre_bias, gamma,
                                    beta, save_mean, save_invstd, act, slope, (int *)sync, (unsigned short *)dx,
-                                   dgamma, dbeta, dpre_bias, spin);
+                                   dgamma, dbeta, dpre_bias, spin, plain);
             else
                 hipLaunchKernelGGL((bn_bwd1_kernel<unsigned short, 2 * BN1_ITEMS_BWD>), grid, dim3(BN1_THREADS), 0, s,
                                    (const unsigned short *)x, (const unsigned short *)dz, M, Mg, Sg, G, pre_bias, gamma,
                                    beta, save_mean, save_invstd, act, slope, (int *)sync, (unsigned short *)dx,
-                                   dgamma, dbeta, dpre_bias, spin);
+                                   dgamma, dbeta, dpre_bias, spin, plain);
             GRAFP_CHECK_LAUNCH("bn_bwd1_kernel");
             return GRAFP_OK;
         }

@@ -33,13 +33,34 @@ __device__ __forceinline__ int mfma_row(int reg, int half) { return (reg & 3) + 
 }  // namespace grafp
 
 // Streaming (non-temporal) store of a result row piece: the consumer is a later launch and the producers' working set
-// should keep the caches.  GRAFP_PLAIN_STORES (an experiment build: make measure XFLAGS=-DGRAFP_PLAIN_STORES) turns every
-// one of them into a plain store for the A/B of tools/step_ab.py at Infinity-Cache-resident tensor sizes.
-#ifdef GRAFP_PLAIN_STORES
+// should keep the caches.  Experiment builds (make measure XFLAGS=-DGRAFP_PLAIN_STORES=f MLIB=... MDIR=...) turn them
+// into plain stores for the A/B of tools/step_lib_ab.py at Infinity-Cache-resident tensor sizes: f = 9 everywhere, or
+// only in the family whose source defines GRAFP_STORE_FAMILY = f (1 BatchNorm, 2 products, 3 max-relative).
+#ifndef GRAFP_STORE_FAMILY
+#define GRAFP_STORE_FAMILY 0
+#endif
+#if defined(GRAFP_PLAIN_STORES) && (GRAFP_PLAIN_STORES == 9 || GRAFP_PLAIN_STORES == GRAFP_STORE_FAMILY)
 #define GRAFP_ST_NT(v, p) (*(p) = (v))
 #else
 #define GRAFP_ST_NT(v, p) __builtin_nontemporal_store(v, p)
 #endif
+
+// A result store whose hint is chosen at RUN time (a wave-uniform flag from the launch plan): `plain` = an ordinary store
+// (the tensor fits the Infinity Cache and its readers are the next launches), otherwise the streaming store of
+// GRAFP_ST_NT.  Issued as inline asm: written as `if (plain) *p = v; else __builtin_nontemporal_store(v, p);` hipcc 7.2
+// sinks the two arms into ONE store and drops the hint (seen in the ISA: no `nt` left in the kernel).
+namespace grafp {
+typedef unsigned st_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned st_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store16_hint(void *p, st_u32x4 v, bool plain) {
+    if (plain) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void store8_hint(void *p, st_u32x2 v, bool plain) {
+    if (plain) asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+    else asm volatile("global_store_dwordx2 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+}
+}  // namespace grafp
 
 #define GRAFP_REQUIRE(cond, ...)              \
     do {                                      \

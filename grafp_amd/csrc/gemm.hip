@@ -24,6 +24,7 @@
 // column i, rows 0..3 -- tools/microbench/tr_read_probe.hip) with the 64-byte segments of a row XOR-swizzled by
 // (k & 3) on the DMA source side and on the read side (conflict-free: a 32-lane pass reads 4 rows x 64 B).
 // The W tile rows are 64 B; their 16-byte slots are swizzled by (r >> 2) & 3 the same way (ds_read_b128).
+#define GRAFP_STORE_FAMILY 2        // (common.h: GRAFP_ST_NT experiment builds)
 #include "common.h"
 #include "dma_ring.h"
 #include "tuning.h"

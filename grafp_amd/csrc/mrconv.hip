@@ -12,7 +12,9 @@
 // an LDS accumulator row, so dx is written once, coalesced, with no global atomics.
 #include <math.h>
 
+#define GRAFP_STORE_FAMILY 3        // (common.h: GRAFP_ST_NT experiment builds)
 #include "common.h"
+#include "tuning.h"
 
 namespace grafp {
 
@@ -59,15 +61,20 @@ __device__ __forceinline__ unsigned mr_pack(float lo, float hi) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, b2));      // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
 }
 // (outputs are streamed with the non-temporal hint: +35-65 % on a plain copy of tensors this size, tools/microbench/copy_bench.hip)
-__device__ __forceinline__ void mr_st4(float *p, const float (&v)[4]) {
+// ... and with PLAIN stores when the result fits the Infinity Cache beside its reader's other operand (`plain`, wave-uniform:
+// mr_plain_stores below; same-box A/B of the whole step, profiles/r06_c_*, r06_d_*: -0.5 % at 128 and 256 pairs, +0.5 % at
+// 512 and 1024)
+__device__ __forceinline__ void mr_st4(float *p, const float (&v)[4], bool plain = false) {
     typedef float f4 __attribute__((ext_vector_type(4)));
     const f4 t = {v[0], v[1], v[2], v[3]};
-    GRAFP_ST_NT(t, reinterpret_cast<f4 *>(p));
+    if (plain) store16_hint(p, __builtin_bit_cast(st_u32x4, t), true);
+    else GRAFP_ST_NT(t, reinterpret_cast<f4 *>(p));
 }
-__device__ __forceinline__ void mr_st4(unsigned short *p, const float (&v)[4]) {
+__device__ __forceinline__ void mr_st4(unsigned short *p, const float (&v)[4], bool plain = false) {
     typedef unsigned u2 __attribute__((ext_vector_type(2)));
     const u2 t = {mr_pack(v[0], v[1]), mr_pack(v[2], v[3])};
-    GRAFP_ST_NT(t, reinterpret_cast<u2 *>(p));
+    if (plain) store8_hint(p, __builtin_bit_cast(st_u32x2, t), true);
+    else GRAFP_ST_NT(t, reinterpret_cast<u2 *>(p));
 }
 
 // The backward scatter accumulates in 64-bit FIXED POINT with integer LDS atomics (ds_add_f32 runs at 0.33 lane-ops per
@@ -182,7 +189,7 @@ template <typename T, typename I, bool WK>
 __global__ __launch_bounds__(MR_THREADS) void mrconv_fwd_p_kernel(const T *__restrict__ x, int64_t x_sb, int64_t x_sc,
                                                                   const I *__restrict__ idx, T *__restrict__ out,
                                                                   int64_t o_sb, int64_t o_sc, int C, int N, int K,
-                                                                  int CC, unsigned char *__restrict__ arg) {
+                                                                  int CC, unsigned char *__restrict__ arg, int plain) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = blockIdx.y, tid = threadIdx.x;
     float *rows = reinterpret_cast<float *>(smem);                 // [CC*N] (<= MRP_SLAB floats)
@@ -258,8 +265,8 @@ __global__ __launch_bounds__(MR_THREADS) void mrconv_fwd_p_kernel(const T *__res
                         }
                         if (WK) arg[((size_t)b * C + c0 + pc[it]) * (N / 4) + pn[it] / 4] = (unsigned char)bk;
                         T *o = ob + (size_t)(2 * (c0 + pc[it])) * o_sc + pn[it];
-                        mr_st4(o, xi[it]);
-                        mr_st4(o + o_sc, m);
+                        mr_st4(o, xi[it], plain != 0);
+                        mr_st4(o + o_sc, m, plain != 0);
                     }
                 }
                 slab += G;
@@ -488,7 +495,7 @@ __global__ __launch_bounds__(MR_THREADS) void mrconv_bwd_a_kernel(const unsigned
                                                                   const I *__restrict__ idx,
                                                                   const T *__restrict__ gout, int64_t g_sb,
                                                                   int64_t g_sc, T *__restrict__ dx, int64_t d_sb,
-                                                                  int64_t d_sc, int C, int N, int K, int CC) {
+                                                                  int64_t d_sc, int C, int N, int K, int CC, int plain) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ unsigned s_max[MR_THREADS / 64];
     const int b = blockIdx.y, tid = threadIdx.x;
@@ -608,7 +615,7 @@ __global__ __launch_bounds__(MR_THREADS) void mrconv_bwd_a_kernel(const unsigned
                                                          ((unsigned long long)a23.w << 32) | a23.z};
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = poisoned ? NAN : base[it][e] + mr_fix_decode(a[e]) * inv_scale;
-                        mr_st4(dx_p[it], v);
+                        mr_st4(dx_p[it], v, plain != 0);
                     }
                     dx_p[it] += dx_step;
                 }
@@ -616,6 +623,11 @@ __global__ __launch_bounds__(MR_THREADS) void mrconv_bwd_a_kernel(const unsigned
             }
         }
     }
+}
+
+// the store hint of the training-path kernels: a pure function of the bytes they write (see mr_st4)
+static int mr_plain_stores(size_t bytes) {
+    return bytes <= ((size_t)GRAFP_TUNE_INT("GRAFP_MR_PLAIN_MAX_MB", 140) << 20) ? 1 : 0;    // profiles/r06_e_mr_plain_threshold.txt
 }
 
 static int pick_cc(int C, int N, int target_elems) {
@@ -661,11 +673,12 @@ static int mrconv_fwd_impl(const void *x, int dtype, int64_t x_sb, int64_t x_sc,
         const size_t ldsp = ((size_t)MRP_SLAB + (size_t)K * N) * 4;
         if (ldsp <= 160 * 1024) {
             const dim3 gridp(per_clip, B);
+            const int plain = mr_plain_stores((size_t)2 * B * C * N * es);
 #define MR_FWDP_W(T, I, WK)                                                                                            \
     (void)hipFuncSetAttribute((const void *)mrconv_fwd_p_kernel<T, I, WK>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                               (int)ldsp);                                                                              \
     hipLaunchKernelGGL((mrconv_fwd_p_kernel<T, I, WK>), gridp, dim3(MR_THREADS), ldsp, (hipStream_t)stream,            \
-                       (const T *)x, x_sb, x_sc, (const I *)idx, (T *)out, o_sb, o_sc, C, N, K, ccp, arg)
+                       (const T *)x, x_sb, x_sc, (const I *)idx, (T *)out, o_sb, o_sc, C, N, K, ccp, arg, plain)
 #define MR_FWDP(T, I)                                                                                                  \
     if (arg) { MR_FWDP_W(T, I, true); } else { MR_FWDP_W(T, I, false); }
             if (dtype == GRAFP_F32) { if (idx32) { MR_FWDP(float, int32_t); } else { MR_FWDP(float, int64_t); } }
@@ -802,11 +815,12 @@ extern "C" int grafp_mrconv_bwd_arg(const uint8_t *arg, int dtype, const void *i
     while ((int64_t)per_clip * B < 1024 && per_clip < nslab) ++per_clip;
     const size_t ldsp = (size_t)8 * MRB_SLAB + (size_t)4 * K * N;             // i64 accumulator + edges [K][N]
     const dim3 gridp(per_clip, B);
+    const int plain = mr_plain_stores((size_t)B * C * N * es);
 #define MR_BWDA(T, I)                                                                                                  \
     (void)hipFuncSetAttribute((const void *)mrconv_bwd_a_kernel<T, I>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
                               (int)ldsp);                                                                              \
     hipLaunchKernelGGL((mrconv_bwd_a_kernel<T, I>), gridp, dim3(MR_THREADS), ldsp, (hipStream_t)stream, arg,           \
-                       (const I *)idx, (const T *)grad_out, g_sb, g_sc, (T *)dx, d_sb, d_sc, C, N, K, ccp)
+                       (const I *)idx, (const T *)grad_out, g_sb, g_sc, (T *)dx, d_sb, d_sc, C, N, K, ccp, plain)
     if (dtype == GRAFP_F32) { if (idx_is_i32) { MR_BWDA(float, int32_t); } else { MR_BWDA(float, int64_t); } }
     else { if (idx_is_i32) { MR_BWDA(unsigned short, int32_t); } else { MR_BWDA(unsigned short, int64_t); } }
 #undef MR_BWDA

@@ -47,7 +47,14 @@ class Trainer:
         # the tensor belongs to the Trainer, not to the optimizer's dict: load_state_dict REPLACES param_group['lr'] with
         # whatever the checkpoint holds (a float from a reference-format file), see load_checkpoint()
         self._lr = torch.tensor(float(lr0), dtype=torch.float32, device=device) if on_gpu else None
-        self.opt = torch.optim.Adam(model.parameters(), lr=self._lr if on_gpu else lr0, fused=on_gpu, capturable=on_gpu)
+        if on_gpu:
+            # round 6: the update itself is the hand-written multi-tensor kernel (csrc/adam.hip: 5 launches at the rate of
+            # a streaming kernel instead of torch's 12 at 1.6 TB/s -- 0.2 ms of EVERY step, 1.4 % at 128 pairs per GPU);
+            # the object is a torch.optim.Adam in every other respect (state keys, state_dict, scheduler)
+            from .optim import Adam
+            self.opt = Adam(model.parameters(), lr=self._lr)
+        else:
+            self.opt = torch.optim.Adam(model.parameters(), lr=lr0)
         self._graph = None                     # (hipGraph, static x_i, static x_j, static loss) once captured
         # modules whose forward depends on .training (BatchNorm statistics, dropout): the short list step() looks at
         self._mode_sensitive = [m for m in model.modules()

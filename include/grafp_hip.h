@@ -393,6 +393,19 @@ int grafp_conv1x1_wgrad_partials_bf16(const void *grad_out, const void *x, int C
                                       size_t ws_bytes, int *n_slices, grafp_stream_t stream);
 int grafp_wgrad_reduce_multi(const void *const *parts, const int *n_slices, const int64_t *n_out, float *const *outs,
                              int n_entries, grafp_stream_t stream);
+/* ---- optimizer update (round 6) ----------------------------------------------------------------------------------
+ * optimizer.step() of /root/reference/train.py:79 for torch.optim.Adam with its defaults (train.py:174: betas
+ * (0.9, 0.999), eps 1e-8, no weight decay, no amsgrad) on ALL parameter tensors in ceil(n_entries / 64) launches (the
+ * table travels in the kernel arguments: graph-capturable, no device-side state).  Host arrays of n_entries device
+ * pointers: the f32 parameter, its f32 gradient, exp_avg, exp_avg_sq (updated in place) and the parameter's step counter
+ * (a f32 scalar holding the count AFTER this update -- the caller bumps it first, as torch does); numels < 2^31.
+ * lr_dev: the learning rate as a f32 scalar on the device, read when the kernel RUNS (a scheduler may update it between
+ * replays of a captured step), or NULL to use `lr`.  Per element, in f32 and in this order (no contraction):
+ *   m = m + (g - m)(1 - beta1);  v = beta2 v + (1 - beta2) g g;
+ *   p = p - ((float)(lr / (1 - beta1^t)) m) / (sqrt(v) / (float)sqrt(1 - beta2^t) + eps)      (corrections in double) */
+int grafp_adam_multi_f32(float *const *params, const float *const *grads, float *const *exp_avgs,
+                         float *const *exp_avg_sqs, const float *const *steps, const int64_t *numels, int n_entries,
+                         const float *lr_dev, double lr, double beta1, double beta2, double eps, grafp_stream_t stream);
 /* f32 operands (the f32 "parity" mode of the step): the same split-K streaming reduction with each value split into
  * hi = bf16(v), lo = bf16(v - hi) on the way into LDS and three bf16 MFMAs per tile step (Gh Xh + Gh Xl + Gl Xh; the
  * dropped Gl Xl term and the 16-bit representation are ~2^-16 relative, f32 accumulation).  Same layouts as above

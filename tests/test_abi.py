@@ -53,7 +53,7 @@ def _ctype_of(arg):
         return ctypes.c_void_p
     base = arg.rsplit(" ", 1)[0].replace("const ", "").strip()
     return {"int": ctypes.c_int, "int64_t": ctypes.c_int64, "size_t": ctypes.c_size_t, "float": ctypes.c_float,
-            "int32_t": ctypes.c_int32}[base]
+            "int32_t": ctypes.c_int32, "double": ctypes.c_double}[base]
 
 
 def test_ctypes_table_matches_header():

@@ -1253,3 +1253,73 @@ def test_eval_faiss_with_the_ivfpq_index(dev, tmp_path, monkeypatch):
     import grafp_amd.eval as geval
     monkeypatch.setattr(geval, "SERVE_IVFPQ_EXACTLY", True)
     np.testing.assert_array_equal(eval_faiss(str(tmp_path), index_type="ivfpq", **kw), g["hit_rates"])
+
+
+# =============================================================== optimizer update (csrc/adam.hip)
+def test_adam_multi_tensor_vs_torch(dev):
+    """grafp_amd.optim.Adam (one hand-written multi-tensor kernel per 64 tensors; /root/reference/train.py:79,174) against
+    torch.optim.Adam (the single-tensor f32 implementation) from the same state over six steps: parameters, both moments
+    and the step counters; 70 tensors (two launches) with sizes around the 4096-element workgroup, an UNALIGNED gradient
+    view, a learning rate that lives on the device and changes between steps, a parameter that gets no gradient in some
+    steps (skipped, its counter stands still), and state_dict round trips in both directions."""
+    from grafp_amd.optim import Adam
+    g = torch.Generator().manual_seed(11)
+    sizes = [1, 3, 4, 64, 127, 4095, 4096, 4097, 8192 + 5, 64 * 64, 3 * 7 * 7 * 8, 300_000] + [257 + 13 * i for i in range(58)]
+    init = [torch.randn(n, generator=g) for n in sizes]
+    mine = [torch.nn.Parameter(t.clone().to(dev)) for t in init]
+    ref = [torch.nn.Parameter(t.clone().to(dev)) for t in init]
+    frozen = torch.nn.Parameter(torch.ones(5, device=dev), requires_grad=False)
+    lr = torch.tensor(3e-3, device=dev)
+    a = Adam(mine + [frozen], lr=lr)
+    b = torch.optim.Adam(ref + [frozen], lr=3e-3, foreach=False, fused=False)
+    flat = torch.empty(sum(sizes) + 1, device=dev)
+    for step in range(6):
+        off = 1                                                      # every gradient of `mine` is a 4-byte-aligned view
+        for i, (p, q) in enumerate(zip(mine, ref)):
+            gr = (torch.randn(p.numel(), generator=g) * (10.0 ** ((i % 5) - 2))).to(dev)
+            if i == 7 and step in (2, 3):
+                p.grad = q.grad = None
+                continue
+            flat[off:off + p.numel()] = gr
+            p.grad = flat[off:off + p.numel()].view_as(p)
+            q.grad = gr.clone()
+            off += p.numel()
+        if step == 4:
+            lr.fill_(1e-3)
+            for grp in b.param_groups:
+                grp["lr"] = 1e-3
+        a.step()
+        b.step()
+        for i, (p, q) in enumerate(zip(mine, ref)):
+            scale = float(q.detach().abs().max()) + 1e-12
+            assert float((p.detach() - q.detach()).abs().max()) <= 2e-6 * scale + 1e-9, (step, i)
+            sa, sb = a.state[p], b.state[q]
+            assert float(sa["step"]) == float(sb["step"]), (step, i)
+            for k in ("exp_avg", "exp_avg_sq"):
+                sk = float(sb[k].abs().max()) + 1e-30                      # (entries near a cancellation: per-tensor scale)
+                assert float((sa[k] - sb[k]).abs().max()) <= 2e-6 * sk, (step, i, k)
+    assert float(a.state[mine[7]]["step"]) == 4.0 and float(a.state[mine[0]]["step"]) == 6.0
+    assert frozen not in a.state or "step" not in a.state[frozen]
+    # state_dict: torch's class loads ours and continues identically; ours loads torch's
+    c = torch.optim.Adam([torch.nn.Parameter(p.detach().clone()) for p in mine] + [frozen], lr=1e-3, foreach=False, fused=False)
+    import copy
+    sd = copy.deepcopy(a.state_dict())           # (load_state_dict keeps the tensors it is given when no cast is needed)
+    sd["param_groups"] = [dict(grp, lr=1e-3) for grp in sd["param_groups"]]
+    c.load_state_dict(sd)
+    d = Adam([torch.nn.Parameter(q.detach().clone()) for q in ref] + [frozen], lr=lr)
+    d.load_state_dict(copy.deepcopy(b.state_dict()))
+    for grp in d.param_groups:
+        grp["lr"] = lr
+    for opt in (a, c, d, b):
+        for i, p in enumerate(opt.param_groups[0]["params"][:-1]):
+            p.grad = torch.full_like(p, 0.01 * (i + 1))
+        opt.step()
+    for pa, pc, pd, pb in zip(*(o.param_groups[0]["params"][:-1] for o in (a, c, d, b))):
+        scale = float(pb.detach().abs().max()) + 1e-12
+        assert float((pa.detach() - pc.detach()).abs().max()) <= 2e-6 * scale + 1e-9
+        assert float((pd.detach() - pb.detach()).abs().max()) <= 2e-6 * scale + 1e-9
+    assert float(d.state[d.param_groups[0]["params"][0]]["step"]) == 7.0
+    with pytest.raises(NotImplementedError):
+        Adam(mine, lr=1e-3, weight_decay=0.1)
+    with pytest.raises(RuntimeError):
+        Adam([torch.nn.Parameter(torch.zeros(4))], lr=1e-3).step()          # a CPU parameter: no fallback

@@ -50,7 +50,7 @@ def force(cfg):
 
 def wgrad(args, dev):
     """dW = G X^T per layer shape (GRAFP_WGRAD_TILE in a measurement build selects a tile configuration)."""
-    depth, tot = (2, 2, 6, 2), 0.0
+    depth, tot, tot_floor = (2, 2, 6, 2), 0.0, 0.0
     for stage, (C, N) in enumerate(((64, 1024), (128, 512), (256, 256), (512, 128))):
         M = args.clips * N
         if str(stage) not in args.stages:
@@ -61,10 +61,19 @@ def wgrad(args, dev):
             X = torch.randn(ci, M, device=dev).to(torch.bfloat16)
             t0 = timeit(lambda: ops.conv1x1_wgrad(G, X, co, ci, g, M, 1))
             by, fl = (co + ci) * M * 2.0, 2.0 * co * (ci // g) * M
+            info = (ctypes.c_int * 8)()
+            lib.grafp_conv1x1_wgrad_plan(co, ci, g, M, 1, info)
+            # floors: the operands once at the part's measured read rate (vmem_pipe_bench: 6.25 TB/s), the products at
+            # the bf16 matrix peak (2.5 PFLOP/s) and at the rate measured on non-constant operands (1.67, mfma_data_bench)
+            f_rd, f_mx, f_md = by / 6.25e6, fl / 2.5e9, fl / 1.67e9
+            floor = max(f_rd, f_md)
             tot += t0 * depth[stage]
+            tot_floor += floor * depth[stage]
             print(f"s{stage} {name:9s} {co:5d} x {ci:5d} g={g} M={M:7d}  wgrad {t0:7.1f} us | "
-                  f"{by / t0 / 1e6:5.2f} TB/s {fl / t0 / 1e6:7.1f} TF/s", flush=True)
-    print(f"weighted by blocks per stage: {tot / 1e3:.2f} ms")
+                  f"{by / t0 / 1e6:5.2f} TB/s {fl / t0 / 1e6:7.1f} TF/s | cfg {info[0]:2d} tiles {info[1]}x{info[2]} slices {info[3]:4d} | "
+                  f"read floor {f_rd:6.1f} us, matrix floor {f_mx:6.1f} (data-dependent {f_md:6.1f}) -> {floor / t0:4.2f} of the "
+                  f"larger; lost {depth[stage] * (t0 - floor):7.1f} us per step", flush=True)
+    print(f"weighted by blocks per stage: {tot / 1e3:.2f} ms measured, {tot_floor / 1e3:.2f} ms at the floors")
 
 
 def main():

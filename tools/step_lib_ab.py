@@ -1,5 +1,5 @@
 """A/B of two BUILDS of the library on the training step (graph replay and eager), alternating child processes:
-    python tools/step_lib_ab.py PAIRS[,PAIRS...] LIB_A LIB_B [reps]
+    python tools/step_lib_ab.py PAIRS[,PAIRS...] LIB_A LIB_B [LIB_C ...] [reps]
 Each child loads one library through GRAFP_HIP_LIB, builds the model from the same seed, and times 20 replayed steps
 (Trainer.step_graph) after capture; the parent alternates A, B, A, B ... so that box drift hits both alike.
 (The experiment builds come from `make measure XFLAGS=-D... MLIB=../libgrafp_hip_x_NAME.so MDIR=_obj_x_NAME`.)"""
@@ -47,10 +47,11 @@ def child(pairs_list):
 def main():
     if sys.argv[1] == "--child":
         return child([int(v) for v in sys.argv[2].split(",")])
-    pairs, lib_a, lib_b = sys.argv[1], sys.argv[2], sys.argv[3]
-    reps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+    pairs, libs, reps = sys.argv[1], sys.argv[2:], 3
+    if libs[-1].isdigit():
+        reps, libs = int(libs[-1]), libs[:-1]
     for _ in range(reps):
-        for lib in (lib_a, lib_b):
+        for lib in libs:
             env = dict(os.environ, GRAFP_HIP_LIB=os.path.abspath(lib))
             subprocess.run([sys.executable, os.path.abspath(__file__), "--child", pairs], env=env, check=True)
 
