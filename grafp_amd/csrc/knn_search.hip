@@ -458,8 +458,10 @@ __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float *__restric
 }
 
 // query operand of the bf16 MFMA: lane (l31, half) holds dims 16 s + 8 half + 0..7 of query l31, s = 0..7
+// `scale`: the operand is round_bf16(scale * q) -- the scans fold their constant factor into the query side, see
+// stream_tiles_bf16 (the error bound of the product is relative to |scale q||x|, i.e. unchanged after dividing back)
 __device__ __forceinline__ void load_queries_bf16(const float *__restrict__ q, int qi, bool qvalid, int half,
-                                                  bf16x8 (&bq)[8]) {
+                                                  bf16x8 (&bq)[8], float scale) {
     typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));   // q is only promised 4-byte alignment
     const f32x4_a4 *qrow = reinterpret_cast<const f32x4_a4 *>(q + (size_t)(qvalid ? qi : 0) * SR_D + 8 * half);
     f32x4 raw[16];                           // unconditional loads, all in flight at once (see load_queries)
@@ -472,7 +474,7 @@ __device__ __forceinline__ void load_queries_bf16(const float *__restrict__ q, i
     for (int s = 0; s < 8; ++s)
 #pragma unroll
         for (int e = 0; e < 8; ++e)
-            bq[s][e] = qvalid ? (short)f32_to_bf16_rne(raw[2 * s + (e >> 2)][e & 3]) : (short)0;
+            bq[s][e] = qvalid ? (short)f32_to_bf16_rne(raw[2 * s + (e >> 2)][e & 3] * scale) : (short)0;
 }
 
 // Tiles of SB_TR bf16 rows through a ring of SB_NS LDS stages, filled by LDS-DMA (no registers, no LDS-write phase):
@@ -492,22 +494,15 @@ __device__ __forceinline__ void load_queries_bf16(const float *__restrict__ q, i
 // LDS rows are 256 B unpadded; piece p of LDS row r holds piece p ^ (r & 15) of the database row (the DMA lane picks
 // its global address accordingly), so the 16-byte fragment reads of a lane group hit 16 different bank groups.
 // Wave (qw, rw) multiplies row blocks rw, rw + RW, ... of the tile with its NQS sets of 32 queries: on_block(t, rb, j, acc,
-// hv) per set j, hv = the norms of the lane's 16 accumulator rows (NaN past the end of the slice); on_tile(t) runs once
-// per tile on every thread at the quiescent point behind the tile barrier.
-// e[r] = hv[r] * k + acc[r] for the 16 accumulator rows of a lane, as eight v_pk_fma_f32 (two lanes of arithmetic per
-// issue slot; the scalar form is sixteen v_fmamk_f32 -- and every VALU slot of the scan loop is paid in full)
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void fma16_pk(const float (&hv)[16], float k, const f32x16 &acc, float (&e)[16]) {
-    const f32x2 kk = {k, k};
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const f32x2 h = {hv[2 * i], hv[2 * i + 1]}, c = {acc[2 * i], acc[2 * i + 1]};
-        const f32x2 r = __builtin_elementwise_fma(h, kk, c);
-        e[2 * i] = r[0];
-        e[2 * i + 1] = r[1];
-    }
-}
-
+// nb) per set j; on_tile(t) runs once per tile on every thread at the quiescent point behind the tile barrier.
+// Round 6: the accumulator chains START from the rows' squared norms (the C operand of a block's first MFMA is the
+// lane's 16 norms as they come out of LDS -- NaN past the end of the slice), and the caller folds its constant into the
+// query operand (q' = -2 q / kappa): acc = dd + <q'^, x^> = dd - (2 / kappa) <q^,x^>, the quantity both scans threshold
+// (scan: keep iff acc <= thr / kminus - qq; pre-pass: the minimum of acc).  Before, every block paid eight v_pk_fma_f32
+// per query set for hv * k + acc and sixteen register moves to line the norms up -- and every VALU slot of this loop is
+// paid in full (tools/search_abl.py: the block callback was 300 us of a 1 130 us pass over 1M rows x 4096 queries, 100
+// after: profiles/r06_search_abl_nqs2.txt, r06_search_abl_nqs2_after.txt).
+// nb: the lane's 16 norms where they stand in LDS (row mfma_row(r, half) at nb[8 (r >> 2) + (r & 3)]).
 // ABL (measurement builds, tools/search_abl.py): bit 0 drops the MFMAs, bit 1 the per-block callback, bit 2 the DMA issue
 // after the prologue, bit 3 the fragment reads -- what the loop costs without each of its parts.
 // prepare() runs once, right behind the DMA issue of the first two tiles: the caller loads and converts its query operand
@@ -599,47 +594,36 @@ __device__ __forceinline__ void stream_tiles_bf16(const unsigned short *__restri
                 if (ABL & 8) a[s2] = bq[0][s2];
                 else a[s2] = *reinterpret_cast<const bf16x8 *>(frag[s2] + OFF);
             }
+            // ... and the 16 norms of the lane's accumulator rows: the C operand of the chains' first MFMA
             f32x4 hv4[4];
-            if (NQS == 1) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    hv4[g] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const unsigned char *>(nrm0 + 8 * g) + NOFF);
-            }
+            for (int g = 0; g < 4; ++g)
+                hv4[g] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const unsigned char *>(nrm0 + 8 * g) + NOFF);
             __builtin_amdgcn_sched_barrier(0);
+            f32x16 cinit;                      // cinit[r]: norm of row mfma_row(r, half) of the block (NaN past the end)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cinit[r] = hv4[r >> 2][r & 3];
             // NQS independent accumulator chains share every row fragment: with two query sets per wave a fragment
             // read feeds two MFMAs and neither chain waits for the other's result
             f32x16 acc[NQS];
 #pragma unroll
-            for (int j = 0; j < NQS; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
-#pragma unroll
             for (int s2 = 0; s2 < 8; ++s2) {
 #pragma unroll
                 for (int j = 0; j < NQS; ++j) {
-                    if (ABL & 1) acc[j][s2] += __builtin_bit_cast(float, (int)a[s2][0] | ((int)a[s2][7] << 16));
-                    else acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s2], bq[j][s2], acc[j], 0, 0, 0);
-                }
-                if (NQS == 2 && s2 == 3) {
-                    // two query sets: the norms are requested half way down the chains, into the registers of the
-                    // fragments already consumed (three waves per SIMD leave 168 registers)
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        hv4[g] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const unsigned char *>(nrm0 + 8 * g) + NOFF);
-                    __builtin_amdgcn_sched_barrier(0);
+                    if (ABL & 1) {
+                        if (s2 == 0) acc[j] = cinit;
+                        acc[j][s2] += __builtin_bit_cast(float, (int)a[s2][0] | ((int)a[s2][7] << 16));
+                    } else {
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s2], bq[j][s2], s2 == 0 ? cinit : acc[j], 0, 0, 0);
+                    }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            float hv[16];                      // hv[r]: norm of row mfma_row(r, half) of the block (NaN past the end)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) hv[r] = hv4[r >> 2][r & 3];
 #pragma unroll
             for (int j = 0; j < NQS; ++j) {
-                // (last argument: the lane's 16 norms where they stand in LDS -- norm of row mfma_row(r, half) at [8 (r >> 2) + (r & 3)])
                 const float *nb = reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(nrm0) + NOFF);
-                if (ABL & 2) { if (acc[j][0] == 12345.678f && hv[3] == acc[j][5]) on_block(t, RB, j, acc[j], hv, nb); }
-                else on_block(t, RB, j, acc[j], hv, nb);
+                if (ABL & 2) { if (acc[j][0] == 12345.678f && acc[j][3] == acc[j][5]) on_block(t, RB, j, acc[j], nb); }
+                else on_block(t, RB, j, acc[j], nb);
             }
         };
         // (Also measured and dropped for the two-query-set form: the reads of both blocks in front of the first chain,
@@ -681,26 +665,26 @@ __global__ __launch_bounds__(256, NQS == 2 ? SB_WGS_NQS2 : 3) void search_bound_
 #pragma unroll
     for (int j = 0; j < NQS; ++j) {
         qi[j] = ((qgroup * QW + qw) * NQS + j) * 32 + l31;
-        bestm[j] = -INFINITY;
+        bestm[j] = INFINITY;
     }
-    // d~ + SLACK (qq + dd) = qk - 2 (<q^,x^> - dd kplus / 2): the lane keeps the MAXIMUM of the bracket (one fma per
-    // element, maxima three at a time); rows past the end carry NaN and are ignored by fmaxf
+    // d~ + SLACK (qq + dd) = qq kplus - 2 (<q^,x^> - dd kplus / 2), and the bracket is -(kplus / 2) acc for the stream's
+    // acc = dd - (2 / kplus) <q^,x^> (query operand scaled by -2 / kplus): the lane keeps the MINIMUM of acc, three at a
+    // time, no arithmetic per element; rows past the end carry NaN and are ignored by fminf
     const float nhk = -0.5f * kplus;
     stream_tiles_bf16<QW, NQS, ABL>(dbh, dd, row_begin, row_end, ring, bq, [&]() {
 #pragma unroll
-        for (int j = 0; j < NQS; ++j) load_queries_bf16(q, qi[j], qi[j] < nq, half, bq[j]);
-    }, [&](int, int, int j, const f32x16 &acc, const float (&hv)[16], const float *) {
-        float e[16];
-        fma16_pk(hv, nhk, acc, e);
+        for (int j = 0; j < NQS; ++j) load_queries_bf16(q, qi[j], qi[j] < nq, half, bq[j], -2.0f / kplus);
+    }, [&](int, int, int j, const f32x16 &acc, const float *) {
 #pragma unroll
-        for (int r = 0; r < 16; r += 2) bestm[j] = fmaxf(fmaxf(bestm[j], e[r]), e[r + 1]);
+        for (int r = 0; r < 16; r += 2) bestm[j] = fminf(fminf(bestm[j], acc[r]), acc[r + 1]);
     }, [](int) {});
-    // every (split, row-wave, half) group of a query has ONE writer: the raw maximum of the bracket goes out as it is
+    // every (split, row-wave, half) group of a query has ONE writer: the maximum of the bracket goes out as it is
     // (-inf when the group saw no row) and search_thr_pre_kernel folds the groups into the 64 classes -- no atomics, so no
     // launch in front of this one to initialise them (round 4: the init kernel was 5 us of a 79 us search)
 #pragma unroll
     for (int j = 0; j < NQS; ++j)
-        if (qi[j] < nq) gmax[(size_t)qi[j] * ngroups + ((split * RW + rw) * 2 + half)] = bestm[j];
+        if (qi[j] < nq)
+            gmax[(size_t)qi[j] * ngroups + ((split * RW + rw) * 2 + half)] = bestm[j] < INFINITY ? nhk * bestm[j] : -INFINITY;
 }
 
 // Hits are rare (a few hundred per query over the whole database) but a returning global atomic costs microseconds,
@@ -768,41 +752,42 @@ __global__ __launch_bounds__(256, NQS == 2 ? SB_WGS_NQS2 : 3) void search_scan_b
         fill += add;
     };
     const float hs = 0.5f * kminus;
-    // keep iff <q^,x^> - H_row >= A_q.  Common case: 16 fmas, their maximum three at a time (NaN past the end of the
-    // slice drops out of fmaxf), ONE compare and one branch per block -- no per-element lane masks, whose 16 dependent
-    // scalar ORs behind 16 VALU compares cost as much as the MFMA chain itself.
+    // keep iff <q^,x^> - dd kminus / 2 >= (qq kminus - thr) / 2  <=>  acc <= thr / kminus - qq for the stream's
+    // acc = dd - (2 / kminus) <q^,x^> (query operand scaled by -2 / kminus).  Common case: the minimum of the 16
+    // accumulators three at a time (NaN past the end of the slice drops out of fminf), ONE compare and one branch per
+    // block -- no arithmetic per element, no per-element lane masks (whose 16 dependent scalar ORs behind 16 VALU
+    // compares cost as much as the MFMA chain itself).
     stream_tiles_bf16<QW, NQS>(dbh, dd, row_begin, row_end, ring, bq, [&]() {
 #pragma unroll
         for (int j = 0; j < NQS; ++j) {
             const int qi = qbase + (qw * NQS + j) * 32 + l31;
-            load_queries_bf16(q, qi, qi < nq, half, bq[j]);
-            a_q[j] = qi < nq ? 0.5f * (qq[qi] * kminus - thr[qi]) : INFINITY;
+            load_queries_bf16(q, qi, qi < nq, half, bq[j], -2.0f / kminus);
+            a_q[j] = qi < nq ? thr[qi] / kminus - qq[qi] : -INFINITY;
         }
-    }, [&](int t, int rb, int j, const f32x16 &acc, const float (&hv)[16], const float *nb) {
-        float e[16];
-        fma16_pk(hv, -hs, acc, e);
-        float m = fmaxf(e[0], e[1]);
+    }, [&](int t, int rb, int j, const f32x16 &e, const float *nb) {
+        float m = fminf(e[0], e[1]);
 #pragma unroll
-        for (int r = 2; r < 16; r += 2) m = fmaxf(fmaxf(m, e[r]), e[r + 1]);
-        if (__ballot(m >= a_q[j]) != 0) {
+        for (int r = 2; r < 16; r += 2) m = fminf(fminf(m, e[r]), e[r + 1]);
+        if (__ballot(m <= a_q[j]) != 0) {
             // A block holds a hit far more often than "rare" suggests -- 32 x 32 pairs against a few hundred candidates
             // per query in a million rows: every second to fourth block -- so this path must be cheap as well: 16
             // compares into a bit mask (no branches); in the usual case of ONE hit among a lane's 16 rows its value is
             // the maximum already at hand.
             unsigned bits = 0;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) bits |= e[r] >= a_q[j] ? 1u << r : 0u;       // (NaN compares false)
+            for (int r = 0; r < 16; ++r) bits |= e[r] <= a_q[j] ? 1u << r : 0u;       // (NaN compares false)
             const int slab0 = (int)(row_begin + (int64_t)t * SB_TR + rb * 32) + 4 * half;
             const int ql = (qw * NQS + j) * 32 + l31;                 // < 256: fits the queue's byte
             const bool single = (bits & (bits - 1)) == 0;
             const int r0 = bits ? __builtin_ctz(bits) : 0;            // row mfma_row(r, half) of the block
             const int off0 = (r0 & 3) + 8 * (r0 >> 2);
-            push(bits != 0 && single, slab0 + off0, m, nb[off0], ql);  // (the norm: one LDS read at the lane's own index)
+            // the record the select kernel reads: E = <q^,x^> - dd kminus / 2 = -(kminus / 2) acc, and the row's norm
+            push(bits != 0 && single, slab0 + off0, -hs * m, nb[off0], ql);  // (the norm: one LDS read at the lane's own index)
             if (__ballot(!single) != 0) {                             // several hits in one lane's 16 rows: rare
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const bool h = !single && ((bits >> r) & 1);
-                    if (__ballot(h) != 0) push(h, slab0 + (r & 3) + 8 * (r >> 2), e[r], hv[r], ql);
+                    if (__ballot(h) != 0) push(h, slab0 + (r & 3) + 8 * (r >> 2), -hs * e[r], nb[(r & 3) + 8 * (r >> 2)], ql);
                 }
             }
         }
