@@ -654,7 +654,7 @@ __global__ __launch_bounds__(256) void bn_affine_bf16_kernel(const unsigned shor
                                                              int views, int chunks_view, int64_t chunk,
                                                              const float2 *__restrict__ tab, BnStatsArgs st,
                                                              const unsigned short *__restrict__ residual, int act,
-                                                             float slope, unsigned short *__restrict__ out) {
+                                                             float slope, unsigned short *__restrict__ out, int plain) {
     const int c = blockIdx.y, s = blockIdx.x, tid = threadIdx.x;
     const int v = s / chunks_view, sl = s - v * chunks_view;
     const unsigned short *row = y + (size_t)c * M, *rrow = residual ? residual + (size_t)c * M : nullptr;
@@ -727,7 +727,8 @@ __global__ __launch_bounds__(256) void bn_affine_bf16_kernel(const unsigned shor
         }
         typedef unsigned u4 __attribute__((ext_vector_type(4)));
         const u4 t = {o[0], o[1], o[2], o[3]};
-        GRAFP_ST_NT(t, reinterpret_cast<u4 *>(dst));
+        if (plain) store16_hint(dst, __builtin_bit_cast(st_u32x4, t), true);      // (wave-uniform: bn_affine_launch)
+        else GRAFP_ST_NT(t, reinterpret_cast<u4 *>(dst));
     };
     while (full) {
 #pragma unroll
@@ -1022,14 +1023,21 @@ static int bn_affine_launch(const void *y, int C, int64_t M, int views, const fl
     chunk = (chunk + 7) / 8 * 8;
     chunks_view = (int)((Mg + chunk - 1) / chunk);
     const dim3 grid(chunks_view * views, C);
+    // store hint by the bytes written, as for the BatchNorm backward (bn.hip: bn_plain_stores): the normalised activation
+    // is the operand of the next launches (graph build, max-relative, product).  Until round 6 these were streaming
+    // stores like the products' (where they ARE worth 10-15 %); the whole-step A/B (tools/step_env_graph_ab.py,
+    // profiles/r06_e_affine_plain_threshold*.txt; tensors up to 70 / 140 / 280 MB / all plain) says otherwise for this
+    // kernel at every size: 128 pairs -1.4 / -1.8 / -1.8 %, 256 pairs -1.4 / -1.2 / -1.7 %, 512 pairs 0 / -0.8 / -1.0
+    // / -0.9 %, 1024 pairs -0.1 (280 MB) ... -0.3 % (all) -- plain everywhere (the knob stays for measurement builds)
+    const int plain = (size_t)C * (size_t)M * 2 <= ((size_t)GRAFP_TUNE_INT("GRAFP_AFFINE_PLAIN_MAX_MB", 1 << 20) << 20) ? 1 : 0;
     if (st)
         hipLaunchKernelGGL(bn_affine_bf16_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short *)y,
                            M, Mg, views, chunks_view, chunk, (const float2 *)nullptr, *st,
-                           (const unsigned short *)residual, act, slope, (unsigned short *)out);
+                           (const unsigned short *)residual, act, slope, (unsigned short *)out, plain);
     else
         hipLaunchKernelGGL(bn_affine_bf16_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short *)y,
                            M, Mg, views, chunks_view, chunk, (const float2 *)tab, BnStatsArgs{},
-                           (const unsigned short *)residual, act, slope, (unsigned short *)out);
+                           (const unsigned short *)residual, act, slope, (unsigned short *)out, plain);
     GRAFP_CHECK_LAUNCH("bn_affine_bf16_kernel");
     return GRAFP_OK;
 }
