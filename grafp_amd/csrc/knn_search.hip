@@ -646,7 +646,7 @@ __device__ __forceinline__ void stream_tiles_bf16(const unsigned short *__restri
 }
 
 template <int QW, int NQS, int ABL = 0>
-__global__ __launch_bounds__(256, NQS == 2 ? SB_WGS_NQS2 : 3) void search_bound_bf16_kernel(
+__global__ __launch_bounds__(256, NQS >= 2 ? SB_WGS_NQS2 : 3) void search_bound_bf16_kernel(
     const unsigned short *__restrict__ dbh, const float *__restrict__ dd, int64_t n_sample, const float *__restrict__ q,
     int nq, int64_t rows_per_split, float *__restrict__ gmax, int ngroups) {
     constexpr int RW = 4 / QW;
@@ -695,7 +695,7 @@ __global__ __launch_bounds__(256, NQS == 2 ? SB_WGS_NQS2 : 3) void search_bound_
 constexpr int HB_CAP = 72;        // entries per wave: 4 x 72 x 13 B = 3.7 KB; with the 49 KB ring three workgroups fit a CU
 
 template <int QW, int NQS>
-__global__ __launch_bounds__(256, NQS == 2 ? SB_WGS_NQS2 : 3) void search_scan_bf16_kernel(
+__global__ __launch_bounds__(256, NQS >= 2 ? SB_WGS_NQS2 : 3) void search_scan_bf16_kernel(
     const unsigned short *__restrict__ dbh, const float *__restrict__ dd, int64_t row0, int64_t n,
     const float *__restrict__ q, const float *__restrict__ qq, int nq, int64_t rows_per_split,
     const float *__restrict__ thr, int *__restrict__ cnt, int *__restrict__ cand_i, float2 *__restrict__ cand_e) {
@@ -704,7 +704,7 @@ __global__ __launch_bounds__(256, NQS == 2 ? SB_WGS_NQS2 : 3) void search_scan_b
     __shared__ int hb_row[4][HB_CAP];
     __shared__ float hb_e[4][HB_CAP];
     __shared__ float hb_d[4][HB_CAP];
-    __shared__ unsigned char hb_q[4][HB_CAP];
+    __shared__ unsigned short hb_q[4][HB_CAP];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int qw = wave % QW;
     int split, qgroup;
@@ -720,7 +720,7 @@ __global__ __launch_bounds__(256, NQS == 2 ? SB_WGS_NQS2 : 3) void search_scan_b
     int *my_row = hb_row[wave];
     float *my_e = hb_e[wave];
     float *my_d = hb_d[wave];
-    unsigned char *my_q = hb_q[wave];
+    unsigned short *my_q = hb_q[wave];
     int fill = 0;                                             // wave-uniform
     auto drain = [&]() {                                      // this wave's queue -> sub-list `sub` of the queries' lists
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -747,7 +747,7 @@ __global__ __launch_bounds__(256, NQS == 2 ? SB_WGS_NQS2 : 3) void search_scan_b
             my_row[slot] = row;
             my_e[slot] = ev;
             my_d[slot] = ddv;
-            my_q[slot] = (unsigned char)ql;
+            my_q[slot] = (unsigned short)ql;
         }
         fill += add;
     };
@@ -777,7 +777,7 @@ __global__ __launch_bounds__(256, NQS == 2 ? SB_WGS_NQS2 : 3) void search_scan_b
 #pragma unroll
             for (int r = 0; r < 16; ++r) bits |= e[r] <= a_q[j] ? 1u << r : 0u;       // (NaN compares false)
             const int slab0 = (int)(row_begin + (int64_t)t * SB_TR + rb * 32) + 4 * half;
-            const int ql = (qw * NQS + j) * 32 + l31;                 // < 256: fits the queue's byte
+            const int ql = (qw * NQS + j) * 32 + l31;                 // < 32 QW NQS <= 384
             const bool single = (bits & (bits - 1)) == 0;
             const int r0 = bits ? __builtin_ctz(bits) : 0;            // row mfma_row(r, half) of the block
             const int off0 = (r0 & 3) + 8 * (r0 >> 2);
@@ -1323,7 +1323,17 @@ static PrePlan pre_plan(int64_t n, int nq) {
     // read from LDS feeds two independent MFMA chains and a tile's DMA, barrier and loop overhead is shared by twice the
     // MFMAs (1M x 128, round 4, after the loop's address arithmetic went into immediates: 4096 queries 1.32 -> 1.20 ms,
     // 2048 0.69 -> 0.645, 1024 0.380 -> 0.365, 512 0.231 -> 0.237; before that the two forms were level)
-    p.nqs = GRAFP_TUNE_INT("GRAFP_SEARCH_NQS", nq >= 1024 ? 2 : 1) == 2 && p.qw == 4 ? 2 : 1;
+    // THREE sets per wave (round 6; 249 registers, still two workgroups per CU): a third fewer fragment reads per MFMA.
+    // Same-process A/B (1M x 128, k = 20, scratch/nqs3_check.py): 4096 queries 1.108 -> 1.080 ms, 2500 0.734 -> 0.704, but
+    // 2048 0.580 -> 0.601 and 1024 0.318 -> 0.332 -- the gain (~8 %) is paid back by the idle query slots of the last
+    // 384-query group, so: from 1536 queries, when the three-set form pads at most 6 % more than the two-set form
+    int nqs_auto = nq >= 1024 ? 2 : 1;
+    if (nq >= 1536) {
+        const int64_t pad3 = (int64_t)((nq + 383) / 384) * 384 - nq, pad2 = (int64_t)((nq + 255) / 256) * 256 - nq;
+        if ((pad3 - pad2) * 100 <= (int64_t)6 * nq) nqs_auto = 3;
+    }
+    p.nqs = p.qw == 4 ? GRAFP_TUNE_INT("GRAFP_SEARCH_NQS", nqs_auto) : 1;
+    if (p.nqs < 1 || p.nqs > 3) p.nqs = 1;
     p.qgroups = (nq + 32 * p.qw * p.nqs - 1) / (32 * p.qw * p.nqs);
     p.b_rows = n / 16 > 65536 ? n / 16 : 65536;
     if (p.b_rows > n) p.b_rows = n;
@@ -1369,7 +1379,7 @@ extern "C" int grafp_knn_search_l2_pre(const float *db, const void *db_bf16, con
     const int64_t b_rows = pl.b_rows, b_rps = pl.b_rps;
     int splits;
     int64_t rps;
-    int64_t want = GRAFP_TUNE_INT("GRAFP_SEARCH_WANT", nqs == 2 ? 256 * SB_WGS_NQS2 : 768) / qgroups;
+    int64_t want = GRAFP_TUNE_INT("GRAFP_SEARCH_WANT", nqs >= 2 ? 256 * SB_WGS_NQS2 : 768) / qgroups;
     if (want < 1) want = 1;
     // Large batches scan in two parts.  The pre-pass bound (k-th smallest of 64 group minima over n/16 rows) lets a few
     // hundred rows per query through; the first n/4 rows are scanned with it, the k-th smallest UPPER bound among their
@@ -1414,6 +1424,7 @@ extern "C" int grafp_knn_search_l2_pre(const float *db, const void *db_bf16, con
                        n_first, n, q, (const float *)qq, nq, rps, (const float *)thr, cnt, cand_i, cand_e)
     if (qw == 2) { SB_LAUNCH(2, 1); }
     else if (nqs == 1) { SB_LAUNCH(4, 1); }
+    else if (nqs == 3) { SB_LAUNCH(4, 3); }
     else { SB_LAUNCH(4, 2); }
 #undef SB_LAUNCH
     GRAFP_CHECK_LAUNCH("search_bound_bf16_kernel / search_scan_bf16_kernel");

@@ -589,6 +589,27 @@ def test_search_two_part_scan_vs_c_oracle(dev):
     assert np.array_equal(i41.cpu().numpy(), i[:41]) and np.array_equal(d41.cpu().numpy(), d[:41])
 
 
+@pytest.mark.parametrize("nq", [1536, 1921])
+def test_search_three_query_sets_vs_c_oracle(dev, nq):
+    """From 1536 queries a wave of the bf16 scan carries THREE query sets where the last 384-query group pads little
+    (knn_search.hip, pre_plan: nq = 1536 -> 4 groups of 384 exactly; 1921 -> 6 groups, 383 idle slots).  200 000 rows
+    (two-part scan): every query against the all-f32 path (`_search` asserts equal bits), a sample across all groups and
+    query sets against the C oracle, the planted answers, and the first 41 through the one-set form: same bits."""
+    from grafp_amd import ops
+    from oracle import native
+    n, k = 200_000, 20
+    db, q, rows = _planted(n, nq, f"threesets{nq}")
+    dbt, qt = t(db).to(dev), t(q).to(dev)
+    d, i = _search(ops, dbt, qt, k)
+    d, i = d.cpu().numpy(), i.cpu().numpy()
+    sample = np.unique(np.r_[0:8, 30:34, 95:97, 127:130, 383:386, 767:770, 1151:1154, nq - 40:nq])
+    wd, wi = native.flat_search_l2(db, q[sample], k)
+    assert np.array_equal(i[sample], wi) and np.array_equal(d[sample], wd)
+    assert np.array_equal(i[:, 0], rows)                              # planted answers, every query
+    d41, i41 = _search(ops, dbt, qt[:41], k)
+    assert np.array_equal(i41.cpu().numpy(), i[:41]) and np.array_equal(d41.cpu().numpy(), d[:41])
+
+
 def test_search_1m_planted_top1(dev):
     """BASELINE config 4 size: 1 000 000 x 128 database resident on the GPU; planted noisy queries must
     come back top-1, and a sample of queries must match the CPU oracle exactly."""
