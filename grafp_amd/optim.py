@@ -29,8 +29,10 @@ class Adam(torch.optim.Adam):
         device; exp_avg / exp_avg_sq: zeros like the parameter) -- with ONE difference that no reader can see: the step
         counters of a group are 0-d views of one flat tensor, so that bumping all of them is one launch."""
         ps = [p for p in group["params"] if p.requires_grad]
+        if not ps:
+            return None                                          # a group of frozen parameters: nothing to update
         cached = self._tables[gi] if self._tables is not None and gi < len(self._tables) else None
-        if cached is not None and cached["n"] == len(ps) and all(
+        if cached is not None and cached["n"] == len(ps) and cached["p"][0] == ps[0].data_ptr() and all(
                 self.state[p].get("step") is not None and self.state[p]["step"].data_ptr() == cached["steps"].data_ptr() + 4 * i
                 for i, p in ((0, ps[0]), (len(ps) - 1, ps[-1]))):
             return cached
@@ -78,6 +80,8 @@ class Adam(torch.optim.Adam):
             if group.get("weight_decay") or group.get("amsgrad") or group.get("maximize"):
                 raise NotImplementedError("grafp_amd.optim.Adam: weight_decay / amsgrad / maximize are outside the path")
             tab = self._group_state(gi, group)
+            if tab is None:
+                continue
             ps = tab["ps"]
             grads = [p.grad for p in ps]
             if all(g is not None for g in grads):
