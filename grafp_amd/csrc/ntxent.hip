@@ -5,6 +5,10 @@
 // forward, as many backward).  Here:
 //   pass 1 (ntxent_lse_kernel)   S tiles by exact-f32 MFMA (32x32x2), online log-sum-exp over c != r and
 //                                the positive logit, per row                 -> lse[r], pos[r]
+//                                (round 6: the candidate rows are split over `splits` workgroups per 32-row block --
+//                                partial (max, sum, positive) per (split, row), combined in a fixed order by
+//                                ntxent_lse_combine_kernel: 64 workgroups of 16 serial passes at 2 048 rows became
+//                                256 of 4, and every rank of the data-parallel step runs this pass over ALL rows)
 //   pass 2 (ntxent_grad_kernel)  S tiles recomputed; W = softmax_r + softmax_c - 2*onehot in registers;
 //                                dZ_r += W^T Z_c by a second MFMA whose A operand IS the accumulator
 //                                fragment (the k index of step `reg` is mfma_row(reg, half), no shuffle)
@@ -59,7 +63,8 @@ template <int NDB>  // D / 32
 __global__ __launch_bounds__(NT_THREADS) void ntxent_lse_kernel(const float *__restrict__ zi,
                                                                 const float *__restrict__ zj, int Ball,
                                                                 float inv_tau, float *__restrict__ lse,
-                                                                float *__restrict__ pos) {
+                                                                float *__restrict__ pos, int cols_per_split,
+                                                                float *__restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int D = NDB * 32;
     constexpr int LS = D + 1;
@@ -74,19 +79,22 @@ __global__ __launch_bounds__(NT_THREADS) void ntxent_lse_kernel(const float *__r
     nt_stage(sQ, zi, zj, Ball, D, q0, NT_Q, M, LS, tid);
 
     float m_run = -INFINITY, l_run = 0.0f, p = -INFINITY;
-    for (int c0 = 0; c0 < M; c0 += NT_C) {
+    // candidate rows [c_begin, c_end) of this workgroup (blockIdx.y = split; one split: all of them)
+    const int c_begin = blockIdx.y * cols_per_split;
+    const int c_end = c_begin + cols_per_split < M ? c_begin + cols_per_split : M;
+    for (int c0 = c_begin; c0 < c_end; c0 += NT_C) {
         __syncthreads();
         nt_stage(sC, zi, zj, Ball, D, c0, NT_C, M, LS, tid);
         __syncthreads();
         const int cw = c0 + wave * 32;
-        if (cw < M) {  // wave-uniform
+        if (cw < c_end) {  // wave-uniform
             const f32x16 acc = nt_s_tile<D>(sQ, sC + wave * 32 * LS, LS, l31, half);
             float sv[16];
             float tmax = -INFINITY;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int c = cw + mfma_row(r, half);
-                const bool valid = c < M && c != myq;
+                const bool valid = c < c_end && c != myq;
                 const float s = valid ? acc[r] * inv_tau : -INFINITY;
                 if (valid && c == partner) p = s;
                 sv[r] = s;
@@ -128,9 +136,33 @@ __global__ __launch_bounds__(NT_THREADS) void ntxent_lse_kernel(const float *__r
             const float mw = red[(0 * 4 + w) * 32 + tid];
             if (mw > -INFINITY) l += red[(1 * 4 + w) * 32 + tid] * expf(mw - m);
         }
-        lse[myq] = m + logf(l);
-        pos[myq] = pp;
+        if (gridDim.y == 1) {
+            lse[myq] = m + logf(l);
+            pos[myq] = pp;
+        } else {                                   // partial (max, sum, positive) of this split: combined below
+            float *o = part + ((size_t)blockIdx.y * M + myq) * 3;
+            o[0] = m; o[1] = l; o[2] = pp;
+        }
     }
+}
+
+// lse[r], pos[r] from the splits' partial (max, sum, positive) triples, splits in ascending order (deterministic)
+__global__ __launch_bounds__(256) void ntxent_lse_combine_kernel(const float *__restrict__ part, int M, int splits,
+                                                                 float *__restrict__ lse, float *__restrict__ pos) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= M) return;
+    float m = -INFINITY, pp = -INFINITY;
+    for (int s2 = 0; s2 < splits; ++s2) {
+        m = fmaxf(m, part[((size_t)s2 * M + r) * 3]);
+        pp = fmaxf(pp, part[((size_t)s2 * M + r) * 3 + 2]);
+    }
+    float l = 0.0f;
+    for (int s2 = 0; s2 < splits; ++s2) {
+        const float ms = part[((size_t)s2 * M + r) * 3];
+        if (ms > -INFINITY) l += part[((size_t)s2 * M + r) * 3 + 1] * expf(ms - m);
+    }
+    lse[r] = m + logf(l);
+    pos[r] = pp;
 }
 
 // ---- pass 2 -------------------------------------------------------------------------------------
@@ -141,7 +173,8 @@ __global__ __launch_bounds__(NT_THREADS) void ntxent_grad_kernel(const float *__
                                                                  const float *__restrict__ lse,
                                                                  const float *__restrict__ pos,
                                                                  float *__restrict__ loss_partial,
-                                                                 float *__restrict__ dzi, float *__restrict__ dzj) {
+                                                                 float *__restrict__ dzi, float *__restrict__ dzj,
+                                                                 int cols_per_split, float *__restrict__ dzpart) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int D = NDB * 32;
     constexpr int LS = D + 1;
@@ -166,13 +199,17 @@ __global__ __launch_bounds__(NT_THREADS) void ntxent_grad_kernel(const float *__
 #pragma unroll
         for (int r = 0; r < 16; ++r) dz[b][r] = 0.0f;
 
-    for (int c0 = 0; c0 < M; c0 += NT_C) {
+    // candidate rows [c_begin, c_end) of this workgroup (blockIdx.z = split; round 6: at 128 local rows of 2 048 -- one
+    // rank of the 8-GPU step -- eight workgroups walked all sixteen 128-row chunks one after the other: 160 us)
+    const int c_begin = blockIdx.z * cols_per_split;
+    const int c_end = c_begin + cols_per_split < M ? c_begin + cols_per_split : M;
+    for (int c0 = c_begin; c0 < c_end; c0 += NT_C) {
         __syncthreads();
         nt_stage(sC, zi, zj, Ball, D, c0, NT_C, M, LS, tid);
         if (tid < NT_C) sLse[tid] = (c0 + tid < M) ? lse[c0 + tid] : 0.0f;
         __syncthreads();
         const int cw = c0 + wave * 32;
-        if (cw < M) {  // wave-uniform
+        if (cw < c_end) {  // wave-uniform
             const float *sCw = sC + wave * 32 * LS;
             const f32x16 acc = nt_s_tile<D>(sQ, sCw, LS, l31, half);
             float w[16];
@@ -180,7 +217,7 @@ __global__ __launch_bounds__(NT_THREADS) void ntxent_grad_kernel(const float *__
             for (int r = 0; r < 16; ++r) {
                 const int cl = wave * 32 + mfma_row(r, half);
                 const int c = c0 + cl;
-                const bool valid = valid_q && c < M && c != rq;
+                const bool valid = valid_q && c < c_end && c != rq;
                 const float s = acc[r] * inv_tau;
                 const float v = expf(s - lse_q) + expf(s - sLse[cl]) - (c == partner ? 2.0f : 0.0f);
                 w[r] = valid ? v : 0.0f;
@@ -210,11 +247,13 @@ __global__ __launch_bounds__(NT_THREADS) void ntxent_grad_kernel(const float *__
     }
     __syncthreads();
     const float scale = inv_tau / (float)M;
-    float *out = (view == 0 ? dzi : dzj) + (size_t)q0l * D;
+    // one split: the gradient itself; several: this split's partial sum (ntxent_dz_combine_kernel adds them in order)
+    float *out = gridDim.z == 1 ? (view == 0 ? dzi : dzj) + (size_t)q0l * D
+                                : dzpart + ((size_t)(blockIdx.z * 2 + view) * n_local + q0l) * D;
     for (int i = tid; i < NT_Q * D; i += NT_THREADS)
         if (q0l + i / D < n_local) out[i] = buf[i] * scale;
 
-    if (wave == 0) {
+    if (wave == 0 && blockIdx.z == 0) {
         float v = (half == 0 && valid_q) ? (lse_q - pos[rq]) : 0.0f;
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -222,10 +261,32 @@ __global__ __launch_bounds__(NT_THREADS) void ntxent_grad_kernel(const float *__
     }
 }
 
+// dz[view][row][d] = sum over the splits, ascending (deterministic)
+__global__ __launch_bounds__(256) void ntxent_dz_combine_kernel(const float *__restrict__ dzpart, int64_t n_per_view,
+                                                                int splits, float *__restrict__ dzi,
+                                                                float *__restrict__ dzj) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= 2 * n_per_view) return;
+    float acc = 0.0f;
+    for (int s2 = 0; s2 < splits; ++s2) acc += dzpart[(size_t)s2 * 2 * n_per_view + i];
+    if (i < n_per_view) dzi[i] = acc;
+    else dzj[i - n_per_view] = acc;
+}
+
 }  // namespace grafp
 
+// candidate splits of pass 1: NT_C-row chunks dealt to up to 8 workgroups per row block, >= 2 chunks each
+static int nt_splits(int M) {
+    const int chunks = (M + grafp::NT_C - 1) / grafp::NT_C;
+    int sp = chunks / 2;
+    if (sp > 8) sp = 8;
+    return sp < 1 ? 1 : sp;
+}
 extern "C" size_t grafp_ntxent_workspace(int B_all) {
-    return B_all > 0 ? (size_t)4 * B_all * sizeof(float) : 0;  // lse[2B] + pos[2B]
+    if (B_all <= 0) return 0;
+    const size_t M = (size_t)2 * B_all;
+    // lse[2B] + pos[2B] + partial triples of pass 1 + partial gradients of pass 2 (n_local <= B_all rows, D <= 128)
+    return (2 * M + (size_t)nt_splits((int)M) * M * 3 + (size_t)nt_splits((int)M) * M * 128) * sizeof(float);
 }
 
 extern "C" int grafp_ntxent_num_partials(int n_local) {
@@ -249,21 +310,36 @@ extern "C" int grafp_ntxent_fwd_bwd_f32(const float *zi_all, const float *zj_all
     }
     hipStream_t s = (hipStream_t)stream;
     const int M = 2 * B_all, LS = D + 1;
-    float *lse = (float *)ws, *pos = lse + M;
+    float *lse = (float *)ws, *pos = lse + M, *part = pos + M;
     const float inv_tau = 1.0f / tau;
+    const int splits = nt_splits(M);
+    const int chunks = (M + NT_C - 1) / NT_C;
+    const int cols_per_split = ((chunks + splits - 1) / splits) * NT_C;
     const size_t lds1 = ((size_t)(NT_Q + NT_C) * LS + 3 * 4 * 32) * sizeof(float);
     const size_t lds2 = ((size_t)(NT_Q + NT_C) * LS + NT_C) * sizeof(float);
-    const dim3 grid1((M + NT_Q - 1) / NT_Q);
-    const dim3 grid((n_local + NT_Q - 1) / NT_Q, 2);
+    const dim3 grid1((M + NT_Q - 1) / NT_Q, splits);
+    // pass 2: candidate splits so that ~256 workgroups run (never more than pass 1's, >= 2 chunks each)
+    int splits2 = 256 / (2 * ((n_local + NT_Q - 1) / NT_Q));
+    if (splits2 > splits) splits2 = splits;
+    if (splits2 < 1) splits2 = 1;
+    const int cols_per_split2 = ((chunks + splits2 - 1) / splits2) * NT_C;
+    float *dzpart = part + (size_t)splits * M * 3;
+    const dim3 grid((n_local + NT_Q - 1) / NT_Q, 2, splits2);
 #define NT_LAUNCH(NDB)                                                                                              \
     (void)hipFuncSetAttribute((const void *)ntxent_lse_kernel<NDB>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
                               (int)lds1);                                                                           \
     hipLaunchKernelGGL(ntxent_lse_kernel<NDB>, grid1, dim3(NT_THREADS), lds1, s, zi_all, zj_all, B_all, inv_tau,    \
-                       lse, pos);                                                                                   \
+                       lse, pos, cols_per_split, part);                                                             \
+    if (splits > 1)                                                                                                 \
+        hipLaunchKernelGGL(ntxent_lse_combine_kernel, dim3((M + 255) / 256), dim3(256), 0, s, (const float *)part,  \
+                           M, splits, lse, pos);                                                                    \
     (void)hipFuncSetAttribute((const void *)ntxent_grad_kernel<NDB>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
                               (int)lds2);                                                                           \
     hipLaunchKernelGGL(ntxent_grad_kernel<NDB>, grid, dim3(NT_THREADS), lds2, s, zi_all, zj_all, B_all, row_begin,  \
-                       n_local, inv_tau, lse, pos, loss_partial, dzi, dzj)
+                       n_local, inv_tau, lse, pos, loss_partial, dzi, dzj, cols_per_split2, dzpart);                \
+    if (splits2 > 1)                                                                                                \
+        hipLaunchKernelGGL(ntxent_dz_combine_kernel, dim3((unsigned)(((int64_t)2 * n_local * D + 255) / 256)),      \
+                           dim3(256), 0, s, (const float *)dzpart, (int64_t)n_local * D, splits2, dzi, dzj)
     switch (D / 32) {
         case 1: NT_LAUNCH(1); break;
         case 2: NT_LAUNCH(2); break;

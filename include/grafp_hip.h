@@ -425,7 +425,10 @@ int grafp_conv1x1_wgrad_f32(const float *grad_out, const float *x, int Cout, int
  *   zi_all, zj_all (B_all, D) f32, D % 32 == 0, D <= 128
  *   loss_partial   (grafp_ntxent_num_partials(n_local)) f32: sum(loss_partial) / (2*B_all) = the
  *                  local rows' share of the mean loss
- *   dzi, dzj       (n_local, D) f32 gradient of the mean loss (unit upstream gradient) */
+ *   dzi, dzj       (n_local, D) f32 gradient of the mean loss (unit upstream gradient)
+ *   ws             grafp_ntxent_workspace(B_all) bytes: per-row log-sum-exp and positive logit of ALL 2*B_all rows plus
+ *                  the partial (max, sum, positive) triples of the first pass's candidate splits (fixed combination
+ *                  order: deterministic) */
 size_t grafp_ntxent_workspace(int B_all);
 int grafp_ntxent_num_partials(int n_local);
 int grafp_ntxent_fwd_bwd_f32(const float *zi_all, const float *zj_all, int B_all, int D, int row_begin,

@@ -74,7 +74,7 @@ def test_argument_errors_are_reported_without_a_gpu():
     with pytest.raises(RuntimeError, match="null pointer"):
         check(rc, "knn_graph")
     assert lib.grafp_knn_graph_workspace(256, 64, 1024) >= 256 * 64 * 1024 * 4 + 256 * 1024 * 4
-    assert lib.grafp_ntxent_num_partials(256) == 16 and lib.grafp_ntxent_workspace(256) == 4096
+    assert lib.grafp_ntxent_num_partials(256) == 16 and lib.grafp_ntxent_workspace(256) == (2 * 512 + 2 * 512 * 3 + 2 * 512 * 128) * 4
     assert lib.grafp_knn_search_workspace(1_000_000, 41, 128, 20) > 0
     assert lib.grafp_knn_search_workspace(1_000_000, 41, 64, 20) == 0          # only 128-d fingerprints
 
