@@ -686,6 +686,28 @@ def main():
                 finally:
                     if dist.is_initialized():
                         dist.destroy_process_group()
+            # What the one-GPU figures above CANNOT contain: at N = 8 a rank's loss runs its 128 local rows against the 2 048
+            # gathered columns (first pass over all rows), where the single-process step above sees 256.  Timed alone
+            # (HIP events around the launches) so that it can be added to the budget arithmetic.
+            try:
+                gen3 = torch.Generator(device=device).manual_seed(7)
+                za = torch.nn.functional.normalize(torch.randn(1024, 128, generator=gen3, device=device), dim=1)
+                zb = torch.nn.functional.normalize(za + 0.3 * torch.randn(1024, 128, generator=gen3, device=device), dim=1)
+                la, lb = za[:B3].clone().requires_grad_(True), zb[:B3].clone().requires_grad_(True)
+                sa, sb = za[:B3].clone().requires_grad_(True), zb[:B3].clone().requires_grad_(True)
+
+                def loss_us(fn):
+                    for _ in range(3):
+                        fn().backward()
+                    with ops.time_kernels("ntxent") as timed3:
+                        for _ in range(20):
+                            fn().backward()
+                        torch.cuda.synchronize()
+                        return round(1e3 * sum(a.elapsed_time(b) for a, b, _ in timed3["ntxent"]) / 20, 1)
+                c3["loss_128_local_x_2048_global_us"] = loss_us(lambda: ops.ntxent(la, lb, cfg["tau"], za, zb, 0))
+                c3["loss_128_x_256_single_process_us"] = loss_us(lambda: ops.ntxent(sa, sb, cfg["tau"]))
+            except Exception as exc:          # noqa: BLE001 -- report, do not fail the bench line
+                c3["loss_probe_error"] = f"{type(exc).__name__}: {exc}"[:200]
             line["config3_per_gpu_128"] = c3
             # measured parity figures of THIS model and build (numbers, not prose): the free-running distance of the bf16
             # mode from the f32 mode on 256 clip-views (eval mode, random-init weights) -- see tests/test_gpu_bf16.py for
