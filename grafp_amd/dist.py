@@ -188,6 +188,9 @@ class GradSync:
         if self.flat is not None and not self._hooks and self._overlap:
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        if self.flat is not None and self.flat.is_cuda:
+            from . import ops
+            ops._GRAD_TARGET_OF = self._target_of       # weight gradients are produced in place (ops._wgrad_bf16)
 
     def close(self):
         """Detach the autograd hooks (a second GradSync over the same parameters -- another Trainer on the same model --
@@ -198,6 +201,15 @@ class GradSync:
         for h in self._handles:
             h.wait()
         self._handles = []
+        if self.flat is not None and self.flat.is_cuda:
+            from . import ops
+            if getattr(ops._GRAD_TARGET_OF, "__self__", None) is self:
+                ops._GRAD_TARGET_OF = None
+
+    def _target_of(self, p):
+        """The slice of the flat buffer a kernel may write parameter p's gradient into directly -- only while p has no
+        gradient yet (autograd then takes the tensor over; an existing .grad would be ADDED to, i.e. to itself)."""
+        return self._view.get(id(p)) if (p is not None and p.grad is None) else None
 
     def _pack(self, b):
         """Bucket b's gradients -> its slice of the flat buffer: one multi-tensor copy.  A parameter that took no part

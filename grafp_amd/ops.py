@@ -1027,11 +1027,24 @@ def defer_wgrad_reduce():
         _WGRAD_DEFERRED_IDS.clear()
 
 
-def _wgrad_bf16(g, x, cout, cin, groups, M, views=1, pro_tab=None, pro_act=ACT_NONE, pro_slope=0.0, tile=-1, may_defer=True):
+# Under data parallelism the parameter gradients live in ONE flat buffer (dist.GradSync) that the bucket all-reduces run on.
+# GradSync.open() registers a function here that maps a parameter to its slice of that buffer (or None): the weight
+# gradient of a layer is then reduced STRAIGHT into the slice -- autograd takes the tensor over as the parameter's .grad, and
+# the bucket's pack step finds it in place (no 50 MB of multi-tensor copies per step at N = 8).
+_GRAD_TARGET_OF = None
+
+
+def _wgrad_bf16(g, x, cout, cin, groups, M, views=1, pro_tab=None, pro_act=ACT_NONE, pro_slope=0.0, tile=-1, may_defer=True,
+                out=None):
     """dW = g f(x)^T for bf16 (rows, M) operands -> (cout, cin/groups) f32; pro_tab (cin, views, 2): f = the BatchNorm
     + activation of the layer that produced x, applied on the fly (see conv1x1_gemm).  tile: -1 = the library's rule,
-    otherwise that tile configuration (grafp_conv1x1_wgrad_tile_bf16; tests)."""
-    dw = torch.empty((cout, cin // groups), dtype=torch.float32, device=x.device)
+    otherwise that tile configuration (grafp_conv1x1_wgrad_tile_bf16; tests).  out: a contiguous f32 tensor of
+    cout * cin / groups elements on x's device to write the gradient into (see _GRAD_TARGET_OF)."""
+    if out is not None and out.dtype == torch.float32 and out.is_contiguous() and out.device == x.device \
+            and out.numel() == cout * (cin // groups):
+        dw = out.view(cout, cin // groups)
+    else:
+        dw = torch.empty((cout, cin // groups), dtype=torch.float32, device=x.device)
     nbytes = lib.grafp_conv1x1_wgrad_tile_workspace(cout, cin, groups, M, views, int(tile))
     ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
     tab = None if pro_tab is None else _f32c(pro_tab)
@@ -1170,11 +1183,15 @@ class _ConvBnAct(torch.autograd.Function):
                 dx = conv1x1_gemm(_group_transpose(wl, cg), dy, cg, 1)
         dw = None
         if ctx.needs_input_grad[1]:
+            md = _may_defer(ctx.w_param)
+            # (a deferred gradient is the FIRST of this weight in the pass and nothing reads it before the flush: it may be
+            #  produced in place, in the parameter's slice of the data-parallel flat buffer)
+            tgt = _GRAD_TARGET_OF(ctx.w_param) if (md and _WGRAD_PENDING is not None and _GRAD_TARGET_OF is not None) else None
             if ctx.pro is not None:                        # x is the producer's raw output: the same transform on load
-                dw = _wgrad_bf16(dy, x, R, K, cg, M, views, ctx.pro[0], ctx.pro[1], ctx.pro[2],
-                                 may_defer=_may_defer(ctx.w_param)).reshape(wfull)
+                dw = _wgrad_bf16(dy, x, R, K, cg, M, views, ctx.pro[0], ctx.pro[1], ctx.pro[2], may_defer=md,
+                                 out=tgt).reshape(wfull)
             else:
-                dw = _wgrad_bf16(dy, x, R, K, cg, M, may_defer=_may_defer(ctx.w_param)).reshape(wfull)
+                dw = _wgrad_bf16(dy, x, R, K, cg, M, may_defer=md, out=tgt).reshape(wfull)
         dres = dz if has_res else None
         if has_res and tok is not None and ctx.token_role == 2 and tok.grad is None:
             tok.grad, dres = dz, None                      # the first layer's backward adds it (see above)
