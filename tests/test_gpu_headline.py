@@ -184,9 +184,12 @@ def test_headline_step_kernels_vs_references(dev):
             assert bool((err <= tol).all()), (key, float((err / tol).max()))
         return out
 
-    def wgrad(g, x, cout, cin, groups, M, views=1, pro_tab=None, pro_act=0, pro_slope=0.0, tile=-1, may_defer=True):
-        # (checked right here against the reference: reduced at once, whatever the caller would allow)
-        dw = orig["_wgrad_bf16"](g, x, cout, cin, groups, M, views, pro_tab, pro_act, pro_slope, tile, may_defer=False)
+    def wgrad(g, x, cout, cin, groups, M, views=1, pro_tab=None, pro_act=0, pro_slope=0.0, tile=-1, may_defer=True,
+              out=None):
+        # (checked right here against the reference: reduced at once, whatever the caller would allow; `out` -- the
+        #  parameter's slice of a data-parallel flat buffer -- is honoured as the product does)
+        dw = orig["_wgrad_bf16"](g, x, cout, cin, groups, M, views, pro_tab, pro_act, pro_slope, tile, may_defer=False,
+                                 out=out)
         key = (cout, cin, groups, M, views, pro_tab is not None)
         if key not in ck.seen["wgrad"]:
             ck.seen["wgrad"].add(key)
