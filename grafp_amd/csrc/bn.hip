@@ -660,8 +660,8 @@ __global__ __launch_bounds__(THREADS) void bn_bwd1_kernel(const T *__restrict__ 
     for (int it = 0; it < ITEMS; ++it) {
         const int64_t m = lo + ((int64_t)it * THREADS + tid) * W;
         if (m < hi) {
-            rx[it] = *reinterpret_cast<const typename BnIO<T>::Raw *>(row + m);
-            rd[it] = *reinterpret_cast<const typename BnIO<T>::Raw *>(grow + m);
+            rx[it] = GRAFP_LD_ONCE(1, reinterpret_cast<const typename BnIO<T>::Raw *>(row + m));
+            rd[it] = GRAFP_LD_ONCE(4, reinterpret_cast<const typename BnIO<T>::Raw *>(grow + m));
         }
     }
     float sd = 0.0f, sdx = 0.0f;

@@ -62,6 +62,32 @@ __device__ __forceinline__ void store8_hint(void *p, st_u32x2 v, bool plain) {
 }
 }  // namespace grafp
 
+// A load of data that is read ONCE (a saved activation in backward, a product's raw output in its normalise pass): the
+// non-temporal hint keeps it from displacing what the next launches re-read.  GRAFP_NT_LOADS is a bit mask of the sites
+// that use it (experiment builds override it: make measure XFLAGS=-DGRAFP_NT_LOADS=n):
+//   1 bn_bwd1: x   2 bn_affine: y   4 bn_bwd1: dz   8 bn_affine: shortcut   16 mrconv_bwd: g   32 mrconv_fwd: x
+// Whole-step A/B of builds (tools/step_lib_ab.py, graph replays; profiles/r06_l_nt_loads_*.txt), 128 / 256 / 1024 pairs:
+// mask 1: -1.0 / -0.8 / -0.4 %;  2: -0.2 / -0.4 / -0.8 %;  7: -1.1 / -1.0 / -1.0 ... -1.4 %;  15: -1.3 / -1.0 / -1.5 %;
+// 63: -1.3 / -1.7 / -1.4 %  -> all six sites.  (The products' X operand is NOT such a load: its column panel is re-read by
+// the other row tiles through L2, and the hint cost 3 % there in round 2.)
+#ifndef GRAFP_NT_LOADS
+#define GRAFP_NT_LOADS 63
+#endif
+namespace grafp {
+template <typename V> __device__ __forceinline__ V ld_once_nt(const V *p) {
+    if constexpr (sizeof(V) == 16) {
+        typedef unsigned e4 __attribute__((ext_vector_type(4)));
+        return __builtin_bit_cast(V, __builtin_nontemporal_load(reinterpret_cast<const e4 *>(p)));
+    } else if constexpr (sizeof(V) == 8) {
+        typedef unsigned e2 __attribute__((ext_vector_type(2)));
+        return __builtin_bit_cast(V, __builtin_nontemporal_load(reinterpret_cast<const e2 *>(p)));
+    } else {
+        return *p;
+    }
+}
+}  // namespace grafp
+#define GRAFP_LD_ONCE(bit, p) (((GRAFP_NT_LOADS) & (bit)) ? grafp::ld_once_nt(p) : *(p))
+
 #define GRAFP_REQUIRE(cond, ...)              \
     do {                                      \
         if (!(cond)) {                        \

@@ -669,8 +669,8 @@ __global__ __launch_bounds__(256) void bn_affine_bf16_kernel(const unsigned shor
     auto fetch = [&]() {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            rx[u] = *reinterpret_cast<const uint4 *>(row + m + u * step);
-            rr[u] = rrow ? *reinterpret_cast<const uint4 *>(rrow + m + u * step) : make_uint4(0, 0, 0, 0);
+            rx[u] = GRAFP_LD_ONCE(2, reinterpret_cast<const uint4 *>(row + m + u * step));
+            rr[u] = rrow ? GRAFP_LD_ONCE(8, reinterpret_cast<const uint4 *>(rrow + m + u * step)) : make_uint4(0, 0, 0, 0);
         }
     };
     if (full) fetch();                                        // in flight while the statistics are combined

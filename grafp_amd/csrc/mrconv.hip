@@ -219,7 +219,7 @@ __global__ __launch_bounds__(MR_THREADS) void mrconv_fwd_p_kernel(const T *__res
         const int c0 = slab * CC, cc = min(CC, C - c0);
 #pragma unroll
         for (int it = 0; it < MRP_ITEMS; ++it)
-            if (pc[it] < cc) pv[par][it] = *reinterpret_cast<const Raw *>(xb + (size_t)(c0 + pc[it]) * x_sc + pn[it]);
+            if (pc[it] < cc) pv[par][it] = GRAFP_LD_ONCE(32, reinterpret_cast<const Raw *>(xb + (size_t)(c0 + pc[it]) * x_sc + pn[it]));
     };
     int slab = blockIdx.x;
     const int G = gridDim.x;
@@ -538,8 +538,8 @@ __global__ __launch_bounds__(MR_THREADS) void mrconv_bwd_a_kernel(const unsigned
 #pragma unroll
         for (int it = 0; it < MRB_ITEMS; ++it) {
             if (pc[it] < cc) {
-                pe[par][it] = *reinterpret_cast<const Raw *>(ge_p[it]);
-                po[par][it] = *reinterpret_cast<const Raw *>(ge_p[it] + g_sc);
+                pe[par][it] = GRAFP_LD_ONCE(16, reinterpret_cast<const Raw *>(ge_p[it]));
+                po[par][it] = GRAFP_LD_ONCE(16, reinterpret_cast<const Raw *>(ge_p[it] + g_sc));
                 pa[par][it] = *ar_p[it];
             }
             ge_p[it] += ge_step;
