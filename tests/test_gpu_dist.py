@@ -134,11 +134,15 @@ def _ranks_against_one_process(tmp_path, world, B, tag):
     loss_v = float(loss.detach())
     assert abs(sum(g["loss_share"] for g in got) - loss_v) <= 1e-5 * max(1.0, abs(loss_v))
     params = dict(model.named_parameters())
+    rel = {}
     for name, g in got[0]["grads"].items():
         want = params[name].grad.detach().float().cpu()
-        assert (g - want).norm() / want.norm().clamp_min(1e-12) < 2e-4, name
+        rel[name] = float((g - want).norm() / want.norm().clamp_min(1e-12))
         for r in range(1, world):
             assert torch.equal(g, got[r]["grads"][name]), (name, r)    # every rank holds the same reduced gradient
+    # (all names in one message: a mismatch that grows towards the first layers points at one backward kernel, the same
+    #  factor everywhere at the loss / the reduction)
+    assert max(rel.values()) < 2e-4, rel
     want_norm = torch.sqrt(sum((p.grad.float() ** 2).sum() for p in model.parameters() if p.grad is not None)).item()
     for r in range(world):
         assert abs(got[r]["grad_norm"] - want_norm) <= 2e-4 * want_norm
