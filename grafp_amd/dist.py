@@ -23,6 +23,19 @@ import torch
 import torch.distributed as dist
 
 
+def shared_device_cu_mask(rank, world, cus=256):
+    """ROC_GLOBAL_CU_MASK of rank `rank` when `world` processes share ONE device: disjoint, equal slices of its CUs.
+    Only the test layouts do that (production is one process per GPU).  Why they need it: from four processes that share
+    CUs on MI355X / ROCm 7.2, single 64-byte loads or registers of long-lived waves come back wrong a few times per
+    10^5 launches once a process has run the bf16 step (tools/contention/); with disjoint CU
+    sets the step is bit-reproducible (0 of 240 iterations against 20-34 of 120).  NOTE the f32 mode's library GEMMs
+    pick their splits by the number of CUs they see: results under a mask differ in the low bits (1e-4 on an embedding)
+    from those on the whole device -- compare like with like (tests/test_gpu_dist.py runs its one-process side under a
+    mask of the same width)."""
+    per = max(1, cus // max(1, world))
+    return hex(((1 << per) - 1) << (per * (rank % max(1, cus // per))))
+
+
 def init_from_env(backend=None, local_device=None):
     """RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as set by torch.distributed.run.  Returns (rank, world, device).
     backend / local_device: for a box with fewer GPUs than ranks (the tests run two ranks on cuda:0 over gloo: same
@@ -30,6 +43,11 @@ def init_from_env(backend=None, local_device=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if local_device is not None and world > 2:
+        # three or more ranks sharing a device (test layouts): disjoint CU sets, see shared_device_cu_mask (two ranks
+        # showed no differing iteration in 80); a launcher that set the variable itself wins.  Measured: the HIP runtime
+        # reads it at its first call, not when torch is imported, so this is early enough
+        os.environ.setdefault("ROC_GLOBAL_CU_MASK", shared_device_cu_mask(rank, world))
     if torch.cuda.is_available():
         if local_device is not None:
             local = int(local_device)

@@ -121,8 +121,41 @@ def graph_mode(out, B, rccl_one_rank=False, overlap=True, timeline=False):
     torch.distributed.destroy_process_group()
 
 
+def reference_mode(out, B, world):
+    """ONE process pushes the `world` shards of the batch through the model one after the other (per-replica BatchNorm
+    statistics, as under the reference's DataParallel, train.py:165-168) and takes the loss over the concatenated batch
+    (train.py:69-71): the embeddings, the loss, every gradient and their norm -> OUT.ref.pt.  A process of its own so
+    that it can run under the same ROC_GLOBAL_CU_MASK width as the ranks: the library GEMMs of the f32 mode pick their
+    splits by the number of CUs they see, i.e. their low bits follow it."""
+    from grafp_amd.simclr.ntxent import ntxent_loss
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    cfg = load_config()
+    cfg["bsz_train"] = B
+    torch.manual_seed(1234)
+    model = build_model(cfg, device=device)
+    trainer = Trainer(cfg, model, device, amp_dtype=None)
+    x_i, x_j = synthetic_batch(B, 7, device)
+    model.train()
+    per = B // world
+    zs_i, zs_j = [], []
+    for r in range(world):
+        with torch.no_grad():
+            X_i, X_j = trainer.augment(x_i[r * per:(r + 1) * per], x_j[r * per:(r + 1) * per])
+        _, _, z_i, z_j = model(X_i, X_j)
+        zs_i.append(z_i); zs_j.append(z_j)
+    loss = ntxent_loss(torch.cat(zs_i), torch.cat(zs_j), cfg)
+    loss.backward()
+    grads = {n: p.grad.detach().float().cpu() for n, p in model.named_parameters() if p.grad is not None}
+    norm = torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values())).item()
+    torch.save({"z_i": [z.detach().cpu() for z in zs_i], "loss": float(loss.detach()), "grads": grads, "grad_norm": norm},
+               f"{out}.ref.pt")
+
+
 def main():
     out, B = sys.argv[1], int(sys.argv[2])
+    if len(sys.argv) > 4 and sys.argv[3] == "reference":
+        return reference_mode(out, B, int(sys.argv[4]))
     if len(sys.argv) > 3 and sys.argv[3] in ("graph", "graph_rccl1", "graph_rccl1_single", "graph_rccl1_timeline"):
         return graph_mode(out, B, rccl_one_rank=sys.argv[3] != "graph", overlap=sys.argv[3] != "graph_rccl1_single",
                           timeline=sys.argv[3] == "graph_rccl1_timeline")

@@ -1,0 +1,89 @@
+"""Several processes share cuda:0; each repeats the SAME 128-pair forward + backward and checks that every output is the
+same BITS each time (one process alone is bit-reproducible: tests/test_gpu_repro.py).
+
+    python tools/contention/step_stress.py NPROC ITERS bf16|f32 [switches] [--disjoint-cus]
+
+switches: '+'-joined from two_pass, spin0, nofuse, nodefer, noknnsplit, noarg (grafp_amd.ops.switches).
+--disjoint-cus gives rank r the CUs [r * 256 / NPROC, (r + 1) * 256 / NPROC) through ROC_GLOBAL_CU_MASK.
+Prints per rank the number of iterations that differ from iteration 0 and, for the first few, which tensors.
+Findings on MI355X / ROCm 7.2: from 4 processes that share CUs some iterations differ -- single
+64-byte loads / single registers of one wave are wrong in the kernels with the longest-lived register state (log-mel,
+single-pass BatchNorm, peak-extractor backward); with disjoint CU sets: 0 of 240."""
+import hashlib
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+
+def cu_mask(rank, world, cus=256):
+    per = cus // world
+    return hex(((1 << per) - 1) << (per * rank))
+
+
+def md5(t):
+    return hashlib.md5(t.detach().float().cpu().numpy().tobytes()).hexdigest()
+
+
+def worker(rank, iters, amp, opt):
+    import torch
+    from grafp_amd import ops
+    from grafp_amd.simclr.ntxent import ntxent_loss
+    from grafp_amd.train import Trainer, build_model, synthetic_batch
+    from grafp_amd.util import load_config
+    for o in opt.split("+"):
+        if o == "two_pass": ops.switches.bn_two_pass = True
+        elif o == "spin0": ops.switches.bn_spin_limit = 0
+        elif o == "nofuse": ops.switches.fused_conv_bn = False
+        elif o == "nodefer": ops.switches.defer_norm = False
+        elif o == "noknnsplit": ops.switches.knn_split = False
+        elif o == "noarg": ops.switches.mrconv_arg = False
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    cfg = load_config()
+    cfg["bsz_train"] = 128
+    torch.manual_seed(1234)
+    model = build_model(cfg, device=dev)
+    tr = Trainer(cfg, model, dev, amp_dtype=torch.bfloat16 if amp else None)
+    x_i, x_j = synthetic_batch(1024, 7, dev)
+    x_i, x_j = x_i[rank * 128:(rank + 1) * 128], x_j[rank * 128:(rank + 1) * 128]
+    model.train()
+    per = []
+    for it in range(iters):
+        for p in model.parameters():
+            p.grad = None
+        with torch.no_grad():
+            X_i, X_j = tr.augment(x_i, x_j)
+        with tr._autocast():
+            _, _, z_i, z_j = model(X_i, X_j)
+        loss = ntxent_loss(z_i, z_j, cfg)
+        loss.backward()
+        torch.cuda.synchronize()
+        hs = {"0 X_i": md5(X_i), "0 X_j": md5(X_j), "1 z_i": md5(z_i), "1 z_j": md5(z_j), "2 loss": md5(loss)}
+        hs.update({"3 " + n: md5(p.grad) for n, p in model.named_parameters() if p.grad is not None})
+        per.append(hs)
+    bad = [i for i in range(1, iters) if per[i] != per[0]]
+    msg = f"[{opt}] rank {rank}: {iters} iterations, BAD {len(bad)}"
+    for i in bad[:3]:
+        diff = sorted(n for n in per[0] if per[0][n] != per[i][n])
+        msg += f"\n   iteration {i}: {len(diff)} of {len(per[0])} tensors differ, first {diff[:4]}"
+    print(msg, flush=True)
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "--worker":
+        worker(int(sys.argv[2]), int(sys.argv[3]), sys.argv[4] == "bf16", sys.argv[5])
+    else:
+        args = [a for a in sys.argv[1:] if not a.startswith("--")]
+        n, iters, mode = int(args[0]), int(args[1]), args[2]
+        opt = args[3] if len(args) > 3 else "default"
+        procs = []
+        for r in range(n):
+            env = dict(os.environ)
+            if "--disjoint-cus" in sys.argv:
+                env["ROC_GLOBAL_CU_MASK"] = cu_mask(r, n)
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--worker", str(r), str(iters), mode, opt],
+                                          env=env))
+        sys.exit(max(p.wait() for p in procs))
