@@ -407,6 +407,11 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
+    # stdout carries the ONE JSON line and nothing else: everything a library prints on file descriptor 1 while the
+    # bench runs (RCCL's version banner at the first communicator, progress lines of the retrieval legs) goes to stderr
+    sys.stdout.flush()
+    line_fd = os.dup(1)
+    os.dup2(2, 1)
     from grafp_amd import dist as gdist
     from grafp_amd import ops
     from grafp_amd.train import Trainer, build_model, synthetic_batch
@@ -891,7 +896,8 @@ def main():
             "retrieval_frac_nq1_nq41_nq4096": [pick(line, "retrieval", "roofline", n, "frac") for n in ("nq1", "nq41", "nq4096")],
             "retrieval_ms_nq4096": pick(line, "retrieval", "ms_per_batch_nq4096"),
         }
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(line_fd, (json.dumps(line) + "\n").encode())
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

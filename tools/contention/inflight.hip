@@ -1,0 +1,96 @@
+// inflight.hip -- the smallest victim: a copy kernel that keeps N 16-byte loads per thread in flight (N x 4 VGPRs live until
+// the last one has returned) and then writes them back.  No LDS, no barrier, no inline asm, no dependence between
+// workgroups; plain hipcc output.  Used by two_stream.py (victim "copyN").
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+template <int N>
+__global__ __launch_bounds__(256) void inflight_copy(const float4 *__restrict__ in, float4 *__restrict__ out, int64_t n) {
+    const int64_t base = (int64_t)blockIdx.x * 256 * N + threadIdx.x;
+    float4 r[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) r[i] = in[base + (int64_t)i * 256];
+    __builtin_amdgcn_sched_barrier(0);            // every load is issued before the first store (else hipcc interleaves them)
+#pragma unroll
+    for (int i = 0; i < N; ++i) out[base + (int64_t)i * 256] = r[i];
+}
+
+// A pure arithmetic victim: every thread runs a chain of `iters` x 8 multiply-adds on 16 registers and stores the result --
+// PK: on float2 operands (hipcc emits v_pk_fma_f32), otherwise on scalars (v_fma_f32).  The result is a deterministic
+// function of (thread, iters): any difference between two launches is a wrong ALU result or a wrong register.
+typedef float f2 __attribute__((ext_vector_type(2)));
+template <bool PK>
+__global__ __launch_bounds__(256) void alu_chain(const float *__restrict__ in, float *__restrict__ out, int iters) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (PK) {
+        f2 a[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] = f2{in[(t * 16 + 2 * i) & 65535], in[(t * 16 + 2 * i + 1) & 65535]};
+        const f2 m = f2{0.999f, 1.001f}, c = f2{0.001f, -0.001f};
+        for (int k = 0; k < iters; ++k) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a[i] = __builtin_elementwise_fma(a[i], m, c + a[(i + 1) & 7] * 1e-3f);
+        }
+        f2 s = a[0];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) s += a[i];
+        out[t] = s.x + s.y;
+    } else {
+        float a[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a[i] = in[(t * 16 + i) & 65535];
+        for (int k = 0; k < iters; ++k) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float m = (i & 1) ? 1.001f : 0.999f, c = (i & 1) ? -0.001f : 0.001f;
+                a[i] = __builtin_fmaf(a[i], m, c + a[(i + 2) & 15] * 1e-3f);
+            }
+        }
+        float s = a[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) s += a[i];
+        out[t] = s;
+    }
+}
+
+// An LDS victim: every thread writes 8 words of a pattern into the workgroup's LDS, then for `rounds` rounds sleeps and
+// reads them back; out[block] = number of words that came back different (0 in a correct machine, whatever else runs).
+__global__ __launch_bounds__(256) void lds_hold(int *__restrict__ out, int rounds, int lds_words) {
+    extern __shared__ unsigned lds[];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < lds_words; i += 256) lds[i] = 0x9e3779b9u * (unsigned)(i + 1) + blockIdx.x;
+    __syncthreads();
+    int bad = 0;
+    for (int r = 0; r < rounds; ++r) {
+        __builtin_amdgcn_s_sleep(32);
+        for (int i = tid; i < lds_words; i += 256) bad += lds[i] != 0x9e3779b9u * (unsigned)(i + 1) + blockIdx.x;
+    }
+    for (int o = 32; o > 0; o >>= 1) bad += __shfl_xor(bad, o);
+    if ((tid & 63) == 0 && bad) atomicAdd(out + blockIdx.x, bad);
+}
+
+extern "C" int lds_hold_launch(void *out, int blocks, int rounds, int lds_bytes, void *stream) {
+    (void)hipFuncSetAttribute((const void *)lds_hold, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    hipLaunchKernelGGL(lds_hold, dim3(blocks), dim3(256), lds_bytes, (hipStream_t)stream, (int *)out, rounds, lds_bytes / 4);
+    return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+extern "C" int alu_chain_launch(const void *in, void *out, int blocks, int iters, int packed, void *stream) {
+    if (packed) hipLaunchKernelGGL(alu_chain<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float *)in, (float *)out, iters);
+    else hipLaunchKernelGGL(alu_chain<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float *)in, (float *)out, iters);
+    return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+extern "C" int inflight_copy_launch(const void *in, void *out, int64_t n_vec, int per_thread, void *stream) {
+    const int64_t per_block = 256 * (int64_t)per_thread;
+    if (n_vec % per_block) return 1;
+    const dim3 grid((unsigned)(n_vec / per_block));
+    switch (per_thread) {
+        case 4: hipLaunchKernelGGL(inflight_copy<4>, grid, dim3(256), 0, (hipStream_t)stream, (const float4 *)in, (float4 *)out, n_vec); break;
+        case 16: hipLaunchKernelGGL(inflight_copy<16>, grid, dim3(256), 0, (hipStream_t)stream, (const float4 *)in, (float4 *)out, n_vec); break;
+        case 32: hipLaunchKernelGGL(inflight_copy<32>, grid, dim3(256), 0, (hipStream_t)stream, (const float4 *)in, (float4 *)out, n_vec); break;
+        case 56: hipLaunchKernelGGL(inflight_copy<56>, grid, dim3(256), 0, (hipStream_t)stream, (const float4 *)in, (float4 *)out, n_vec); break;
+        default: return 2;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : 3;
+}

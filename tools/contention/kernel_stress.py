@@ -9,9 +9,10 @@ rank r runs KIND[r % len].  PRELUDE runs two training steps of the model in the 
 depthN: peak extractor, weight preparation, stem and the first N backbone modules only; free: the model is deleted and the
 allocator emptied before the loop).
 Findings on MI355X / ROCm 7.2: without a prelude every kind is bit-stable over millions of
-launches, also next to processes that run the full step; after a bf16 prelude logmel, peak and bn show wrong 64-byte
-pieces a few times per 10^5 launches (more the deeper the prelude ran), logmel512 / logmel2048 / bn2 / mm never; an f32
-prelude or single kernels as prelude: never; disjoint CU sets: never."""
+launches.  With a bf16 prelude logmel, peak and bn show wrong 64-byte pieces in their FIRST ~1 000 launches -- while the
+other processes are still running their prelude, i.e. next to those processes' bf16 GEMMs (the deeper the prelude runs,
+the longer that window) -- logmel512 / logmel2048 / bn2 / mm never; an f32 prelude: never; disjoint CU sets: never.
+two_stream.py shows the same in ONE process (the GEMM on a second stream)."""
 import os
 import subprocess
 import sys

@@ -7,8 +7,9 @@ switches: '+'-joined from two_pass, spin0, nofuse, nodefer, noknnsplit, noarg (g
 --disjoint-cus gives rank r the CUs [r * 256 / NPROC, (r + 1) * 256 / NPROC) through ROC_GLOBAL_CU_MASK.
 Prints per rank the number of iterations that differ from iteration 0 and, for the first few, which tensors.
 Findings on MI355X / ROCm 7.2: from 4 processes that share CUs some iterations differ -- single
-64-byte loads / single registers of one wave are wrong in the kernels with the longest-lived register state (log-mel,
-single-pass BatchNorm, peak-extractor backward); with disjoint CU sets: 0 of 240."""
+64-byte pieces / single registers of one wave are wrong in the kernels with the longest-lived waves (log-mel, single-pass
+BatchNorm, peak-extractor backward) while another process's bf16 GEMM runs on the same CUs (two_stream.py: the same in
+one process); with disjoint CU sets: 0 of 240."""
 import hashlib
 import os
 import subprocess

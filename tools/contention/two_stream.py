@@ -1,0 +1,138 @@
+"""ONE process, two streams: stream A repeats a kernel of this repository on fixed inputs and checks its output bits,
+stream B keeps the device busy with torch matrix products (no code of this repository).
+
+    python tools/contention/two_stream.py VICTIM OFFENDER SECONDS
+VICTIM: bn | bn2 | logmel | peak | mm | t_layernorm | t_softmax | t_batchnorm | t_cumsum | t_gelu | t_conv (torch only) | copy4 | copy16 | copy32 | alu_pk | alu_scalar | lds8 | lds64 (inflight.hip); OFFENDER: mmbf16 | mmf32 | mmbf16small (torch products) | gemm | knn | mr | wgrad (kernels of this repository) | none"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from grafp_amd import ops  # noqa: E402
+
+victim, offender, secs = sys.argv[1], sys.argv[2], float(sys.argv[3])
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+g = torch.Generator(device="cpu").manual_seed(5)
+if victim in ("bn", "bn2"):
+    ops.switches.bn_two_pass = victim == "bn2"
+    C, M = 160, 256 * 512
+    x = torch.randn(C, M, generator=g).to(dev)
+    ga, be = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    f = lambda: ops.bn_act(x, ga, be, rm.clone(), rv.clone(), True, act=1, groups=2)
+elif victim == "logmel":
+    wav = (torch.rand(256, 16000, generator=g) * 2 - 1).to(dev)
+    f = lambda: ops.logmel(wav, 16000, 1024, 1024, 512, 64)
+elif victim == "peak":
+    spec = torch.randn(256, 64, 32, generator=g).to(dev)
+    w = (torch.randn(8, 3, 7, 7, generator=g) * 0.1).to(dev)
+    b = torch.zeros(8, device=dev)
+    f = lambda: ops.peak_extract(spec, w, b, 2)
+elif victim.startswith("copy"):                # tools/contention/inflight.hip: N 16-byte loads per thread in flight, then N stores
+    import ctypes
+    so = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libinflight.so")
+    if not os.path.exists(so):
+        raise SystemExit("build it first: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -shared tools/contention/inflight.hip "
+                         "-o tools/contention/libinflight.so")
+    cl = ctypes.CDLL(so)
+    cl.inflight_copy_launch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
+    per = int(victim[4:])
+    n_vec = 256 * per * 2048                                    # 2048 workgroups
+    src = torch.randn(n_vec * 4, generator=g).to(dev)
+
+    def f():
+        out = torch.empty_like(src)
+        rc = cl.inflight_copy_launch(src.data_ptr(), out.data_ptr(), n_vec, per,
+                                     torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
+        assert rc == 0, rc
+        return out
+elif victim in ("alu_pk", "alu_scalar"):       # inflight.hip: a chain of packed (v_pk_fma_f32) / scalar (v_fma_f32) multiply-adds
+    import ctypes
+    cl = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libinflight.so"))
+    cl.alu_chain_launch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    src = torch.rand(65536, generator=g).to(dev)
+
+    def f():
+        out = torch.empty(2048 * 256, device=dev)
+        rc = cl.alu_chain_launch(src.data_ptr(), out.data_ptr(), 2048, 400, int(victim == "alu_pk"),
+                                 torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
+        assert rc == 0, rc
+        return out
+elif victim.startswith("lds"):                 # inflight.hip: a pattern held in LDS (ldsNN = NN KB per workgroup) and re-read for ~100 us
+    import ctypes
+    cl = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libinflight.so"))
+    cl.lds_hold_launch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    kb = int(victim[3:])
+
+    def f():
+        out = torch.zeros(1024, dtype=torch.int32, device=dev)
+        rc = cl.lds_hold_launch(out.data_ptr(), 1024, 40, kb * 1024, torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
+        assert rc == 0, rc
+        return out
+elif victim == "t_layernorm":
+    a1 = torch.randn(8192, 2048, generator=g).to(dev)
+    f = lambda: torch.nn.functional.layer_norm(a1, (2048,))
+elif victim == "t_softmax":
+    a1 = torch.randn(8192, 2048, generator=g).to(dev)
+    f = lambda: torch.softmax(a1, dim=1)
+elif victim == "t_batchnorm":
+    a1 = torch.randn(256, 160, 512, generator=g).to(dev)
+    f = lambda: torch.nn.functional.batch_norm(a1, None, None, training=True)
+elif victim == "t_cumsum":
+    a1 = torch.randn(8192, 2048, generator=g).to(dev)
+    f = lambda: torch.cumsum(a1, dim=1)
+elif victim == "t_gelu":
+    a1 = torch.randn(8192, 2048, generator=g).to(dev)
+    f = lambda: torch.nn.functional.gelu(a1 * 1.5 + a1.sin())
+elif victim == "t_conv":
+    a1 = torch.randn(64, 32, 64, 64, generator=g).to(dev); cw = (torch.randn(32, 32, 3, 3, generator=g) / 17).to(dev)
+    f = lambda: torch.nn.functional.conv2d(a1, cw, padding=1)
+else:
+    a1, a2 = torch.randn(2048, 2048, generator=g).to(dev), torch.randn(2048, 2048, generator=g).to(dev)
+    f = lambda: a1 @ a2
+if offender == "mmbf16":
+    o1 = torch.randn(4096, 4096, device=dev).bfloat16()
+    off = lambda: o1 @ o1
+elif offender == "mmf32":
+    o1 = torch.randn(4096, 4096, device=dev)
+    off = lambda: o1 @ o1
+elif offender == "mmbf16small":
+    o1, o2 = torch.randn(128, 128, device=dev).bfloat16(), torch.randn(128, 262144, device=dev).bfloat16()
+    off = lambda: o1 @ o2
+elif offender == "gemm":                      # this repository's streaming GEMM on the same product as mmbf16small
+    o1, o2 = torch.randn(128, 128, device=dev).bfloat16(), torch.randn(128, 262144, device=dev).bfloat16()
+    off = lambda: ops.conv1x1_gemm(o1, o2)
+elif offender == "knn":
+    o1 = torch.randn(64, 96, 1024, device=dev).bfloat16()
+    off = lambda: ops.knn_graph(o1, 3)
+elif offender == "mr":
+    o1 = torch.randn(64, 96, 1024, device=dev).bfloat16()
+    o2 = torch.randint(0, 1024, (64, 1024, 3), device=dev)
+    off = lambda: ops.max_relative(o1, o2)
+elif offender == "wgrad":
+    o1, o2 = torch.randn(128, 262144, device=dev).bfloat16(), torch.randn(128, 262144, device=dev).bfloat16()
+    off = lambda: ops._wgrad_bf16(o1, o2, 128, 128, 1, 262144, may_defer=False)
+else:
+    off = None
+with torch.no_grad():
+    ref = f().clone()
+    torch.cuda.synchronize()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    t0, n, nbad = time.time(), 0, 0
+    while time.time() - t0 < secs:
+        if off is not None:
+            with torch.cuda.stream(sb):
+                for _ in range(6):
+                    keep = off()
+        with torch.cuda.stream(sa):
+            flags = []
+            for _ in range(24):
+                flags.append((f() != ref).any())
+                n += 1
+            bad = int(torch.stack(flags).sum())
+        nbad += bad
+    torch.cuda.synchronize()
+print(f"[one process, two streams] victim {victim}, offender {offender}: {n} launches, {nbad} bad", flush=True)
