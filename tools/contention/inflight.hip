@@ -75,6 +75,31 @@ extern "C" int lds_hold_launch(void *out, int blocks, int rounds, int lds_bytes,
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
+// A barrier victim: in every round each thread publishes a round-dependent word in LDS, the workgroup meets at a barrier,
+// and each thread reads the word of a thread in ANOTHER wave; a second barrier closes the round.  A read that sees the
+// previous round's word means a barrier let a wave through early.  out[block] = number of such reads.
+__global__ __launch_bounds__(256) void barrier_ring(int *__restrict__ out, int rounds, int work) {
+    __shared__ unsigned slot[256];
+    const int tid = threadIdx.x;
+    int bad = 0;
+    float x = (float)tid;
+    for (int r = 0; r < rounds; ++r) {
+        for (int k = 0; k < work * (1 + (tid >> 6)); ++k) x = __builtin_fmaf(x, 0.999f, 0.5f);     // waves arrive at different times
+        slot[tid] = (unsigned)r * 256u + (unsigned)tid + (x == 12345.0f);
+        __syncthreads();
+        const int peer = (tid + 64) & 255;
+        bad += slot[peer] != (unsigned)r * 256u + (unsigned)peer;
+        __syncthreads();
+    }
+    for (int o = 32; o > 0; o >>= 1) bad += __shfl_xor(bad, o);
+    if ((tid & 63) == 0 && bad) atomicAdd(out + blockIdx.x, bad);
+}
+
+extern "C" int barrier_ring_launch(void *out, int blocks, int rounds, int work, void *stream) {
+    hipLaunchKernelGGL(barrier_ring, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (int *)out, rounds, work);
+    return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
 extern "C" int alu_chain_launch(const void *in, void *out, int blocks, int iters, int packed, void *stream) {
     if (packed) hipLaunchKernelGGL(alu_chain<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float *)in, (float *)out, iters);
     else hipLaunchKernelGGL(alu_chain<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float *)in, (float *)out, iters);

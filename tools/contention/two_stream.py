@@ -2,7 +2,7 @@
 stream B keeps the device busy with torch matrix products (no code of this repository).
 
     python tools/contention/two_stream.py VICTIM OFFENDER SECONDS
-VICTIM: bn | bn2 | logmel | peak | mm | t_layernorm | t_softmax | t_batchnorm | t_cumsum | t_gelu | t_conv (torch only) | copy4 | copy16 | copy32 | alu_pk | alu_scalar | lds8 | lds64 (inflight.hip); OFFENDER: mmbf16 | mmf32 | mmbf16small (torch products) | gemm | knn | mr | wgrad (kernels of this repository) | none"""
+VICTIM: bn | bn2 | logmel | peak | mm | t_layernorm | t_softmax | t_batchnorm | t_cumsum | t_gelu | t_conv (torch only) | copy4 | copy16 | copy32 | alu_pk | alu_scalar | lds8 | lds64 | barrier (inflight.hip); OFFENDER: mmbf16 | mmf32 | mmbf16small | mmf32small | mmbf16mid | ewadd (torch) | gemm | knn | mr | wgrad (kernels of this repository) | none"""
 import os
 import sys
 import time
@@ -16,16 +16,19 @@ victim, offender, secs = sys.argv[1], sys.argv[2], float(sys.argv[3])
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
 g = torch.Generator(device="cpu").manual_seed(5)
-if victim in ("bn", "bn2"):
+if victim in ("bn", "bn2", "bn_spin0"):
     ops.switches.bn_two_pass = victim == "bn2"
+    if victim == "bn_spin0":
+        ops.switches.bn_spin_limit = 0          # never wait for row-mates: every workgroup recomputes what is missing
     C, M = 160, 256 * 512
     x = torch.randn(C, M, generator=g).to(dev)
     ga, be = torch.ones(C, device=dev), torch.zeros(C, device=dev)
     rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
     f = lambda: ops.bn_act(x, ga, be, rm.clone(), rv.clone(), True, act=1, groups=2)
-elif victim == "logmel":
+elif victim in ("logmel", "logmel2048", "logmel512"):
+    nf = int(victim[6:] or 1024)                 # 1024: the register-FFT kernel; 512 / 2048: the generic radix-2 kernel
     wav = (torch.rand(256, 16000, generator=g) * 2 - 1).to(dev)
-    f = lambda: ops.logmel(wav, 16000, 1024, 1024, 512, 64)
+    f = lambda: ops.logmel(wav, 16000, nf, nf, 512, 64)
 elif victim == "peak":
     spec = torch.randn(256, 64, 32, generator=g).to(dev)
     w = (torch.randn(8, 3, 7, 7, generator=g) * 0.1).to(dev)
@@ -72,6 +75,16 @@ elif victim.startswith("lds"):                 # inflight.hip: a pattern held in
         rc = cl.lds_hold_launch(out.data_ptr(), 1024, 40, kb * 1024, torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
         assert rc == 0, rc
         return out
+elif victim == "barrier":                      # inflight.hip: 200 rounds of publish / barrier / read a word of another wave
+    import ctypes
+    cl = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libinflight.so"))
+    cl.barrier_ring_launch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+
+    def f():
+        out = torch.zeros(2048, dtype=torch.int32, device=dev)
+        rc = cl.barrier_ring_launch(out.data_ptr(), 2048, 200, 8, torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
+        assert rc == 0, rc
+        return out
 elif victim == "t_layernorm":
     a1 = torch.randn(8192, 2048, generator=g).to(dev)
     f = lambda: torch.nn.functional.layer_norm(a1, (2048,))
@@ -102,6 +115,15 @@ elif offender == "mmf32":
 elif offender == "mmbf16small":
     o1, o2 = torch.randn(128, 128, device=dev).bfloat16(), torch.randn(128, 262144, device=dev).bfloat16()
     off = lambda: o1 @ o2
+elif offender == "mmf32small":
+    o1, o2 = torch.randn(128, 128, device=dev), torch.randn(128, 262144, device=dev)
+    off = lambda: o1 @ o2
+elif offender == "mmbf16mid":
+    o1, o2 = torch.randn(128, 128, device=dev).bfloat16(), torch.randn(128, 32768, device=dev).bfloat16()
+    off = lambda: o1 @ o2
+elif offender == "ewadd":                     # a streaming elementwise kernel over the same 64 MB, no matrix cores
+    o1, o2 = torch.randn(128, 262144, device=dev).bfloat16(), torch.randn(128, 262144, device=dev).bfloat16()
+    off = lambda: o1 + o2
 elif offender == "gemm":                      # this repository's streaming GEMM on the same product as mmbf16small
     o1, o2 = torch.randn(128, 128, device=dev).bfloat16(), torch.randn(128, 262144, device=dev).bfloat16()
     off = lambda: ops.conv1x1_gemm(o1, o2)
@@ -129,10 +151,18 @@ with torch.no_grad():
                     keep = off()
         with torch.cuda.stream(sa):
             flags = []
+            outs = []
             for _ in range(24):
-                flags.append((f() != ref).any())
+                outs.append(f())
+                flags.append((outs[-1] != ref).any())
                 n += 1
             bad = int(torch.stack(flags).sum())
+            if bad and nbad < 3 and ref.dim() >= 2:
+                o = next(t for t, fl in zip(outs, flags) if bool(fl))
+                d = (o != ref).reshape(ref.shape[0], -1)
+                rows = d.any(1).nonzero().flatten().tolist()
+                desc = [(r, int(d[r].sum()), int(d[r].nonzero().min()), int(d[r].nonzero().max())) for r in rows[:5]]
+                print(f"   wrong launch: {int(d.sum())} elements in {len(rows)} of {ref.shape[0]} rows; (row, count, first, last) {desc}", flush=True)
         nbad += bad
     torch.cuda.synchronize()
 print(f"[one process, two streams] victim {victim}, offender {offender}: {n} launches, {nbad} bad", flush=True)
