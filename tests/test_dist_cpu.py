@@ -384,3 +384,18 @@ def test_grad_buckets_follow_the_observed_arrival_order():
         covered[off // 4: off // 4 + p.numel()] += 1
         assert torch.equal(sync._view[id(p)], want[id(p)])
     assert bool((covered == 1).all())
+
+
+def test_shared_device_cu_masks_are_disjoint_and_cover_the_device():
+    """grafp_amd.dist.shared_device_cu_mask: the CU slices of ranks that share one device (test layouts only; DESIGN.md
+    section 12.7b) are disjoint, equally wide and together cover the 256 CUs."""
+    from grafp_amd.dist import shared_device_cu_mask
+    for world in (2, 3, 4, 8):
+        masks = [int(shared_device_cu_mask(r, world), 16) for r in range(world)]
+        width = 256 // world
+        for i, m in enumerate(masks):
+            assert bin(m).count("1") == width and m >> 256 == 0
+            for n in masks[i + 1:]:
+                assert m & n == 0
+        if 256 % world == 0:
+            assert sum(masks) == (1 << 256) - 1
