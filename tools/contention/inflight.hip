@@ -100,6 +100,37 @@ extern "C" int barrier_ring_launch(void *out, int blocks, int rounds, int work, 
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
+// The arithmetic victim again, with the multiplier where the log-mel and BatchNorm kernels have theirs: SCALAR -- a uniform
+// value in an SGPR, read by the vector instruction through the constant bus (v_fma_f32 v, s, v, v) -- or, as the control,
+// the same value in a VGPR.  out[thread] is a deterministic function of (thread, iters, k).
+template <bool SCALAR>
+__global__ __launch_bounds__(256) void sgpr_chain(const float *__restrict__ in, float *__restrict__ out, int iters, float k0,
+                                                  float k1) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    float a[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = in[(t * 8 + i) & 65535];
+    float vk0 = k0, vk1 = k1;
+    asm volatile("" : "+v"(vk0), "+v"(vk1));                  // the control's copies live in VGPRs
+    for (int r = 0; r < iters; ++r) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (SCALAR) asm volatile("v_fma_f32 %0, %1, %0, %2\n\tv_fma_f32 %0, %3, %0, %2" : "+v"(a[i]) : "s"(k0), "v"(a[(i + 1) & 7] * 1e-3f), "s"(k1));
+            else asm volatile("v_fma_f32 %0, %1, %0, %2\n\tv_fma_f32 %0, %3, %0, %2" : "+v"(a[i]) : "v"(vk0), "v"(a[(i + 1) & 7] * 1e-3f), "v"(vk1));
+        }
+    }
+    float s = a[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) s += a[i];
+    out[t] = s;
+}
+
+extern "C" int sgpr_chain_launch(const void *in, void *out, int blocks, int iters, int scalar, void *stream) {
+    if (scalar) hipLaunchKernelGGL(sgpr_chain<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float *)in, (float *)out, iters, 0.999f, 1.001f);
+    else hipLaunchKernelGGL(sgpr_chain<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float *)in, (float *)out, iters, 0.999f, 1.001f);
+    return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
 extern "C" int alu_chain_launch(const void *in, void *out, int blocks, int iters, int packed, void *stream) {
     if (packed) hipLaunchKernelGGL(alu_chain<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float *)in, (float *)out, iters);
     else hipLaunchKernelGGL(alu_chain<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float *)in, (float *)out, iters);

@@ -2,7 +2,7 @@
 stream B keeps the device busy with torch matrix products (no code of this repository).
 
     python tools/contention/two_stream.py VICTIM OFFENDER SECONDS
-VICTIM: bn | bn2 | logmel | peak | mm | t_layernorm | t_softmax | t_batchnorm | t_cumsum | t_gelu | t_conv (torch only) | copy4 | copy16 | copy32 | alu_pk | alu_scalar | lds8 | lds64 | barrier (inflight.hip); OFFENDER: mmbf16 | mmf32 | mmbf16small | mmf32small | mmbf16mid | ewadd (torch) | gemm | knn | mr | wgrad (kernels of this repository) | none"""
+VICTIM: bn | bn2 | bn_spin0 | logmel | logmel512 | logmel2048 | logmel_dbg (logmel with a per-stage trace) | peak | mm | t_layernorm | t_softmax | t_batchnorm | t_cumsum | t_gelu | t_conv (torch only) | copy4 | copy16 | copy32 | alu_pk | alu_scalar | lds8 | lds64 | barrier | sgpr_chain | vgpr_chain (inflight.hip); OFFENDER: mmbf16 | mmf32 | mmbf16small | mmf32small | mmbf16mid | ewadd (torch) | gemm | knn | mr | wgrad (kernels of this repository) | none"""
 import os
 import sys
 import time
@@ -29,6 +29,30 @@ elif victim in ("logmel", "logmel2048", "logmel512"):
     nf = int(victim[6:] or 1024)                 # 1024: the register-FFT kernel; 512 / 2048: the generic radix-2 kernel
     wav = (torch.rand(256, 16000, generator=g) * 2 - 1).to(dev)
     f = lambda: ops.logmel(wav, 16000, nf, nf, 512, 64)
+elif victim == "logmel_dbg":                   # logmel_dbg.hip: the register-FFT kernel with a per-stage trace per frame pair
+    import ctypes
+    so = os.path.join(os.path.dirname(os.path.abspath(__file__)), "liblogmel_dbg.so")
+    if not os.path.exists(so):
+        raise SystemExit("build it first: (cd tools/contention && hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off "
+                         "-fhip-fp32-correctly-rounded-divide-sqrt -I../../include -Wno-inline-asm -fPIC -shared logmel_dbg.hip "
+                         "-o liblogmel_dbg.so)")
+    cl = ctypes.CDLL(so)
+    vp = ctypes.c_void_p
+    cl.logmel1024_dbg_launch.argtypes = [vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp,
+                                         vp, vp, vp, vp]
+    wav = (torch.rand(256, 16000, generator=g) * 2 - 1).to(dev)
+    plan = ops._mel_plan(dev, 16000, 1024, 1024, 64)
+    STAGES = ("windowed samples", "first FFT x twiddle", "transposed read", "second FFT", "power spectrum", "mel sums")
+
+    def f():
+        out = torch.empty((256, 64, 32), dtype=torch.float32, device=dev)
+        dbg = torch.empty((256, 16, 6), dtype=torch.int32, device=dev)
+        rc = cl.logmel1024_dbg_launch(wav.data_ptr(), wav.stride(0), 256, 16000, 512, 64, plan.window.data_ptr(),
+                                      plan.twiddle.data_ptr(), plan.fb.data_ptr(), plan.band_lo.data_ptr(),
+                                      plan.band_hi.data_ptr(), out.data_ptr(), dbg.data_ptr(),
+                                      torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
+        assert rc == 0, rc
+        return torch.cat((dbg.reshape(256, -1), out.reshape(256, -1).view(torch.int32)), dim=1)      # (256, 96 + 2048)
 elif victim == "peak":
     spec = torch.randn(256, 64, 32, generator=g).to(dev)
     w = (torch.randn(8, 3, 7, 7, generator=g) * 0.1).to(dev)
@@ -75,6 +99,18 @@ elif victim.startswith("lds"):                 # inflight.hip: a pattern held in
         rc = cl.lds_hold_launch(out.data_ptr(), 1024, 40, kb * 1024, torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
         assert rc == 0, rc
         return out
+elif victim in ("sgpr_chain", "vgpr_chain"):    # inflight.hip: v_fma_f32 chains whose multiplier is an SGPR / a VGPR
+    import ctypes
+    cl = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libinflight.so"))
+    cl.sgpr_chain_launch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    src = torch.rand(65536, generator=g).to(dev)
+
+    def f():
+        out = torch.empty(2048 * 256, device=dev)
+        rc = cl.sgpr_chain_launch(src.data_ptr(), out.data_ptr(), 2048, 300, int(victim == "sgpr_chain"),
+                                  torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
+        assert rc == 0, rc
+        return out.reshape(2048 * 4, 64)                      # one row per wave: the column is the lane
 elif victim == "barrier":                      # inflight.hip: 200 rounds of publish / barrier / read a word of another wave
     import ctypes
     cl = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libinflight.so"))
@@ -157,7 +193,23 @@ with torch.no_grad():
                 flags.append((outs[-1] != ref).any())
                 n += 1
             bad = int(torch.stack(flags).sum())
-            if bad and nbad < 3 and ref.dim() >= 2:
+            if bad and victim == "logmel_dbg" and nbad < 12:
+                for o, fl in zip(outs, flags):
+                    if not bool(fl):
+                        continue
+                    dd = (o[:, :96] != ref[:, :96]).reshape(256, 16, 6)
+                    pairs = dd.any(2).nonzero().tolist()
+                    firsts = [STAGES[int(dd[b_, p_].nonzero()[0])] for b_, p_ in pairs[:6]]
+                    outd = (o[:, 96:] != ref[:, 96:]).reshape(256, 64, 32)
+                    print(f"   wrong launch: {len(pairs)} frame pairs with a differing trace; (clip, pair) {pairs[:6]}; first differing stage "
+                          f"{firsts}; all differing stages of the first: {[STAGES[i] for i in dd[pairs[0][0], pairs[0][1]].nonzero().flatten().tolist()] if pairs else None}; "
+                          f"outputs differing {int(outd.sum())} in clips {sorted(set(outd.nonzero()[:, 0].tolist()))[:6]}", flush=True)
+            elif bad and victim in ("sgpr_chain", "vgpr_chain") and nbad < 6:
+                o = next(t for t, fl in zip(outs, flags) if bool(fl))
+                d = o != ref
+                lanes = d.any(0).nonzero().flatten().tolist()
+                print(f"   wrong launch: {int(d.sum())} values in {int(d.any(1).sum())} waves; lanes {lanes}", flush=True)
+            elif bad and nbad < 3 and ref.dim() >= 2:
                 o = next(t for t, fl in zip(outs, flags) if bool(fl))
                 d = (o != ref).reshape(ref.shape[0], -1)
                 rows = d.any(1).nonzero().flatten().tolist()
