@@ -131,6 +131,32 @@ extern "C" int sgpr_chain_launch(const void *in, void *out, int blocks, int iter
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
+// ... and with MANY live registers: NREG accumulators per thread (NREG + ~10 VGPRs), each updated in turn by plain hipcc
+// arithmetic (no inline asm) from its neighbour, so every one of them is read and written in every round.
+template <int NREG>
+__global__ __launch_bounds__(256) void wide_chain(const float *__restrict__ in, float *__restrict__ out, int iters, float k0) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    float a[NREG];
+#pragma unroll
+    for (int i = 0; i < NREG; ++i) a[i] = in[(t * 8 + i) & 65535];
+    for (int r = 0; r < iters; ++r) {
+#pragma unroll
+        for (int i = 0; i < NREG; ++i) a[i] = __builtin_fmaf(a[i], k0, a[(i + 1) % NREG] * 1e-3f);
+    }
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NREG; ++i) s += a[i];
+    out[t] = s;
+}
+
+extern "C" int wide_chain_launch(const void *in, void *out, int blocks, int iters, int nreg, void *stream) {
+    if (nreg == 64) hipLaunchKernelGGL(wide_chain<64>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float *)in, (float *)out, iters, 0.999f);
+    else if (nreg == 128) hipLaunchKernelGGL(wide_chain<128>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float *)in, (float *)out, iters, 0.999f);
+    else if (nreg == 224) hipLaunchKernelGGL(wide_chain<224>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float *)in, (float *)out, iters, 0.999f);
+    else return 2;
+    return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
 extern "C" int alu_chain_launch(const void *in, void *out, int blocks, int iters, int packed, void *stream) {
     if (packed) hipLaunchKernelGGL(alu_chain<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float *)in, (float *)out, iters);
     else hipLaunchKernelGGL(alu_chain<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float *)in, (float *)out, iters);

@@ -2,7 +2,7 @@
 stream B keeps the device busy with torch matrix products (no code of this repository).
 
     python tools/contention/two_stream.py VICTIM OFFENDER SECONDS
-VICTIM: bn | bn2 | bn_spin0 | logmel | logmel512 | logmel2048 | logmel_dbg (logmel with a per-stage trace) | peak | mm | t_layernorm | t_softmax | t_batchnorm | t_cumsum | t_gelu | t_conv (torch only) | copy4 | copy16 | copy32 | alu_pk | alu_scalar | lds8 | lds64 | barrier | sgpr_chain | vgpr_chain (inflight.hip); OFFENDER: mmbf16 | mmf32 | mmbf16small | mmf32small | mmbf16mid | ewadd (torch) | gemm | knn | mr | wgrad (kernels of this repository) | none"""
+VICTIM: bn | bn2 | bn_spin0 | logmel | logmel512 | logmel2048 | logmel_dbg (logmel with a per-stage trace) | peak | mm | t_layernorm | t_softmax | t_batchnorm | t_cumsum | t_gelu | t_conv (torch only) | copy4 | copy16 | copy32 | alu_pk | alu_scalar | lds8 | lds64 | barrier | sgpr_chain | vgpr_chain | wide64 | wide128 | wide224 (inflight.hip); OFFENDER: mmbf16 | mmf32 | mmbf16small | mmf32small | mmbf16mid | ewadd (torch) | gemm | knn | mr | wgrad (kernels of this repository) | none"""
 import os
 import sys
 import time
@@ -111,6 +111,19 @@ elif victim in ("sgpr_chain", "vgpr_chain"):    # inflight.hip: v_fma_f32 chains
                                   torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
         assert rc == 0, rc
         return out.reshape(2048 * 4, 64)                      # one row per wave: the column is the lane
+elif victim.startswith("wide"):                # inflight.hip: wideNN = NN accumulators per thread, all live, plain arithmetic
+    import ctypes
+    cl = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libinflight.so"))
+    cl.wide_chain_launch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    src = torch.rand(65536, generator=g).to(dev)
+    nreg = int(victim[4:])
+
+    def f():
+        out = torch.empty(2048 * 256, device=dev)
+        rc = cl.wide_chain_launch(src.data_ptr(), out.data_ptr(), 2048, 2400 // nreg, nreg,
+                                  torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
+        assert rc == 0, rc
+        return out.reshape(2048 * 4, 64)                      # one row per wave: the column is the lane
 elif victim == "barrier":                      # inflight.hip: 200 rounds of publish / barrier / read a word of another wave
     import ctypes
     cl = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libinflight.so"))
@@ -204,7 +217,7 @@ with torch.no_grad():
                     print(f"   wrong launch: {len(pairs)} frame pairs with a differing trace; (clip, pair) {pairs[:6]}; first differing stage "
                           f"{firsts}; all differing stages of the first: {[STAGES[i] for i in dd[pairs[0][0], pairs[0][1]].nonzero().flatten().tolist()] if pairs else None}; "
                           f"outputs differing {int(outd.sum())} in clips {sorted(set(outd.nonzero()[:, 0].tolist()))[:6]}", flush=True)
-            elif bad and victim in ("sgpr_chain", "vgpr_chain") and nbad < 6:
+            elif bad and (victim in ("sgpr_chain", "vgpr_chain") or victim.startswith("wide")) and nbad < 6:
                 o = next(t for t, fl in zip(outs, flags) if bool(fl))
                 d = o != ref
                 lanes = d.any(0).nonzero().flatten().tolist()
