@@ -228,6 +228,14 @@ with torch.no_grad():
                 rows = d.any(1).nonzero().flatten().tolist()
                 desc = [(r, int(d[r].sum()), int(d[r].nonzero().min()), int(d[r].nonzero().max())) for r in rows[:5]]
                 print(f"   wrong launch: {int(d.sum())} elements in {len(rows)} of {ref.shape[0]} rows; (row, count, first, last) {desc}", flush=True)
+                if victim.startswith("bn"):
+                    # f32 rows: element m of a row sits in lane ((m / 4) % 256) % 64 of its workgroup (bn_fwd1: 4 floats per
+                    # 16-byte vector, 256 threads); rows whose statistics moved differ on every lane, a workgroup whose OWN
+                    # arithmetic was hit differs on the lanes that were hit
+                    cols = d.nonzero()[:, 1]
+                    lanes = ((cols // 4) % 256) % 64
+                    hist = torch.bincount(lanes, minlength=64)
+                    print(f"      wrong elements by lane quarter [0-15, 16-31, 32-47, 48-63]: {[int(hist[q * 16:(q + 1) * 16].sum()) for q in range(4)]}", flush=True)
         nbad += bad
     torch.cuda.synchronize()
 print(f"[one process, two streams] victim {victim}, offender {offender}: {n} launches, {nbad} bad", flush=True)
