@@ -30,8 +30,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-if "--local-device" in sys.argv and int(os.environ.get("WORLD_SIZE", "1")) > 2 and "RANK" in os.environ:
-    # test hook only: three or more ranks share ONE device -> disjoint CU sets, set before the HIP runtime exists in this process
+if "--local-device" in sys.argv and int(os.environ.get("WORLD_SIZE", "1")) > 1 and "RANK" in os.environ:
+    # test hook only: the ranks share ONE device -> disjoint CU sets, set before the HIP runtime exists in this process
     # (grafp_amd.dist.shared_device_cu_mask says why; restated here because that module imports torch)
     _per = 256 // int(os.environ["WORLD_SIZE"])
     os.environ.setdefault("ROC_GLOBAL_CU_MASK", hex(((1 << _per) - 1) << (_per * int(os.environ["RANK"]))))

@@ -44,10 +44,10 @@ def init_from_env(backend=None, local_device=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if local_device is not None and world > 2:
-        # three or more ranks sharing a device (test layouts): disjoint CU sets, see shared_device_cu_mask (two ranks
-        # showed no differing iteration in 80); a launcher that set the variable itself wins.  Measured: the HIP runtime
-        # reads it at its first call, not when torch is imported, so this is early enough
+    if local_device is not None and world > 1:
+        # ranks sharing a device (test layouts): disjoint CU sets, see shared_device_cu_mask; a launcher that set the
+        # variable itself wins.  Measured: the HIP runtime reads it at its first call, not when torch is imported, so
+        # this is early enough
         os.environ.setdefault("ROC_GLOBAL_CU_MASK", shared_device_cu_mask(rank, world))
     if torch.cuda.is_available():
         if local_device is not None:

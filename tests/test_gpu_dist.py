@@ -16,11 +16,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def _shared_device_env(rank, world):
-    """Ranks that share ONE device: from three of them on, disjoint CU sets (grafp_amd.dist.shared_device_cu_mask says
-    why).  Two ranks stay unmasked -- 0 differing iterations of 80 in tools/contention/step_stress.py -- so that the
-    two-rank tests keep comparing against this process on the whole device."""
+    """Ranks that share ONE device run on disjoint CU sets (grafp_amd.dist.shared_device_cu_mask says why; two unmasked
+    processes repeating the 128-pair step: 7 differing iterations of 118, profiles/r06_contention_single.txt)."""
     from grafp_amd.dist import shared_device_cu_mask
-    return {"ROC_GLOBAL_CU_MASK": shared_device_cu_mask(rank, world)} if world > 2 else {}
+    return {"ROC_GLOBAL_CU_MASK": shared_device_cu_mask(rank, world)} if world > 1 else {}
 
 
 def _launch(world, out, B, extra=()):
@@ -38,9 +37,6 @@ def _launch(world, out, B, extra=()):
 
 def test_two_ranks_match_one_process(tmp_path):
     from grafp_amd import ops
-    from grafp_amd.simclr.ntxent import ntxent_loss
-    from grafp_amd.train import Trainer, build_model, synthetic_batch
-    from grafp_amd.util import load_config
     B = 8
     out = str(tmp_path / "w2")
     from _common import eval_case, golden, write_eval_case
@@ -58,35 +54,7 @@ def test_two_ranks_match_one_process(tmp_path):
         np.testing.assert_array_equal(got[r]["rates"], g["hit_rates"])
 
     device = torch.device("cuda:0")
-    cfg = load_config()
-    cfg["bsz_train"] = B
-    torch.manual_seed(1234)
-    model = build_model(cfg, device=device)
-    trainer = Trainer(cfg, model, device, amp_dtype=None)
-    x_i, x_j = synthetic_batch(B, 7, device)
-    model.train()
-    zs_i, zs_j = [], []
-    for lo in (0, B // 2):
-        with torch.no_grad():
-            X_i, X_j = trainer.augment(x_i[lo:lo + B // 2], x_j[lo:lo + B // 2])
-        _, _, z_i, z_j = model(X_i, X_j)
-        zs_i.append(z_i); zs_j.append(z_j)
-    loss = ntxent_loss(torch.cat(zs_i), torch.cat(zs_j), cfg)
-    loss.backward()
-    # embeddings of each shard: same kernels, same inputs -> equal up to the k-NN near-tie sensitivity (none expected
-    # between two runs of the same code on the same device)
-    for r in range(2):
-        assert torch.allclose(got[r]["z_i"], zs_i[r].detach().cpu(), rtol=0, atol=1e-6)
-    loss_v = float(loss.detach())
-    assert abs(got[0]["loss_share"] + got[1]["loss_share"] - loss_v) <= 1e-5 * max(1.0, abs(loss_v))
-    params = dict(model.named_parameters())
-    for name, g in got[0]["grads"].items():
-        want = params[name].grad.detach().float().cpu()
-        rel = (g - want).norm() / want.norm().clamp_min(1e-12)
-        assert rel < 2e-4, (name, float(rel))
-        assert torch.equal(g, got[1]["grads"][name])                   # every rank holds the same reduced gradient
-    want_norm = torch.sqrt(sum((p.grad.float() ** 2).sum() for p in model.parameters() if p.grad is not None)).item()
-    assert abs(got[0]["grad_norm"] - want_norm) <= 2e-4 * want_norm
+    _compare_with_one_process(out, B, 2, got)
 
     # sharded search == unsharded search, on both ranks
     gen = torch.Generator().manual_seed(3)
@@ -109,15 +77,11 @@ def test_two_ranks_match_one_process(tmp_path):
     assert (wid[:, 0].cpu().reshape(4, 3) == starts[:, None]).all()          # planted runs found, across the boundary
 
 
-def _ranks_against_one_process(tmp_path, world, B, tag):
-    """`world` ranks on cuda:0 over gloo, B // world pairs each, against ONE process pushing the shards through the model
-    one after the other (per-replica BatchNorm statistics, as under the reference's DataParallel, train.py:165-168) with
-    the loss over the concatenated batch (train.py:69-71)."""
-    out = str(tmp_path / tag)
-    _launch(world, out, B)
-    got = [torch.load(f"{out}.{r}.pt", weights_only=False) for r in range(world)]
-    device = torch.device("cuda:0")
-    # the one-process side runs in a process of its own under a CU mask of the ranks' width (_launch: from three ranks on)
+def _compare_with_one_process(out, B, world, got):
+    """The ranks' embeddings, loss shares, reduced gradients and gradient norm against ONE process that pushes the `world`
+    shards through the model one after the other (tests/_dist_gpu_worker.py reference_mode).  That side runs in a process
+    of its own under a CU mask of the ranks' width: the f32 mode's library GEMMs choose their splits by the number of
+    CUs they see."""
     env = dict(os.environ, **_shared_device_env(0, world))
     p = subprocess.run([sys.executable, os.path.join(HERE, "_dist_gpu_worker.py"), out, str(B), "reference", str(world)],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
@@ -141,6 +105,17 @@ def _ranks_against_one_process(tmp_path, world, B, tag):
     want_norm = ref["grad_norm"]
     for r in range(world):
         assert abs(got[r]["grad_norm"] - want_norm) <= 2e-4 * want_norm
+
+
+def _ranks_against_one_process(tmp_path, world, B, tag):
+    """`world` ranks on cuda:0 over gloo, B // world pairs each, against ONE process pushing the shards through the model
+    one after the other (per-replica BatchNorm statistics, as under the reference's DataParallel, train.py:165-168) with
+    the loss over the concatenated batch (train.py:69-71)."""
+    out = str(tmp_path / tag)
+    _launch(world, out, B)
+    got = [torch.load(f"{out}.{r}.pt", weights_only=False) for r in range(world)]
+    device = torch.device("cuda:0")
+    _compare_with_one_process(out, B, world, got)
     return got, device
 
 
