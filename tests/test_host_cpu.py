@@ -287,3 +287,25 @@ def test_reference_scripts_import_through_the_alias_route(tmp_path):
     res = subprocess.run([sys.executable, str(script), ROOT], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
                          timeout=600, cwd=str(tmp_path))
     assert res.returncode == 0 and "import through the alias route" in res.stdout, res.stdout[-3000:]
+
+
+def test_optimizer_refuses_what_the_path_does_not_use():
+    """grafp_amd.optim.Adam is torch.optim.Adam with step() on the multi-tensor kernel for what train.py:174 uses (the
+    defaults); the options outside the path raise at construction instead of silently running another update, and the
+    object keeps torch's state_dict schema (param_groups keys) so that a checkpoint of either class loads into the other."""
+    import torch
+    from grafp_amd.optim import Adam
+    w = torch.nn.Parameter(torch.zeros(4))
+    for bad in ({"weight_decay": 1e-2}, {"amsgrad": True}, {"maximize": True}):
+        with pytest.raises(NotImplementedError):
+            Adam([w], lr=1e-3, **bad)
+    opt = Adam([w], lr=3e-4)
+    ref = torch.optim.Adam([torch.nn.Parameter(torch.zeros(4))], lr=3e-4)
+    assert isinstance(opt, torch.optim.Adam)
+    keys = set(ref.state_dict()["param_groups"][0])
+    assert set(opt.state_dict()["param_groups"][0]) == keys
+    g, h = opt.param_groups[0], ref.param_groups[0]
+    assert (g["lr"], g["betas"], g["eps"], g["weight_decay"], g["amsgrad"]) == (h["lr"], h["betas"], h["eps"], 0, False)
+    w.grad = torch.ones(4)
+    with pytest.raises(RuntimeError):                   # a CPU parameter: there is no CPU fallback behind step()
+        opt.step()
