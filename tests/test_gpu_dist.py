@@ -19,7 +19,8 @@ def _shared_device_env(rank, world):
     """Ranks that share ONE device run on disjoint CU sets (grafp_amd.dist.shared_device_cu_mask says why; two unmasked
     processes repeating the 128-pair step: 7 differing iterations of 118, profiles/r06_contention_single.txt)."""
     from grafp_amd.dist import shared_device_cu_mask
-    return {"ROC_GLOBAL_CU_MASK": shared_device_cu_mask(rank, world)} if world > 1 else {}
+    cus = torch.cuda.get_device_properties(0).multi_processor_count        # 256 on an MI355X in its default partition mode
+    return {"ROC_GLOBAL_CU_MASK": shared_device_cu_mask(rank, world, cus)} if world > 1 else {}
 
 
 def _launch(world, out, B, extra=()):

@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 
 
-def cu_mask(rank, world, cus=256):
+def cu_mask(rank, world, cus=256):                 # (256 CUs: an MI355X in its default partition mode)
     per = cus // world
     return hex(((1 << per) - 1) << (per * rank))
 
