@@ -196,7 +196,7 @@ with torch.no_grad():
     while time.time() - t0 < secs:
         if off is not None:
             with torch.cuda.stream(sb):
-                for _ in range(6):
+                for _ in range(int(os.environ.get("OFFENDER_PER_ROUND", "6"))):    # per 24 victim launches
                     keep = off()
         with torch.cuda.stream(sa):
             flags = []
