@@ -25,11 +25,12 @@ import torch.distributed as dist
 
 def shared_device_cu_mask(rank, world, cus=256):
     """ROC_GLOBAL_CU_MASK of rank `rank` when `world` processes share ONE device: disjoint, equal slices of its CUs.
-    Only the test layouts do that (production is one process per GPU).  Why they need it: on MI355X / ROCm 7.2 the
-    kernels with the longest-lived waves (log-mel, single-pass BatchNorm, peak-extractor backward) return single wrong
-    64-byte pieces in a few per cent of their launches while a skinny bf16 GEMM of ANOTHER stream or process -- hipBLASLt's
-    or this repository's -- runs on the same CUs (tools/contention/); with disjoint CU sets the
-    step is bit-reproducible (0 of 240 iterations against 20-34 of 120).  NOTE the f32 mode's library GEMMs
+    Only the test layouts do that (production is one process per GPU).  Why they need it: on MI355X / ROCm 7.2 a
+    packed-f32 instruction whose low lane reads the high register of a pair (`v_pk_add_f32 ... op_sel:[0,1]`; hipcc emits it
+    in the log-mel, single-pass BatchNorm and peak-extractor kernels) returns wrong values on lanes 48-63 while bf16 MFMA
+    waves of ANOTHER kernel -- another process's or stream's GEMM -- run on the same SIMD (DESIGN.md section 12.7b,
+    tools/contention/two_stream.py); with disjoint CU sets the step is bit-reproducible (0 of 240 iterations against 20-34
+    of 120).  NOTE the f32 mode's library GEMMs
     pick their splits by the number of CUs they see: results under a mask differ in the low bits (1e-4 on an embedding)
     from those on the whole device -- compare like with like (tests/test_gpu_dist.py runs its one-process side under a
     mask of the same width)."""

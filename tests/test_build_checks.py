@@ -90,3 +90,21 @@ def test_checker_guards_the_accumulator_file_of_the_four_wave_gemm():
     assert len(tool.check_gemm_xl(_FAKE_XL.format(extra="\tscratch_store_dword off, v0, off", agpr=256))[1]) == 1
     assert len(tool.check_gemm_xl(_FAKE_XL.format(extra="", agpr=128))[1]) == 1
     assert tool.check_gemm_xl("nothing here")[1]
+
+
+def test_no_matrix_kernel_takes_a_packed_low_lane_from_a_high_register():
+    """The rule of tools/check_kernel_regs.py:check_mfma_packed_select over EVERY kernel source (the hazard measured in
+    DESIGN.md section 12.7b): it holds for the shipped sources, and the checker does flag the form."""
+    import subprocess
+    import sys
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_kernel_regs.py"), "--all"], stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT, text=True)
+    assert res.returncode == 0, res.stdout[-3000:]
+    assert "no packed-f32 high-register select in any of the" in res.stdout
+    tool = _tool()
+    k = "foo_kernel: ; @foo_kernel\n\tv_mfma_f32_32x32x16_bf16 a[0:15], v[0:3], v[4:7], a[0:15]\n{}\n\ts_endpgm\n\t.amdhsa_kernel foo_kernel\n"
+    assert tool.check_mfma_packed_select(k.format("\tv_pk_mul_f32 v[0:1], v[0:1], v[2:3] op_sel_hi:[1,0]")) == (1, [])
+    n, errs = tool.check_mfma_packed_select(k.format("\tv_pk_add_f32 v[0:1], v[0:1], v[2:3] op_sel:[0,1] op_sel_hi:[1,0]"))
+    assert n == 1 and len(errs) == 1
+    nomfma = k.replace("\tv_mfma_f32_32x32x16_bf16 a[0:15], v[0:3], v[4:7], a[0:15]\n", "")
+    assert tool.check_mfma_packed_select(nomfma.format("\tv_pk_add_f32 v[0:1], v[0:1], v[2:3] op_sel:[0,1]")) == (0, [])

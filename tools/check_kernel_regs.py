@@ -86,6 +86,47 @@ def check_gemm_splat(asm):
     return kernels, errors
 
 
+def check_mfma_packed_select(asm):
+    """EVERY kernel that issues matrix instructions: no packed-f32 instruction may take the LOW lane of a source from the
+    HIGH register of its pair (`v_pk_{add,mul,fma}_f32 ... op_sel:[..1..]`).  Measured on MI355X (DESIGN.md section 12.7b,
+    tools/contention/two_stream.py pk_add_hi / pk_add_swap): while bf16 MFMA waves are active on the SIMD -- the kernel's
+    own or, under two streams / processes, another kernel's -- that form returns a wrong value on lanes 48-63 in a third of
+    the launches; the forms that only broadcast the LOW register (`op_sel_hi:[1,0]`) and the unselected ones do not.
+    check_gemm_splat is the instance found in round 3; this is the rule for the whole library."""
+    errors, kernels = [], 0
+    for m in re.finditer(r"^(\w+):\s*; @\w+\s*$", asm, flags=re.M):
+        name = m.group(1)
+        end = asm.find(".amdhsa_kernel " + name, m.start())
+        if end < 0:
+            continue
+        body = asm[m.start():end]
+        if not re.search(r"^\s*v_mfma", body, flags=re.M):
+            continue
+        kernels += 1
+        for ln in body.split("\n"):
+            if re.match(r"\s*v_pk_\w+_f32", ln) and re.search(r"op_sel:\[[01,]*1[01,]*\]", ln):
+                errors.append(f"{name[:60]}...: {ln.strip()}")
+    return kernels, errors[:20]
+
+
+def compile_all(hipcc, flags, jobs=8):
+    """Device assembly of every csrc/*.hip (the product flags), in parallel: name -> text."""
+    import concurrent.futures
+    import glob
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        def one(src):
+            dst = os.path.join(tmp, os.path.basename(src) + ".s")
+            res = subprocess.run([hipcc] + flags + [src, "-o", dst], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            if res.returncode != 0:
+                raise RuntimeError(res.stdout[-2000:])
+            return os.path.basename(src), open(dst).read()
+        with concurrent.futures.ThreadPoolExecutor(jobs) as ex:
+            for name, text in ex.map(one, sorted(glob.glob(os.path.join(CSRC, "*.hip")))):
+                out[name] = text
+    return out
+
+
 def check_gemm_xl(asm):
     """conv1x1_gemm_xl_kernel (gemm_xl.h): its 256 accumulators are AGPRs a0-a255 NAMED in asm text; the compiler only
     knows sixteen placeholder values that occupy the file from the first instruction to the last.  Every build must show:
@@ -121,8 +162,20 @@ def main():
     ap.add_argument("--asm-wgrad", default=None, help="assembly of wgrad.hip (device only) instead of compiling it here")
     ap.add_argument("--asm-gemm", default=None, help="assembly of gemm.hip")
     ap.add_argument("--measure", action="store_true", help="compile with -DGRAFP_MEASURE (the measurement library)")
+    ap.add_argument("--all", action="store_true", help="only the packed-select rule, over EVERY csrc/*.hip (compiles them all)")
     args = ap.parse_args()
     flags = FLAGS + (["-DGRAFP_MEASURE"] if args.measure else [])
+    if args.all:
+        total, bad = 0, []
+        for name, text in compile_all(args.hipcc, flags).items():
+            k, errs = check_mfma_packed_select(text)
+            total += k
+            bad += [f"{name}: {e}" for e in errs]
+        for e in bad:
+            print("PACKED-F32 LOW LANE FROM A HIGH REGISTER IN A MATRIX KERNEL:", e)
+        if not bad:
+            print(f"no packed-f32 high-register select in any of the {total} kernels that issue matrix instructions")
+        return 1 if bad else 0
     with tempfile.TemporaryDirectory() as tmp:
         out = args.asm_wgrad or os.path.join(tmp, "wgrad.s")
         if not args.asm_wgrad:
@@ -152,7 +205,14 @@ def main():
         print("ACCUMULATOR FILE TOUCHED BY THE COMPILER:", e)
     if not xerrors:
         print(f"conv1x1_gemm_xl_kernel: accumulator registers untouched by the compiler ({xk} instantiations)")
-    for e in gerrors:
+    pk, perrors = check_mfma_packed_select(gemm_asm)
+    pk2, perrors2 = check_mfma_packed_select(asm)
+    for e in perrors + perrors2:
+        print("PACKED-F32 LOW LANE FROM A HIGH REGISTER IN A MATRIX KERNEL:", e)
+    if not (perrors or perrors2):
+        print(f"gemm.hip + wgrad.hip: no packed-f32 high-register select in {pk + pk2} kernels that issue matrix instructions")
+    gerrors = gerrors + perrors + perrors2
+    for e in gerrors[:len(gerrors) - len(perrors) - len(perrors2)]:
         print("HIGH-REGISTER SPLAT IN A PACKED SUBTRACTION:", e)
     if not gerrors:
         print(f"conv1x1_gemm_kernel: no high-register splat in a packed subtraction ({gk} instantiations)")

@@ -69,6 +69,52 @@ __global__ __launch_bounds__(256) void lds_hold(int *__restrict__ out, int round
     if ((tid & 63) == 0 && bad) atomicAdd(out + blockIdx.x, bad);
 }
 
+// LDS victims with BANK CONFLICTS, the way the log-mel kernel has them (lane l and lane l + 32 of a wave address the same
+// bank at different rows -- its two half-waves own buffers 8 448 bytes apart) and the way a transposition has them:
+//   mode 0: word (tid & 31) + (tid >> 5) * 2112            2-way conflict between the halves of every wave
+//   mode 1: word tid * 64 (mod the buffer)                  every lane on one bank
+//   mode 2: no LDS; __shfl_xor butterflies (ds_bpermute / DPP) over values that are a function of the lane
+// Every round rewrites and re-reads; out[block] counts words that came back different from what the thread wrote.
+__global__ __launch_bounds__(256) void lds_conflict(int *__restrict__ out, int rounds, int mode) {
+    __shared__ unsigned buf[8 * 2112];
+    const int tid = threadIdx.x;
+    int bad = 0;
+    if (mode == 2) {
+        for (int r = 0; r < rounds * 8; ++r) {
+            unsigned v = (unsigned)(tid & 63) * 2654435761u + (unsigned)r, want = 0;
+            for (int l = 0; l < 64; ++l) want ^= (unsigned)l * 2654435761u + (unsigned)r;
+            for (int o = 32; o > 0; o >>= 1) v ^= (unsigned)__shfl_xor((int)v, o);
+            bad += v != want;
+        }
+    } else {
+        const int idx = mode == 0 ? (tid & 31) + (tid >> 5) * 2112 : (tid * 64) % (8 * 2112);
+        for (int r = 0; r < rounds; ++r) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int at = mode == 0 ? idx + 33 * k : (idx + k) % (8 * 2112);
+                buf[at] = (unsigned)(r * 16 + k) * 2654435761u + (unsigned)tid;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int at = mode == 0 ? idx + 33 * k : (idx + k) % (8 * 2112);
+                bad += buf[at] != (unsigned)(r * 16 + k) * 2654435761u + (unsigned)tid;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) bad += __shfl_xor(bad, o);
+    if ((tid & 63) == 0 && bad) atomicAdd(out + blockIdx.x, bad);
+}
+
+extern "C" int lds_conflict_launch(void *out, int blocks, int rounds, int mode, void *stream) {
+    hipLaunchKernelGGL(lds_conflict, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (int *)out, rounds, mode);
+    return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
 extern "C" int lds_hold_launch(void *out, int blocks, int rounds, int lds_bytes, void *stream) {
     (void)hipFuncSetAttribute((const void *)lds_hold, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     hipLaunchKernelGGL(lds_hold, dim3(blocks), dim3(256), lds_bytes, (hipStream_t)stream, (int *)out, rounds, lds_bytes / 4);
@@ -154,6 +200,57 @@ extern "C" int wide_chain_launch(const void *in, void *out, int blocks, int iter
     else if (nreg == 128) hipLaunchKernelGGL(wide_chain<128>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float *)in, (float *)out, iters, 0.999f);
     else if (nreg == 224) hipLaunchKernelGGL(wide_chain<224>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float *)in, (float *)out, iters, 0.999f);
     else return 2;
+    return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+// The packed-f32 forms hipcc emits for complex arithmetic: the second source taken with a lane SELECT (op_sel / op_sel_hi:
+// "the low result lane reads the pair's high register" and vice versa).  SEL: chains of
+//   v_pk_mul_f32 d, d, k op_sel_hi:[1,0]      and      v_pk_add_f32 d, d, c op_sel:[0,1] op_sel_hi:[1,0]
+// otherwise the same chains without the selects (MODE below).  out[thread] is a deterministic function of (thread, iters).
+template <int MODE>
+__global__ __launch_bounds__(256) void pk_sel_chain(const float *__restrict__ in, float *__restrict__ out, int iters) {
+    // MODE 0: no selects; 1: both forms below; 2: only  v_pk_mul_f32 d, d, k op_sel_hi:[1,0]  (broadcast of the LOW register);
+    // 3: only  v_pk_add_f32 d, d, c op_sel:[0,1] op_sel_hi:[1,0]  (the pair swapped); 4: only  v_pk_add_f32 d, d, c op_sel:[0,1]
+    // (broadcast of the HIGH register); 5: v_pk_fma_f32 d, d, k, c op_sel_hi:[1,0,1]  (the form in this repository's scan kernel)
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    f2 a[8], k = f2{0.9995f, 1.0005f}, c[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        a[i] = f2{in[(t * 16 + 2 * i) & 65535], in[(t * 16 + 2 * i + 1) & 65535]};
+        c[i] = f2{1e-3f * (float)(i + 1), -1e-3f * (float)(i + 2)};
+    }
+    for (int r = 0; r < iters; ++r) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (MODE == 5) {
+                asm volatile("v_pk_fma_f32 %0, %0, %1, %2 op_sel_hi:[1,0,1]" : "+v"(a[i]) : "v"(k), "v"(c[i]));
+                continue;
+            }
+            if (MODE == 1 || MODE == 2) asm volatile("v_pk_mul_f32 %0, %0, %1 op_sel_hi:[1,0]" : "+v"(a[i]) : "v"(k));
+            else asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(k));
+            if (MODE == 1 || MODE == 3) asm volatile("v_pk_add_f32 %0, %0, %1 op_sel:[0,1] op_sel_hi:[1,0]" : "+v"(a[i]) : "v"(c[i]));
+            else if (MODE == 4) asm volatile("v_pk_add_f32 %0, %0, %1 op_sel:[0,1]" : "+v"(a[i]) : "v"(c[i]));
+            else asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c[i]));
+        }
+    }
+    f2 s2 = a[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) s2 += a[i];
+    out[t] = s2.x + 3.0f * s2.y;
+}
+
+extern "C" int pk_sel_chain_launch(const void *in, void *out, int blocks, int iters, int mode, void *stream) {
+#define PKL(M) hipLaunchKernelGGL(pk_sel_chain<M>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float *)in, (float *)out, iters)
+    switch (mode) {
+        case 0: PKL(0); break;
+        case 1: PKL(1); break;
+        case 2: PKL(2); break;
+        case 3: PKL(3); break;
+        case 4: PKL(4); break;
+        case 5: PKL(5); break;
+        default: return 2;
+    }
+#undef PKL
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 

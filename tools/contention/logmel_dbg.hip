@@ -22,16 +22,21 @@ __global__ __launch_bounds__(256, 2) void logmel1024_dbg_kernel(const float *__r
                                                                 const float2 *__restrict__ twiddle,
                                                                 const float *__restrict__ fb, const int *__restrict__ band_lo,
                                                                 const int *__restrict__ band_hi, float *__restrict__ out,
-                                                                unsigned *__restrict__ dbg) {
+                                                                unsigned *__restrict__ dbg, int variant) {
+    // variant 0: the whole kernel; 1: stop after the first FFT (its values written to LDS); 2: no filter staging, no
+    // workgroup barrier, no LDS at all -- loads, window, 32-point FFT and twiddle recurrence in registers, trace, return;
+    // 3: as 2 with the samples made up from indices instead of loaded; 4: as 3 with the window made up as well
     constexpr int N = 1024;
     __shared__ float2 lds[LM1K_PAIRS][32 * LM1K_ROW];
     __shared__ float wband[64][LM1K_BW];
     const int tid = threadIdx.x, l = tid & 31, g = tid >> 5, b = blockIdx.y;
-    for (int i = tid; i < n_mels * LM1K_BW; i += 256) {
-        const int m = i / LM1K_BW, j = i - m * LM1K_BW, k = band_lo[m] + j;
-        wband[m][j] = k <= band_hi[m] ? fb[(size_t)k * n_mels + m] : 0.0f;
+    if (variant < 2) {
+        for (int i = tid; i < n_mels * LM1K_BW; i += 256) {
+            const int m = i / LM1K_BW, j = i - m * LM1K_BW, k = band_lo[m] + j;
+            wband[m][j] = k <= band_hi[m] ? fb[(size_t)k * n_mels + m] : 0.0f;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     const float *x = wav + (size_t)b * wav_stride;
     float2 *const my = lds[g];
     const float2 st = twiddle[l];
@@ -48,11 +53,13 @@ __global__ __launch_bounds__(256, 2) void logmel1024_dbg_kernel(const float *__r
         p1 = p1 < 0 ? -p1 : (p1 >= T ? 2 * (T - 1) - p1 : p1);
         p1 = p1 < 0 ? 0 : p1;
         a[n1] = make_float2(x[(unsigned)p0], x[(unsigned)p1]);
+        if (variant >= 3)                                      // 3, 4: no sample loads -- values made up from the indices
+            a[n1] = make_float2(__sinf(0.37f * (float)(p0 & 1023)) * 0.5f, __cosf(0.11f * (float)(p1 & 1023)) * 0.5f);
     }
     unsigned h = 0;
 #pragma unroll
     for (int n1 = 0; n1 < 32; ++n1) {
-        const float w = window[32 * n1 + l];
+        const float w = variant >= 4 ? 0.5f + 0.25f * (float)((32 * n1 + l) & 15) : window[32 * n1 + l];     // 4: no window loads
         a[n1] = make_float2(a[n1].x * w, has1 ? a[n1].y * w : 0.0f);
         h ^= bits2(a[n1]) * (2u * n1 + 1u);
     }
@@ -66,13 +73,14 @@ __global__ __launch_bounds__(256, 2) void logmel1024_dbg_kernel(const float *__r
         for (int k1 = 0; k1 < 32; ++k1) {
             const float2 v = a[lm_rev5(k1)];
             const float2 r = make_float2(v.x * w.x - v.y * w.y, v.x * w.y + v.y * w.x);
-            my[k1 * LM1K_ROW + l] = r;
+            if (variant < 2) my[k1 * LM1K_ROW + l] = r;
             h ^= bits2(r) * (2u * k1 + 1u);
             w = make_float2(w.x * st.x - w.y * st.y, w.x * st.y + w.y * st.x);
         }
     }
     h = hw_xor(h);
     if (l == 0) d[1] = h;
+    if (variant) return;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -146,11 +154,11 @@ __global__ __launch_bounds__(256, 2) void logmel1024_dbg_kernel(const float *__r
 
 extern "C" int logmel1024_dbg_launch(const float *wav, int64_t wav_stride, int B, int T, int hop, int n_mels, const float *window,
                                      const float *twiddle, const float *fb, const int32_t *band_lo, const int32_t *band_hi,
-                                     float *out, unsigned *dbg, void *stream) {
+                                     float *out, unsigned *dbg, int variant, void *stream) {
     using namespace grafp;
     const int n_frames = 1 + T / hop;
     const dim3 g1k((n_frames + 2 * LM1K_PAIRS - 1) / (2 * LM1K_PAIRS), B);
     hipLaunchKernelGGL(logmel1024_dbg_kernel, g1k, dim3(256), 0, (hipStream_t)stream, wav, wav_stride, T, hop, n_mels, n_frames,
-                       window, reinterpret_cast<const float2 *>(twiddle), fb, band_lo, band_hi, out, dbg);
+                       window, reinterpret_cast<const float2 *>(twiddle), fb, band_lo, band_hi, out, dbg, variant);
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }

@@ -2,7 +2,7 @@
 stream B keeps the device busy with torch matrix products (no code of this repository).
 
     python tools/contention/two_stream.py VICTIM OFFENDER SECONDS
-VICTIM: bn | bn2 | bn_spin0 | logmel | logmel512 | logmel2048 | logmel_dbg (logmel with a per-stage trace) | peak | mm | t_layernorm | t_softmax | t_batchnorm | t_cumsum | t_gelu | t_conv (torch only) | copy4 | copy16 | copy32 | alu_pk | alu_scalar | lds8 | lds64 | barrier | sgpr_chain | vgpr_chain | wide64 | wide128 | wide224 (inflight.hip); OFFENDER: mmbf16 | mmf32 | mmbf16small | mmf32small | mmbf16mid | ewadd (torch) | gemm | knn | mr | wgrad (kernels of this repository) | none"""
+VICTIM: bn | bn2 | bn_spin0 | logmel | logmel512 | logmel2048 | logmel_dbg (logmel with a per-stage trace) | peak | mm | t_layernorm | t_softmax | t_batchnorm | t_cumsum | t_gelu | t_conv (torch only) | copy4 | copy16 | copy32 | alu_pk | alu_scalar | lds8 | lds64 | conf_2way | conf_1bank | shfl | barrier | sgpr_chain | vgpr_chain | pk_plain | pk_sel | pk_mul_lo | pk_add_swap | pk_add_hi | pk_fma_lo | wide64 | wide128 | wide224 (inflight.hip); OFFENDER: mmbf16 | mmf32 | mmbf16small | mmf32small | mmbf16mid | ewadd (torch) | gemm | knn | mr | wgrad (kernels of this repository) | none"""
 import os
 import sys
 import time
@@ -29,7 +29,7 @@ elif victim in ("logmel", "logmel2048", "logmel512"):
     nf = int(victim[6:] or 1024)                 # 1024: the register-FFT kernel; 512 / 2048: the generic radix-2 kernel
     wav = (torch.rand(256, 16000, generator=g) * 2 - 1).to(dev)
     f = lambda: ops.logmel(wav, 16000, nf, nf, 512, 64)
-elif victim == "logmel_dbg":                   # logmel_dbg.hip: the register-FFT kernel with a per-stage trace per frame pair
+elif victim in ("logmel_dbg", "logmel_dbg1", "logmel_dbg2", "logmel_dbg3", "logmel_dbg4"):                   # logmel_dbg.hip: the register-FFT kernel with a per-stage trace per frame pair
     import ctypes
     so = os.path.join(os.path.dirname(os.path.abspath(__file__)), "liblogmel_dbg.so")
     if not os.path.exists(so):
@@ -39,17 +39,18 @@ elif victim == "logmel_dbg":                   # logmel_dbg.hip: the register-FF
     cl = ctypes.CDLL(so)
     vp = ctypes.c_void_p
     cl.logmel1024_dbg_launch.argtypes = [vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp,
-                                         vp, vp, vp, vp]
+                                         vp, vp, vp, ctypes.c_int, vp]
+    variant = int(victim[10:] or 0)               # 1: stop after the first FFT; 2: the same with no LDS and no barrier at all
     wav = (torch.rand(256, 16000, generator=g) * 2 - 1).to(dev)
     plan = ops._mel_plan(dev, 16000, 1024, 1024, 64)
     STAGES = ("windowed samples", "first FFT x twiddle", "transposed read", "second FFT", "power spectrum", "mel sums")
 
     def f():
-        out = torch.empty((256, 64, 32), dtype=torch.float32, device=dev)
-        dbg = torch.empty((256, 16, 6), dtype=torch.int32, device=dev)
+        out = torch.zeros((256, 64, 32), dtype=torch.float32, device=dev)
+        dbg = torch.zeros((256, 16, 6), dtype=torch.int32, device=dev)
         rc = cl.logmel1024_dbg_launch(wav.data_ptr(), wav.stride(0), 256, 16000, 512, 64, plan.window.data_ptr(),
                                       plan.twiddle.data_ptr(), plan.fb.data_ptr(), plan.band_lo.data_ptr(),
-                                      plan.band_hi.data_ptr(), out.data_ptr(), dbg.data_ptr(),
+                                      plan.band_hi.data_ptr(), out.data_ptr(), dbg.data_ptr(), variant,
                                       torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
         assert rc == 0, rc
         return torch.cat((dbg.reshape(256, -1), out.reshape(256, -1).view(torch.int32)), dim=1)      # (256, 96 + 2048)
@@ -122,6 +123,30 @@ elif victim.startswith("wide"):                # inflight.hip: wideNN = NN accum
         out = torch.empty(2048 * 256, device=dev)
         rc = cl.wide_chain_launch(src.data_ptr(), out.data_ptr(), 2048, 2400 // nreg, nreg,
                                   torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
+        assert rc == 0, rc
+        return out.reshape(2048 * 4, 64)                      # one row per wave: the column is the lane
+elif victim in ("conf_2way", "conf_1bank", "shfl"):  # inflight.hip: LDS round trips with bank conflicts / shuffle butterflies
+    import ctypes
+    cl = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libinflight.so"))
+    cl.lds_conflict_launch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    mode = ("conf_2way", "conf_1bank", "shfl").index(victim)
+
+    def f():
+        out = torch.zeros(2048, dtype=torch.int32, device=dev)
+        rc = cl.lds_conflict_launch(out.data_ptr(), 2048, 60, mode, torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
+        assert rc == 0, rc
+        return out
+elif victim in ("pk_plain", "pk_sel", "pk_mul_lo", "pk_add_swap", "pk_add_hi", "pk_fma_lo"):         # inflight.hip: packed-f32 chains with / without lane selects on the second source
+    import ctypes
+    cl = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libinflight.so"))
+    cl.pk_sel_chain_launch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    src = torch.rand(65536, generator=g).to(dev)
+
+    def f():
+        out = torch.empty(2048 * 256, device=dev)
+        rc = cl.pk_sel_chain_launch(src.data_ptr(), out.data_ptr(), 2048, 300,
+                                    ("pk_plain", "pk_sel", "pk_mul_lo", "pk_add_swap", "pk_add_hi", "pk_fma_lo").index(victim),
+                                    torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
         assert rc == 0, rc
         return out.reshape(2048 * 4, 64)                      # one row per wave: the column is the lane
 elif victim == "barrier":                      # inflight.hip: 200 rounds of publish / barrier / read a word of another wave
@@ -206,7 +231,7 @@ with torch.no_grad():
                 flags.append((outs[-1] != ref).any())
                 n += 1
             bad = int(torch.stack(flags).sum())
-            if bad and victim == "logmel_dbg" and nbad < 12:
+            if bad and victim.startswith("logmel_dbg") and nbad < 6:
                 for o, fl in zip(outs, flags):
                     if not bool(fl):
                         continue
@@ -214,10 +239,12 @@ with torch.no_grad():
                     pairs = dd.any(2).nonzero().tolist()
                     firsts = [STAGES[int(dd[b_, p_].nonzero()[0])] for b_, p_ in pairs[:6]]
                     outd = (o[:, 96:] != ref[:, 96:]).reshape(256, 64, 32)
+                    if not pairs:
+                        continue
                     print(f"   wrong launch: {len(pairs)} frame pairs with a differing trace; (clip, pair) {pairs[:6]}; first differing stage "
                           f"{firsts}; all differing stages of the first: {[STAGES[i] for i in dd[pairs[0][0], pairs[0][1]].nonzero().flatten().tolist()] if pairs else None}; "
                           f"outputs differing {int(outd.sum())} in clips {sorted(set(outd.nonzero()[:, 0].tolist()))[:6]}", flush=True)
-            elif bad and (victim in ("sgpr_chain", "vgpr_chain") or victim.startswith("wide")) and nbad < 6:
+            elif bad and (victim in ("sgpr_chain", "vgpr_chain") or victim.startswith("wide") or victim.startswith("pk_")) and nbad < 6:
                 o = next(t for t, fl in zip(outs, flags) if bool(fl))
                 d = o != ref
                 lanes = d.any(0).nonzero().flatten().tolist()
