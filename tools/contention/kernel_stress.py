@@ -12,7 +12,8 @@ Findings on MI355X / ROCm 7.2: without a prelude every
 launches.  With a bf16 prelude logmel, peak and bn show wrong 64-byte pieces in their FIRST ~1 000 launches -- while the
 other processes are still running their prelude, i.e. next to those processes' bf16 GEMMs (the deeper the prelude runs,
 the longer that window) -- logmel512 / logmel2048 / bn2 / mm never; an f32 prelude: never; disjoint CU sets: never.
-two_stream.py shows the same in ONE process (the GEMM on a second stream)."""
+two_stream.py shows the same in ONE process (the GEMM on a second stream) and isolates the cause: a packed-f32
+operand form (low lane from the high register of a pair) that reads wrong on lanes 48-63 next to bf16 MFMA waves."""
 import os
 import subprocess
 import sys

@@ -9,7 +9,8 @@ Prints per rank the number of iterations that differ from iteration 0 and, for t
 Findings on MI355X / ROCm 7.2: from 4 processes that share CUs some iterations differ -- single
 64-byte pieces / single registers of one wave are wrong in the kernels with the longest-lived waves (log-mel, single-pass
 BatchNorm, peak-extractor backward) while another process's bf16 GEMM runs on the same CUs (two_stream.py: the same in
-one process); with disjoint CU sets: 0 of 240."""
+one process, and the cause -- a packed-f32 operand form that reads wrong on lanes 48-63 next to bf16 MFMA waves); with
+disjoint CU sets: 0 of 240."""
 import hashlib
 import os
 import subprocess

@@ -1,5 +1,9 @@
-"""ONE process, two streams: stream A repeats a kernel of this repository on fixed inputs and checks its output bits,
-stream B keeps the device busy with torch matrix products (no code of this repository).
+"""ONE process, two streams: stream A repeats a kernel on fixed inputs and checks its output bits, stream B keeps the device
+busy with matrix products.  What it showed: next to a skinny bf16 GEMM -- torch's hipBLASLt
+kernel or this repository's -- a packed-f32 instruction whose LOW lane reads the HIGH register of a pair (victims pk_add_hi,
+pk_add_swap; hipcc emits the form in logmel / bn / peak) is wrong on lanes 48-63 in a third of the launches; every other
+victim below, and every victim without the neighbour, is bit-stable.  OFFENDER_PER_ROUND (default 6) = products per 24
+victim launches.
 
     python tools/contention/two_stream.py VICTIM OFFENDER SECONDS
 VICTIM: bn | bn2 | bn_spin0 | logmel | logmel512 | logmel2048 | logmel_dbg (logmel with a per-stage trace) | peak | mm | t_layernorm | t_softmax | t_batchnorm | t_cumsum | t_gelu | t_conv (torch only) | copy4 | copy16 | copy32 | alu_pk | alu_scalar | lds8 | lds64 | conf_2way | conf_1bank | shfl | barrier | sgpr_chain | vgpr_chain | pk_plain | pk_sel | pk_mul_lo | pk_add_swap | pk_add_hi | pk_fma_lo | wide64 | wide128 | wide224 (inflight.hip); OFFENDER: mmbf16 | mmf32 | mmbf16small | mmf32small | mmbf16mid | ewadd (torch) | gemm | knn | mr | wgrad (kernels of this repository) | none"""
