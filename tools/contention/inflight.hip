@@ -211,7 +211,8 @@ template <int MODE>
 __global__ __launch_bounds__(256) void pk_sel_chain(const float *__restrict__ in, float *__restrict__ out, int iters) {
     // MODE 0: no selects; 1: both forms below; 2: only  v_pk_mul_f32 d, d, k op_sel_hi:[1,0]  (broadcast of the LOW register);
     // 3: only  v_pk_add_f32 d, d, c op_sel:[0,1] op_sel_hi:[1,0]  (the pair swapped); 4: only  v_pk_add_f32 d, d, c op_sel:[0,1]
-    // (broadcast of the HIGH register); 5: v_pk_fma_f32 d, d, k, c op_sel_hi:[1,0,1]  (the form in this repository's scan kernel)
+    // (broadcast of the HIGH register); 5: v_pk_fma_f32 d, d, k, c op_sel_hi:[1,0,1]  (the form in this repository's scan kernel);
+    // 6 / 7: v_pk_fma_f32 with the high-register select on the first / the third source
     const int t = blockIdx.x * 256 + threadIdx.x;
     f2 a[8], k = f2{0.9995f, 1.0005f}, c[8];
 #pragma unroll
@@ -224,6 +225,23 @@ __global__ __launch_bounds__(256) void pk_sel_chain(const float *__restrict__ in
         for (int i = 0; i < 8; ++i) {
             if (MODE == 5) {
                 asm volatile("v_pk_fma_f32 %0, %0, %1, %2 op_sel_hi:[1,0,1]" : "+v"(a[i]) : "v"(k), "v"(c[i]));
+                continue;
+            }
+            if (MODE == 6) {                                  // the select on the FIRST source (the form in peak_fwd8)
+                asm volatile("v_pk_fma_f32 %0, %1, %0, %2 op_sel:[1,0,0]" : "+v"(a[i]) : "v"(k), "v"(c[i]));
+                continue;
+            }
+            if (MODE == 8) {                                  // ... on the SECOND source of an fma (the form in peak_bwd8)
+                asm volatile("v_pk_fma_f32 %0, %0, %1, %2 op_sel:[0,1,0]" : "+v"(a[i]) : "v"(k), "v"(c[i]));
+                continue;
+            }
+            if (MODE == 9) {                                  // ... on the second source of a multiply, then a plain add
+                asm volatile("v_pk_mul_f32 %0, %0, %1 op_sel:[0,1]" : "+v"(a[i]) : "v"(k));
+                asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c[i]));
+                continue;
+            }
+            if (MODE == 7) {                                  // the select on the THIRD source
+                asm volatile("v_pk_fma_f32 %0, %0, %1, %2 op_sel:[0,0,1]" : "+v"(a[i]) : "v"(k), "v"(c[i]));
                 continue;
             }
             if (MODE == 1 || MODE == 2) asm volatile("v_pk_mul_f32 %0, %0, %1 op_sel_hi:[1,0]" : "+v"(a[i]) : "v"(k));
@@ -248,6 +266,10 @@ extern "C" int pk_sel_chain_launch(const void *in, void *out, int blocks, int it
         case 3: PKL(3); break;
         case 4: PKL(4); break;
         case 5: PKL(5); break;
+        case 6: PKL(6); break;
+        case 7: PKL(7); break;
+        case 8: PKL(8); break;
+        case 9: PKL(9); break;
         default: return 2;
     }
 #undef PKL

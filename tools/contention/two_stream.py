@@ -6,7 +6,7 @@ victim below, and every victim without the neighbour, is bit-stable.  OFFENDER_P
 victim launches.
 
     python tools/contention/two_stream.py VICTIM OFFENDER SECONDS
-VICTIM: bn | bn2 | bn_spin0 | logmel | logmel512 | logmel2048 | logmel_dbg (logmel with a per-stage trace) | peak | mm | t_layernorm | t_softmax | t_batchnorm | t_cumsum | t_gelu | t_conv (torch only) | copy4 | copy16 | copy32 | alu_pk | alu_scalar | lds8 | lds64 | conf_2way | conf_1bank | shfl | barrier | sgpr_chain | vgpr_chain | pk_plain | pk_sel | pk_mul_lo | pk_add_swap | pk_add_hi | pk_fma_lo | wide64 | wide128 | wide224 (inflight.hip); OFFENDER: mmbf16 | mmf32 | mmbf16small | mmf32small | mmbf16mid | ewadd (torch) | gemm | knn | mr | wgrad (kernels of this repository) | none"""
+VICTIM: bn | bn2 | bn_spin0 | logmel | logmel512 | logmel2048 | logmel_dbg (logmel with a per-stage trace) | peak | mm | t_layernorm | t_softmax | t_batchnorm | t_cumsum | t_gelu | t_conv (torch only) | copy4 | copy16 | copy32 | alu_pk | alu_scalar | lds8 | lds64 | conf_2way | conf_1bank | shfl | barrier | sgpr_chain | vgpr_chain | pk_plain | pk_sel | pk_mul_lo | pk_add_swap | pk_add_hi | pk_fma_lo | pk_fma_hi0 | pk_fma_hi2 | pk_fma_hi1 | pk_mul_hi1 | wide64 | wide128 | wide224 (inflight.hip); OFFENDER: mmbf16 | mmf32 | mmbf16small | mmf32small | mmbf16mid | ewadd (torch) | gemm | knn | mr | wgrad (kernels of this repository) | none"""
 import os
 import sys
 import time
@@ -140,7 +140,7 @@ elif victim in ("conf_2way", "conf_1bank", "shfl"):  # inflight.hip: LDS round t
         rc = cl.lds_conflict_launch(out.data_ptr(), 2048, 60, mode, torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
         assert rc == 0, rc
         return out
-elif victim in ("pk_plain", "pk_sel", "pk_mul_lo", "pk_add_swap", "pk_add_hi", "pk_fma_lo"):         # inflight.hip: packed-f32 chains with / without lane selects on the second source
+elif victim in ("pk_plain", "pk_sel", "pk_mul_lo", "pk_add_swap", "pk_add_hi", "pk_fma_lo", "pk_fma_hi0", "pk_fma_hi2", "pk_fma_hi1", "pk_mul_hi1"):         # inflight.hip: packed-f32 chains with / without lane selects on the second source
     import ctypes
     cl = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libinflight.so"))
     cl.pk_sel_chain_launch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
@@ -149,7 +149,7 @@ elif victim in ("pk_plain", "pk_sel", "pk_mul_lo", "pk_add_swap", "pk_add_hi", "
     def f():
         out = torch.empty(2048 * 256, device=dev)
         rc = cl.pk_sel_chain_launch(src.data_ptr(), out.data_ptr(), 2048, 300,
-                                    ("pk_plain", "pk_sel", "pk_mul_lo", "pk_add_swap", "pk_add_hi", "pk_fma_lo").index(victim),
+                                    ("pk_plain", "pk_sel", "pk_mul_lo", "pk_add_swap", "pk_add_hi", "pk_fma_lo", "pk_fma_hi0", "pk_fma_hi2", "pk_fma_hi1", "pk_mul_hi1").index(victim),
                                     torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
         assert rc == 0, rc
         return out.reshape(2048 * 4, 64)                      # one row per wave: the column is the lane
